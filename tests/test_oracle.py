@@ -1,0 +1,202 @@
+"""Pin the CPU oracle: against golden vectors produced by the reference's own numpy functions
+(tests/golden/make_golden.py) and through the algebraic identities of SURVEY.md section 4."""
+import numpy as np
+import pytest
+
+from oracle import drnmf_oracle as O
+
+
+# ------------------------------------------------------------------ golden vectors (reference)
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("name", ["ed", "kl", "beta"])
+def test_ista_matches_reference_golden(golden, tag, name):
+    g = golden
+    W, x, H0 = g["ista_%s_W" % tag], g["ista_%s_x" % tag], g["ista_%s_H0" % tag]
+    lam1, K = g["ista_%s_lam1" % tag][()], int(g["ista_%s_K" % tag])
+    alph = g["ista_%s_alph" % tag][()] if name == "ed" else g["ista_%s_alph_kl" % tag][()]
+    if name == "ed":
+        H, tr = O.ista_ed(x, W, H0, lam1, alph, K, trace=True)
+    elif name == "kl":
+        H, tr = O.ista_kl(x, W, H0, lam1, alph, K, trace=True)
+    else:
+        H, tr = O.ista_beta(x, W, H0, lam1, alph, K, float(g["ista_beta_value"]), trace=True)
+    ref = g["ista_%s_%s_H" % (tag, name)]
+    assert H.dtype == ref.dtype
+    np.testing.assert_array_equal(H, ref)            # same numpy ops, same order: bit-exact
+    np.testing.assert_allclose(tr, g["ista_%s_%s_trace" % (tag, name)], rtol=2e-6)  # printed %e
+
+
+def test_divergences_match_reference_golden(golden):
+    g = golden
+    np.testing.assert_array_equal(O.kl_div(g["div_x"], g["div_y"]), g["div_kl"])
+    for b in (0., 1., 2., 0.5, 1.5):
+        np.testing.assert_array_equal(O.beta_div(g["div_x"], g["div_y"], b),
+                                      g["div_beta_%s" % str(b).replace(".", "p")])
+
+
+def test_layout_helpers_match_reference_golden(golden):
+    g = golden
+    np.testing.assert_array_equal(O.masked_seqs_to_frames(g["m2f_x"], g["m2f_mask"]), g["m2f_out"])
+    np.testing.assert_array_equal(O.pad_axis_toN_with_constant(g["m2f_x"], 1, 15, -1.),
+                                  g["pad_out"])
+    for ml in (None, 10, 25):
+        x, y, m = O.reshape_and_pad_stacks(g["rps_x_stack"], g["rps_y_stack"], g["rps_fidx"],
+                                           pad_value=-1., maxlen=ml)
+        np.testing.assert_array_equal(x, g["rps_%s_x" % ml])
+        np.testing.assert_array_equal(y, g["rps_%s_y" % ml])
+        np.testing.assert_array_equal(m, g["rps_%s_mask" % ml])
+        # valid frames are a prefix of every sequence (audio_dataset.py:159-161)
+        mm = m[..., 0]
+        assert np.all(np.diff(mm, axis=1) <= 0)
+    mag = (lambda v: np.sqrt(v[:v.shape[0] // 2, :] ** 2 + v[v.shape[0] // 2:, :] ** 2))
+    x, y, m = O.reshape_and_pad_stacks(g["rps_x_stack"], g["rps_y_stack"], g["rps_fidx"],
+                                       transform_x=mag, transform_y=mag, pad_value=-1., maxlen=10)
+    np.testing.assert_array_equal(x, g["rps_mag10_x"])
+
+
+def test_ista_ed_cost_decreases(golden):
+    tr = golden["ista_c_ed_trace"]
+    assert np.all(np.diff(tr[:, 1]) <= 1e-6 * tr[:-1, 1])   # enhance.py:408-417 prints this trace
+
+
+# ------------------------------------------------------------------ cell identities
+def _small(B=3, T=5, F=21, r=6, K=4, untied=("log_D", "log_alph"), untie_alph=False, seed=3,
+           ragged=False):
+    P = O.synth_problem(B, T, F, r, seed=seed, ragged=ragged, density=0.2)
+    N = 2 * r
+    alph = np.float32(N / 4.0)
+    if untie_alph:
+        alph = alph * np.ones((N,), np.float32)
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=alph, lam1=np.float32(0.3))
+    alt, labels = O.build_alt(N, K, params, untied)
+    rng = np.random.default_rng(seed)
+    for k in list(alt):       # make untied copies actually differ
+        if k.startswith("log_D_") or k.startswith("log_alph_"):
+            alt[k] = (alt[k] + 0.05 * rng.standard_normal(alt[k].shape)).astype(np.float32)
+    return P, alt, labels, N, K
+
+
+@pytest.mark.parametrize("untie_alph", [False, True])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_gram_form_equals_factored_form(untie_alph, ragged):
+    P, alt, labels, N, K = _small(untie_alph=untie_alph, ragged=ragged)
+    Wk, Uk, bk, Sk = O.maps_dense(alt, labels, K, N)
+    hd = O.cell_forward_dense(P["X"], Wk, Uk, bk, Sk, P["log_h0"])
+    hf = O.cell_forward_factored(P["X"], O.maps_factored(alt, labels, K), O.u_scalars(alt),
+                                 P["log_h0"])
+    assert np.max(np.abs(hd - hf)) < 1e-12 * max(1.0, np.max(np.abs(hd)))
+    hd32 = O.cell_forward_dense(P["X"], *[[m.astype(np.float32) for m in L]
+                                          for L in (Wk, Uk, bk, Sk)], P["log_h0"],
+                                dtype=np.float32)
+    assert np.max(np.abs(hd32 - hd)) < 1e-4 * max(1.0, np.max(np.abs(hd)))
+
+
+def test_return_all_hidden_last_block_is_output():
+    P, alt, labels, N, K = _small()
+    Wk, Uk, bk, Sk = O.maps_dense(alt, labels, K, N)
+    h = O.cell_forward_dense(P["X"], Wk, Uk, bk, Sk, P["log_h0"])
+    ha = O.cell_forward_dense(P["X"], Wk, Uk, bk, Sk, P["log_h0"], return_all_hidden=True)
+    assert ha.shape[-1] == K * N
+    np.testing.assert_allclose(ha[..., -N:], h, rtol=0, atol=0)
+    hfa = O.cell_forward_factored(P["X"], O.maps_factored(alt, labels, K), O.u_scalars(alt),
+                                  P["log_h0"], return_all_hidden=True)
+    np.testing.assert_allclose(hfa, ha, atol=1e-12)
+
+
+def test_cell_T1_is_ista_ed_from_layer0():
+    """With the U-term zeroed, layers 1..K-1 of one frame are ista_ed with K-1 iterations started
+    from h^(0); tied parameters."""
+    P, alt, labels, N, K = _small(T=1, untied=())
+    layers = O.maps_factored(alt, labels, K)
+    x = P["X"][:, :1].astype(np.float64)
+    h = O.cell_forward_factored(x, layers, (1.0, 0.0, 0.0), P["log_h0"])[:, 0]
+    Dn, ia, b = layers[0]
+    p = O.softplus(P["log_h0"].astype(np.float64))[None, :]
+    h0 = np.maximum(p + (x[:, 0] @ Dn) * ia + b, 0)
+    alph = 1.0 / ia[0]
+    lam1 = -b[0] * alph
+    H = O.ista_ed(x[:, 0].T, Dn, h0.T, lam1, alph, K - 1)
+    np.testing.assert_allclose(h, H.T, rtol=1e-12, atol=1e-13)
+
+
+def test_masked_steps_repeat_output_and_hold_state():
+    P, alt, labels, N, K = _small(B=2, T=6)
+    X = P["X"].copy()
+    X[0, 3:] = -1.0          # row 0: valid prefix of 3
+    X[1, :2] = -1.0          # row 1: masked head (outside the reference's layout contract)
+    layers, u = O.maps_factored(alt, labels, K), O.u_scalars(alt)
+    h = O.cell_forward_factored(X, layers, u, P["log_h0"])
+    np.testing.assert_array_equal(h[0, 3], h[0, 2])
+    np.testing.assert_array_equal(h[0, 5], h[0, 2])
+    np.testing.assert_array_equal(h[1, 0], np.zeros(N))      # zeros before the first valid step
+    # state was held at h0 through the masked head: equals a run on the valid suffix alone
+    h_suffix = O.cell_forward_factored(X[1:2, 2:], layers, u, P["log_h0"])
+    np.testing.assert_allclose(h[1, 2:], h_suffix[0], atol=1e-14)
+
+
+def test_u_scalars_detects_trained_U():
+    P, alt, labels, N, K = _small()
+    assert O.u_scalars(alt) is not None
+    u0d, u0o, uko = O.u_scalars(alt, np.float32)
+    assert abs(u0d - 1.0) < 1e-6 and abs(u0o - 1e-7) < 1e-9 and abs(uko - 1e-7) < 1e-9
+    alt2 = dict(alt)
+    alt2["log_Uk"] = alt["log_Uk"].copy()
+    alt2["log_Uk"][1, 2] += 0.5
+    assert O.u_scalars(alt2) is None
+
+
+# ------------------------------------------------------------------ head / loss / MU / STFT
+def test_head_mask_range_and_formula():
+    rng = np.random.default_rng(0)
+    h = np.abs(rng.standard_normal((2, 3, 8)))
+    kc, kn = rng.standard_normal((4, 5)), rng.standard_normal((4, 5))
+    m, A, Bn = O.head_forward(h, kc, kn)
+    assert np.all(m > 0) and np.all(m <= 1)
+    np.testing.assert_allclose(m, (1e-7 + A) / (1e-7 + A + Bn), rtol=1e-12)
+    m2, A2, B2 = O.head_forward(h, kc, kn, square=True)
+    np.testing.assert_allclose(A2, A * A)
+
+
+def test_loss_masked_mean():
+    rng = np.random.default_rng(1)
+    x, m, y = rng.random((2, 4, 3)), rng.random((2, 4, 3)), rng.random((2, 4, 3))
+    w = np.array([[1, 1, 1, 0], [1, 0, 0, 0]], float)
+    L = O.loss_mse_of_masked(x, m, y, w)
+    ref = np.sum(np.mean((x * m - y) ** 2, -1) * w) / w.sum()
+    np.testing.assert_allclose(L, ref, rtol=1e-13)
+    L2 = O.loss_mse_of_masked(x, m, y, w, norm="keras_mask_and_weight")
+    np.testing.assert_allclose(L2, ref / w.mean(), rtol=1e-13)
+
+
+def test_mu_fixed_point_and_monotone():
+    rng = np.random.default_rng(2)
+    F, N, n = 20, 8, 15
+    W = rng.random((F, N))
+    V = W @ (rng.random((N, n)) * (rng.random((N, n)) < 0.4)) + 1e-3
+    H, Wn, tr = O.mu_infer(V, W, rng.random((N, n)), 0.1, 200, trace=True)
+    assert np.all(np.diff(tr[:, 1]) <= 1e-9 * tr[:-1, 1])
+    H2, _ = O.mu_infer(V, Wn, H, 0.1, 1)
+    assert np.max(np.abs(H2 - H)) < 5e-3 * np.max(H)
+    irm = O.snmf_irm(Wn, H, N // 2)
+    assert np.all(irm >= 0) and np.all(irm < 1)
+
+
+def test_stft_framing_and_magnitude():
+    rng = np.random.default_rng(4)
+    N, hop = 64, 16
+    x = rng.standard_normal(1000)
+    w = O.sqrt_hann(N)
+    S = O.stft_mc(x, N, hop, w)
+    assert S.shape == (N // 2 + 1, O.stft_frames(1000, N, hop))
+    # frame j covers padded samples [j*hop, j*hop+N); first N samples are zeros (util.py:189-190)
+    xp = np.concatenate([np.zeros(N), x, np.zeros(int(np.ceil(1000 / hop)) * hop - 1000),
+                         np.zeros(N)])
+    j = 7
+    ref = np.fft.rfft(w * xp[j * hop:j * hop + N])
+    np.testing.assert_allclose(O.stft_mag(x, N, hop, w)[:, j], np.abs(ref), atol=1e-12)
+    np.testing.assert_allclose(S[:, j], np.conj(ref), atol=1e-12)
+    assert np.all(O.stft_mag(x, N, hop, w)[:, 0] == 0)      # all-zero leading frame
+    # sqrt-Hann is COLA at hop = N/4 for the squared window (istft_noDiv relies on it)
+    ola = sum(np.roll(w.astype(np.float64) ** 2, k * hop) for k in range(N // hop))
+    np.testing.assert_allclose(ola, ola[0], rtol=1e-6)
