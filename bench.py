@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the DR-NMF hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): K=25 unrolled SNMF forward (recurrent cell + mask head),
+dictionary 513x2000 (1000 speech + 1000 noise atoms, untied per layer as the shipped configs do),
+synthetic 513x2000-frame spectrograms, batch 64 per GPU.  One step = one forward over the batch,
+inputs resident in HBM.  Utterances shard over GPUs with no data-path collective (weak scaling:
+64 utterances per GPU).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=2000)
+    ap.add_argument("--bins", type=int, default=513)
+    ap.add_argument("--r", type=int, default=1000, help="atoms per source (N = 2r)")
+    ap.add_argument("--layers", type=int, default=25)
+    ap.add_argument("--tied", action="store_true", help="tie log_D/log_alph across layers")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0,
+                    help="frame-steps of the CPU baseline sample (0 = auto, ~15-25 s)")
+    return ap.parse_args()
+
+
+def synth_on_device(torch, dev, B, T, F, r, seed):
+    """SURVEY.md section 8d generator; the dictionary comes from numpy PCG64(7654), the
+    activations/noise from torch's generator on the device (256M draws)."""
+    N = 2 * r
+    rng = np.random.Generator(np.random.PCG64(7654))
+    W = rng.random((F, N)) ** 4
+    W = (W / np.sqrt(np.sum(W * W, axis=0, keepdims=True))).astype(np.float32)
+    log_h0 = rng.uniform(-0.05, 0.05, N).astype(np.float32)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    Wt = torch.from_numpy(W).to(dev)
+    X = torch.empty((B, T, F), dtype=torch.float32, device=dev)
+    for b in range(B):
+        Ht = (torch.rand((T, N), generator=g, device=dev) < 0.02) * \
+            torch.rand((T, N), generator=g, device=dev) * 5.0
+        X[b] = Ht @ Wt.t() + 0.01 * torch.rand((T, F), generator=g, device=dev)
+    return W, log_h0, X
+
+
+def cpu_baseline(F, r, K, B, frames, tied):
+    """The reference's op graph (dense p.U_k, materialised Gram h.S_k, x.Wk_k, bias+relu, K layers
+    per frame inside a loop over time; custom_layers.py:361-369 + enhance.py:161-204) restated in
+    numpy fp32 (oracle/), timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import drnmf_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    N = 2 * r
+    P = O.synth_problem(B, max(frames, 1), F, r, seed=7654)
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(400.0 if r >= 1000 else 50.0), lam1=np.float32(1.0))
+    alt, labels = O.build_alt(N, K, params, () if tied else ("log_D", "log_alph"))
+    t0 = time.perf_counter()
+    Wk, Uk, bk, Sk = O.maps_dense(alt, labels, K, N, dtype=np.float32)
+    t_maps = time.perf_counter() - t0
+    if frames <= 0:      # auto-size: probe one frame-step, aim at ~15 s
+        t0 = time.perf_counter()
+        O.cell_forward_dense(P["X"][:, :1], Wk, Uk, bk, Sk, P["log_h0"], dtype=np.float32)
+        t1 = time.perf_counter() - t0
+        frames = int(max(2, min(200, 15.0 / max(t1, 1e-3))))
+        P = O.synth_problem(B, frames, F, r, seed=7654)
+    t0 = time.perf_counter()
+    O.cell_forward_dense(P["X"], Wk, Uk, bk, Sk, P["log_h0"], dtype=np.float32)
+    t_dense = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.cell_forward_factored(P["X"], O.maps_factored(alt, labels, K, np.float32),
+                            O.u_scalars(alt, np.float32), P["log_h0"], dtype=np.float32)
+    t_fact = time.perf_counter() - t0
+    return {
+        "value": B * frames / t_dense, "unit": "frames/s", "cores": int(threads), "kind": "port",
+        "sample": "numpy fp32 restatement of the reference op graph (dense U, Gram S, per-step "
+                  "GEMMs) on %d utterances x %d frames of the same workload (recurrent cell only; "
+                  "Gram/matrix build %.1f s excluded); factored form on the same sample: %.0f "
+                  "frames/s" % (B, frames, t_maps, B * frames / t_fact),
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import __graft_entry__ as G
+    G.build()
+    from drnmf_amd import layers
+
+    B, T, F, r, K = a.batch, a.frames, a.bins, a.r, a.layers
+    N = 2 * r
+    W, log_h0, X = synth_on_device(torch, dev, B, T, F, r, seed=7654 + rank)
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K, W=W,
+             alph=400.0 if r >= 1000 else 50.0, lam1=1.0, params_trainable=["log_D", "log_alph"])
+    if not a.tied:
+        p["params_untied"] = ["log_D", "log_alph"]
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.cell.log_h0.copy_(torch.from_numpy(log_h0))
+    h_buf = torch.empty((B, T, N), dtype=torch.float32, device=dev)
+    m_buf = torch.empty((B, T, F), dtype=torch.float32, device=dev)
+    from drnmf_amd import ops
+
+    def step():
+        h = model.cell.call(X, mask_value=-1., out=h_buf)
+        ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    ev_ms = e0.elapsed_time(e1)
+
+    ok = bool(torch.isfinite(m_buf).all().item()) and float(m_buf.min()) > 0.0
+    frames_total = world * B * T * a.steps
+    value = frames_total / wall
+    # algorithmic MFMA work per frame: fwd = 4*F*N*K
+    flops_per_frame = 4.0 * F * N * K
+    achieved = (B * T * a.steps) * flops_per_frame / (ev_ms * 1e-3) / 1e12
+    out = {
+        "metric": "STFT frames/sec (K=%d unrolled DR-NMF forward, %d-bin x %d-frame)" % (K, F, T),
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: K=%d unrolled SNMF forward (recurrent cell + "
+                               "mask head), W %dx%d, %s log_D/log_alph, batch %d x %d frames per "
+                               "GPU" % (K, F, N, "tied" if a.tied else "untied", B, T),
+                   "B_per_gpu": B, "T": T, "F": F, "N": N, "K": K, "untied": not a.tied},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "whole forward (all launches of one step), rank 0, HIP events on "
+                               "the launch stream"},
+        "finite_positive_masks": ok,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(F, r, K, B, a.cpu_frames, a.tied)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

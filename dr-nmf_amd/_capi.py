@@ -1,0 +1,95 @@
+"""ctypes binding of libdrnmf.so (C ABI in include/drnmf.h).
+
+The library is the product path: there is NO fallback.  If the shared object is missing or a
+call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdrnmf.so")
+
+OK = 0
+DIV_ED, DIV_KL, DIV_BETA = 0, 1, 2
+
+
+class CellDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "T", "F", "N", "K", "n_D", "n_alph", "alph_len", "n_lam",
+                 "return_all_hidden")]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_DP = C.POINTER(CellDesc)
+
+# name -> (restype, argtypes); mirrors include/drnmf.h one to one
+SIGNATURES = {
+    "drnmf_version": (_i32, []),
+    "drnmf_create": (_i32, [C.POINTER(_vp), _i32]),
+    "drnmf_destroy": (_i32, [_vp]),
+    "drnmf_last_error": (C.c_char_p, [_vp]),
+    "drnmf_params_bytes": (_sz, [_DP]),
+    "drnmf_prepare_params": (_i32, [_vp, _DP, _vp, _vp, _vp, _vp, _vp]),
+    "drnmf_cell_workspace_bytes": (_sz, [_DP]),
+    "drnmf_cell_forward": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _sz,
+                                  _vp]),
+    "drnmf_padded_f": (_i32, [_i32]),
+    "drnmf_head_forward": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp,
+                                  _vp, _vp, _vp, _vp]),
+    "drnmf_ista_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "drnmf_ista_forward": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp,
+                                  _vp, _vp, _sz, _vp]),
+    "drnmf_mu_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "drnmf_mu_forward": (_i32, [_vp, _i64, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _sz, _vp]),
+    "drnmf_stft_frames": (_i32, [_i64, _i32, _i32]),
+    "drnmf_stft_mag": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+}
+
+_lib = None
+_handles = {}
+
+
+class DrnmfError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdrnmf.so (once).  Raises ImportError with the build command if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libdrnmf.so not found at %s -- build it with `python dr-nmf_amd/build.py` "
+                "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def handle(device=0):
+    """One library handle per device per process."""
+    if device not in _handles:
+        L = lib()
+        h = _vp()
+        rc = L.drnmf_create(C.byref(h), int(device))
+        if rc != OK:
+            raise DrnmfError("drnmf_create(device=%d) failed (%d): %s" %
+                             (device, rc, L.drnmf_last_error(None).decode()))
+        _handles[device] = h
+    return _handles[device]
+
+
+def check(rc, h, what):
+    if rc != OK:
+        msg = lib().drnmf_last_error(h).decode(errors="replace")
+        exc = ValueError if rc in (-1, -2, -4) else DrnmfError
+        raise exc("%s failed (%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else _vp(t.data_ptr())

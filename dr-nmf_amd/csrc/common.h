@@ -1,0 +1,78 @@
+// Shared host/device helpers for libdrnmf.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/drnmf.h"
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// v_mfma_f32_16x16x4_f32: D[i][j] += sum_{k<4} A[i][k] B[k][j]
+//   lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+//   result register v of lane l is D[i = 4*(l>>4) + v][j = l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// padded dims used by every kernel: batch rows to 16 (one MFMA M-tile), bins to 16 (one MFMA
+// tile along F), atoms to 32 (one workgroup's atom block)
+static inline int pad_b(int B) { return round_up(B, 16); }
+static inline int pad_f(int F) { return round_up(F, 16); }
+static inline int pad_n(int N) { return round_up(N, 32); }
+
+struct GraphEntry {
+    std::vector<uint64_t> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct drnmf_handle_s {
+    int device = 0;
+    char err[512] = {0};
+    std::vector<GraphEntry> graphs;
+};
+
+extern char g_create_err[512];
+
+#define DRNMF_FAIL(h, code, ...)                                  \
+    do {                                                          \
+        if (h) snprintf((h)->err, sizeof((h)->err), __VA_ARGS__); \
+        return (code);                                            \
+    } while (0)
+
+#define DRNMF_HIP(h, expr)                                                               \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            DRNMF_FAIL(h, DRNMF_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                 \
+                       hipGetErrorString(e_), __FILE__, __LINE__);                       \
+        }                                                                                \
+    } while (0)
+
+// params block layout (see drnmf_prepare_params)
+struct ParamsLayout {
+    int Fp, Np;
+    size_t off_dn, off_colnorm, off_inv_alpha, off_bias, total;
+};
+static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
+    ParamsLayout L;
+    L.Fp = pad_f(d->F);
+    L.Np = pad_n(d->N);
+    size_t o = 0;
+    L.off_dn = o;        o += (size_t)d->n_D * L.Fp * L.Np * sizeof(float);
+    L.off_colnorm = o;   o += round_up_sz((size_t)d->n_D * L.Np * sizeof(float), 256);
+    L.off_inv_alpha = o; o += round_up_sz((size_t)d->K * L.Np * sizeof(float), 256);
+    L.off_bias = o;      o += round_up_sz((size_t)d->K * L.Np * sizeof(float), 256);
+    L.total = o;
+    return L;
+}
+
+int validate_cell_desc(drnmf_handle_t h, const drnmf_cell_desc_t* d);

@@ -1,0 +1,189 @@
+// Mask head on gfx950: the two non-negative reconstructions and the ratio mask in one kernel.
+//
+// Reference: H_clean / H_noise slices + TimeDistributed(DenseNonNegW) x2 (custom_layers.py:23-29;
+// enhance.py:277-292), optional 'square' (enhance.py:294-300), DivideAbyAplusB
+// (custom_layers.py:41-45):   A = h[:, :r] exp(Kc),  Bn = h[:, r:] exp(Kn),
+//                             mask = exp(log(1e-7 + A) - log(1e-7 + A + Bn)).
+// Frames are independent here, so this is a plain large-M GEMM pair (M = B*T rows) with both
+// accumulators kept in registers and the mask computed in the epilogue: A and Bn never touch
+// HBM unless the caller asks for them.
+#include "common.h"
+
+namespace {
+
+// exp of the log-domain kernels into one zero-padded block: ecat[seg][k][f], seg 0 = clean,
+// seg 1 = noise, k < rp = round_up(r,16), f < Fp.
+__global__ void __launch_bounds__(256)
+head_exp_kernel(const float* __restrict__ kc, const float* __restrict__ kn,
+                float* __restrict__ ecat, int r, int rp, int F, int Fp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t tot = (size_t)2 * rp * Fp;
+    if (i >= tot) return;
+    const int f = (int)(i % Fp);
+    const int k = (int)((i / Fp) % rp);
+    const int seg = (int)(i / ((size_t)Fp * rp));
+    float v = 0.f;
+    if (k < r && f < F) v = expf((seg ? kn : kc)[(size_t)k * F + f]);
+    ecat[i] = v;
+}
+
+struct HeadArgs {
+    const float* hidden;
+    const float* ecat;
+    float* mask;
+    float* A_out;
+    float* Bn_out;
+    int64_t rows, ld_h;
+    int h_off, F, Fp, r, rp, square;
+};
+
+// workgroup = 4 waves x 32 rows; each wave owns 2 row tiles x FT bin tiles x {A, Bn}.
+template <int FT, bool ALIGNED>
+__global__ void __launch_bounds__(256) head_kernel(const HeadArgs a) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, q = l >> 4;
+    const int64_t rowbase = (int64_t)blockIdx.x * 128 + w * 32;
+    const int f0 = blockIdx.y * FT * 16;
+    if (rowbase >= a.rows) return;
+
+    const float* hrow[2];
+    bool rok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int64_t row = rowbase + 16 * mt + j;
+        rok[mt] = row < a.rows;
+        if (!rok[mt]) row = a.rows - 1;   // clamp: loaded but never stored
+        hrow[mt] = a.hidden + row * a.ld_h + a.h_off;
+    }
+    bool fok[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) fok[ft] = f0 + 16 * ft < a.Fp;
+
+    f32x4 acc[2][2][FT];   // [segment][row tile][bin tile]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) acc[s][mt][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.rp / 16;
+
+    auto load_a = [&](int seg, int c, f32x4 (&av)[2]) {
+        const int k = 16 * c + 4 * q;   // within the segment
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float* p = hrow[mt] + (size_t)seg * a.r + k;
+            if (ALIGNED && k + 3 < a.r) {
+                av[mt] = *(const f32x4*)p;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[mt][e] = (k + e < a.r) ? p[e] : 0.f;
+            }
+        }
+    };
+    auto load_b = [&](int seg, int c, float (&bv)[4][FT]) {
+        const float* p = a.ecat + ((size_t)seg * a.rp + 16 * c + 4 * q) * a.Fp + f0 + j;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft)
+                bv[s][ft] = fok[ft] ? p[(size_t)s * a.Fp + 16 * ft] : 0.f;
+    };
+
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        f32x4 av[2], avn[2];
+        float bv[4][FT], bvn[4][FT];
+        load_a(seg, 0, av);
+        load_b(seg, 0, bv);
+        for (int c = 0; c < nk; ++c) {
+            if (c + 1 < nk) {   // software pipeline: next chunk's loads fly under this chunk's MFMAs
+                load_a(seg, c + 1, avn);
+                load_b(seg, c + 1, bvn);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft)
+                        acc[seg][mt][ft] = mfma16(av[mt][s], bv[s][ft], acc[seg][mt][ft]);
+            if (c + 1 < nk) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) av[mt] = avn[mt];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) bv[s][ft] = bvn[s][ft];
+            }
+        }
+    }
+
+    // epilogue: lane (j, q) holds rows 4q+v, bin column j of each tile
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            const int f = f0 + 16 * ft + j;
+            if (f >= a.F) continue;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t row = rowbase + 16 * mt + 4 * q + v;
+                if (row >= a.rows) continue;
+                float A = acc[0][mt][ft][v], Bn = acc[1][mt][ft][v];
+                if (a.square) { A = A * A; Bn = Bn * Bn; }
+                const size_t o = (size_t)row * a.F + f;
+                a.mask[o] = expf(logf(1e-7f + A) - logf(1e-7f + A + Bn));
+                if (a.A_out) a.A_out[o] = A;
+                if (a.Bn_out) a.Bn_out[o] = Bn;
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int32_t drnmf_padded_f(int32_t F) { return F > 0 ? pad_f(F) : 0; }
+
+extern "C" int32_t drnmf_head_forward(drnmf_handle_t h, int64_t rows, int32_t F, int32_t r,
+                                      const float* hidden, int64_t ld_h, int32_t h_off,
+                                      const float* kernel_clean, const float* kernel_noise,
+                                      int32_t square, float* mask, float* A_out, float* Bn_out,
+                                      float* ecat, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (rows <= 0 || F <= 0 || r <= 0 || ld_h < 2 * (int64_t)r + h_off || h_off < 0)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "head_forward: bad shape rows=%lld F=%d r=%d ld_h=%lld",
+                   (long long)rows, F, r, (long long)ld_h);
+    if (!hidden || !kernel_clean || !kernel_noise || !mask || !ecat)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "head_forward: NULL pointer argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int Fp = pad_f(F), rp = round_up(r, 16);
+    {
+        const size_t tot = (size_t)2 * rp * Fp;
+        hipLaunchKernelGGL(head_exp_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                           stream, kernel_clean, kernel_noise, ecat, r, rp, F, Fp);
+    }
+    HeadArgs a;
+    a.hidden = hidden; a.ecat = ecat; a.mask = mask; a.A_out = A_out; a.Bn_out = Bn_out;
+    a.rows = rows; a.ld_h = ld_h; a.h_off = h_off; a.F = F; a.Fp = Fp; a.r = r; a.rp = rp;
+    a.square = square;
+    const bool aligned = (ld_h % 4 == 0) && (h_off % 4 == 0) && (r % 4 == 0) &&
+                         (((uintptr_t)hidden & 15) == 0);
+    const int nt = Fp / 16;
+    // bin tiles per wave: the value in {4,3,2} that wastes the fewest padded tiles
+    int FT = 4, best = round_up(nt, 4);
+    if (round_up(nt, 3) < best) { FT = 3; best = round_up(nt, 3); }
+    if (round_up(nt, 2) < best) { FT = 2; }
+    dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((nt + FT - 1) / FT));
+#define LAUNCH_HEAD(FT_, AL_) \
+    hipLaunchKernelGGL((head_kernel<FT_, AL_>), grid, dim3(256), 0, stream, a)
+    if (aligned) {
+        if (FT == 4) LAUNCH_HEAD(4, true); else if (FT == 3) LAUNCH_HEAD(3, true);
+        else LAUNCH_HEAD(2, true);
+    } else {
+        if (FT == 4) LAUNCH_HEAD(4, false); else if (FT == 3) LAUNCH_HEAD(3, false);
+        else LAUNCH_HEAD(2, false);
+    }
+#undef LAUNCH_HEAD
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}

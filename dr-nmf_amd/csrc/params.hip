@@ -1,0 +1,146 @@
+// Handle management + parameter maps (log-domain SNMF parameters -> prepared per-layer block).
+// Reference: build_alt's maps_from_alt (enhance.py:161-204), evaluated in
+// SimpleDeepRNN.build (custom_layers.py:234-287).
+#include "common.h"
+
+char g_create_err[512] = {0};
+
+extern "C" int32_t drnmf_version(void) { return DRNMF_VERSION; }
+
+extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
+    if (!out) return DRNMF_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        snprintf(g_create_err, sizeof(g_create_err), "no HIP device visible (%s)",
+                 e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return DRNMF_ERR_HIP;
+    }
+    if (device < 0 || device >= n) {
+        snprintf(g_create_err, sizeof(g_create_err), "device %d out of range [0,%d)", device, n);
+        return DRNMF_ERR_INVALID_ARG;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        snprintf(g_create_err, sizeof(g_create_err), "hipGetDeviceProperties: %s",
+                 hipGetErrorString(e));
+        return DRNMF_ERR_HIP;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_create_err, sizeof(g_create_err),
+                 "device %d is %s; libdrnmf is built for gfx950 (MI355X) only", device,
+                 prop.gcnArchName);
+        return DRNMF_ERR_UNSUPPORTED;
+    }
+    drnmf_handle_t h = new (std::nothrow) drnmf_handle_s();
+    if (!h) return DRNMF_ERR_HIP;
+    h->device = device;
+    *out = h;
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    delete h;
+    return DRNMF_OK;
+}
+
+extern "C" const char* drnmf_last_error(drnmf_handle_t h) { return h ? h->err : g_create_err; }
+
+int validate_cell_desc(drnmf_handle_t h, const drnmf_cell_desc_t* d) {
+    if (!d) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "desc is NULL");
+    if (d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0 || d->K <= 0)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "B,T,F,N,K must be positive (got %d,%d,%d,%d,%d)",
+                   d->B, d->T, d->F, d->N, d->K);
+    if ((d->n_D != 1 && d->n_D != d->K) || (d->n_alph != 1 && d->n_alph != d->K) ||
+        (d->n_lam != 1 && d->n_lam != d->K))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "n_D/n_alph/n_lam must be 1 or K");
+    if (d->alph_len != 1 && d->alph_len != d->N)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "alph_len must be 1 or N");
+    if ((int64_t)d->B * d->T * (int64_t)d->N * (d->return_all_hidden ? d->K : 1) >= (1ll << 40))
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "output tensor too large");
+    return DRNMF_OK;
+}
+
+extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
+    if (!d || d->F <= 0 || d->N <= 0 || d->K <= 0 || d->n_D <= 0) return 0;
+    return params_layout(d).total;
+}
+
+// One thread per (stored layer, atom column): pass 1 accumulates sum_f exp(log_D)^2 in f order,
+// pass 2 writes exp(log_D)/sqrt(sum) -- enhance.py:177-178 / 190-191.  Columns are contiguous
+// across lanes, so every row read/write is a coalesced 256-byte segment.  Padded rows/columns
+// are written as zeros.
+__global__ void __launch_bounds__(256)
+prep_dict_kernel(const float* __restrict__ log_D, float* __restrict__ Dn,
+                 float* __restrict__ colnorm, int F, int N, int Fp, int Np) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int layer = blockIdx.y;
+    if (n >= Np) return;
+    float* dn = Dn + (size_t)layer * Fp * Np;
+    if (n >= N) {
+        for (int f = 0; f < Fp; ++f) dn[(size_t)f * Np + n] = 0.f;
+        colnorm[(size_t)layer * Np + n] = 1.f;
+        return;
+    }
+    const float* ld = log_D + (size_t)layer * F * N;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float e = expf(ld[(size_t)f * N + n]);
+        s = fmaf(e, e, s);
+    }
+    const float nrm = sqrtf(s);
+    colnorm[(size_t)layer * Np + n] = nrm;
+    for (int f = 0; f < F; ++f) dn[(size_t)f * Np + n] = expf(ld[(size_t)f * N + n]) / nrm;
+    for (int f = F; f < Fp; ++f) dn[(size_t)f * Np + n] = 0.f;
+}
+
+// 1/alpha[n] and b[n] = -lam/alpha[n] per layer (enhance.py:187-194, 201-203).  Padded atoms get
+// a bias of -1e30 so that relu() pins them to exactly zero.
+__global__ void __launch_bounds__(256)
+prep_scalars_kernel(const float* __restrict__ log_alph, const float* __restrict__ log_lam1,
+                    float* __restrict__ inv_alpha, float* __restrict__ bias, int N, int Np,
+                    int n_alph, int alph_len, int n_lam) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (n >= Np) return;
+    float ia = 0.f, b = -1e30f;
+    if (n < N) {
+        const float* la = log_alph + (size_t)(n_alph == 1 ? 0 : k) * alph_len;
+        const float al = expf(la[alph_len == 1 ? 0 : n]);
+        const float lam = expf(log_lam1[n_lam == 1 ? 0 : k]);
+        ia = 1.0f / al;
+        b = -lam / al;
+    }
+    inv_alpha[(size_t)k * Np + n] = ia;
+    bias[(size_t)k * Np + n] = b;
+}
+
+extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_t* d,
+                                        const float* log_D, const float* log_alph,
+                                        const float* log_lam1, void* params, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    int rc = validate_cell_desc(h, d);
+    if (rc) return rc;
+    if (!log_D || !log_alph || !log_lam1 || !params)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "prepare_params: NULL pointer argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const ParamsLayout L = params_layout(d);
+    char* base = (char*)params;
+    dim3 g1((L.Np + 255) / 256, d->n_D);
+    hipLaunchKernelGGL(prep_dict_kernel, g1, dim3(256), 0, stream, log_D,
+                       (float*)(base + L.off_dn), (float*)(base + L.off_colnorm), d->F, d->N,
+                       L.Fp, L.Np);
+    dim3 g2((L.Np + 255) / 256, d->K);
+    hipLaunchKernelGGL(prep_scalars_kernel, g2, dim3(256), 0, stream, log_alph, log_lam1,
+                       (float*)(base + L.off_inv_alpha), (float*)(base + L.off_bias), d->N, L.Np,
+                       d->n_alph, d->alph_len, d->n_lam);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}

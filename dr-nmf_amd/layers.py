@@ -1,0 +1,510 @@
+"""Host-side mirror of the reference's Keras-layer call surface for the DR-NMF hot path.
+
+Same names, constructor arguments and protocol as the reference (custom_layers.py; enhance.py:
+139-317) so an enhance.py-style driver can switch imports:
+
+    from drnmf_amd.layers import (SimpleDeepRNN, DenseNonNegW, DivideAbyAplusB,
+                                  divide_A_by_AplusB, build_alt, build_unfolded_snmf)
+
+Weights live in torch tensors on the GPU (containers only); every forward goes through the
+hand-written HIP kernels in libdrnmf.so.  There is no CPU/oracle fallback: configurations the
+kernels do not cover raise NotImplementedError.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------
+# build_alt  (enhance.py:139-206)
+# ------------------------------------------------------------------------------------------
+class AltMaps(dict):
+    """maps_from_alt as returned by build_alt: {'U','S','W','b'} -> per-layer callables, plus the
+    per-layer parameter labels so SimpleDeepRNN can dispatch them to the fused kernels."""
+    labels_per_k = None
+    output_dim = None
+    K_layers = None
+
+
+def _xp(v):
+    return torch if isinstance(v, torch.Tensor) else np
+
+
+def _unit_cols(a_logD):
+    xp = _xp(a_logD)
+    D = xp.exp(a_logD)
+    return D / xp.sqrt((D * D).sum(0, keepdims=True) if xp is np else (D * D).sum(0, keepdim=True))
+
+
+def build_alt(output_dim, K_layers, params, params_untied=[]):
+    """enhance.py:139-206.  params = {'W','U1','Uk','alph','lam1'} (numpy).  Returns
+    (alt_params, maps_from_alt).  The maps are plain callables on a dict of numpy arrays or torch
+    tensors (row-vector convention, as the reference's Theano lambdas)."""
+    f32 = np.float32
+    alt_params = OrderedDict()
+    alt_params['log_D'] = np.log(f32(1e-7) + np.asarray(params['W'], f32))        # :147
+    alt_params['log_U1'] = np.log(f32(1e-7) + np.asarray(params['U1'], f32))
+    alt_params['log_Uk'] = np.log(f32(1e-7) + np.asarray(params['Uk'], f32))
+    alt_params['log_alph'] = np.log(f32(1e-7) + np.asarray(params['alph'], f32))
+    alt_params['log_lam1'] = np.log(f32(1e-7) + np.asarray(params['lam1'], f32))
+
+    labels_per_k = {}
+    for name in ['log_D', 'log_alph', 'log_lam1']:                                # :150-159
+        if name in params_untied:
+            labels_per_k[name] = [name + ('_%d' % k) for k in range(K_layers)]
+            v = alt_params.pop(name)
+            for k in range(K_layers):
+                alt_params[name + ('_%d' % k)] = np.array(v, copy=True)
+        else:
+            labels_per_k[name] = [name] * K_layers
+
+    maps = AltMaps()
+    maps.labels_per_k, maps.output_dim, maps.K_layers = labels_per_k, output_dim, K_layers
+
+    def _t(m):
+        return m.T if isinstance(m, np.ndarray) else m.t()
+
+    maps['U'] = [lambda a: _t(_xp(a['log_U1']).exp(a['log_U1']))]                # :163
+    maps['U'] += [(lambda a: _t(_xp(a['log_Uk']).exp(a['log_Uk'])))] * (K_layers - 1)   # :165-167
+
+    def make_S(k):
+        lD, lA = labels_per_k['log_D'][k], labels_per_k['log_alph'][k]
+
+        def Sk(a):                                                                # :172-181
+            Dn = _unit_cols(a[lD])
+            xp = _xp(Dn)
+            eye = np.eye(output_dim, dtype=np.float32) if xp is np else \
+                torch.eye(output_dim, dtype=Dn.dtype, device=Dn.device)
+            return _t(eye - _t(Dn / xp.exp(a[lA])) @ Dn)
+        return Sk
+
+    def make_W(k):
+        lD, lA = labels_per_k['log_D'][k], labels_per_k['log_alph'][k]
+        return lambda a: _unit_cols(a[lD]) / _xp(a[lA]).exp(a[lA])               # :187-194
+
+    def make_b(k):
+        lA, lL = labels_per_k['log_alph'][k], labels_per_k['log_lam1'][k]
+
+        def bk(a):                                                                # :201-203
+            xp = _xp(a[lA])
+            ones = np.ones((output_dim,), np.float32) if xp is np else \
+                torch.ones(output_dim, dtype=a[lA].dtype, device=a[lA].device)
+            return -ones * xp.exp(a[lL]) / xp.exp(a[lA])
+        return bk
+
+    maps['S'] = [make_S(k) for k in range(1, K_layers)]
+    maps['W'] = [make_W(k) for k in range(K_layers)]
+    maps['b'] = [make_b(k) for k in range(K_layers)]
+    return alt_params, maps
+
+
+# ------------------------------------------------------------------------------------------
+# small layer objects (Keras protocol subset used by enhance.py)
+# ------------------------------------------------------------------------------------------
+class _Layer(object):
+    _counters = {}
+
+    def __init__(self, name=None, **kwargs):
+        if name is None:
+            base = type(self).__name__.lower()
+            i = _Layer._counters.get(base, 0) + 1
+            _Layer._counters[base] = i
+            name = '%s_%d' % (base, i)
+        self.name = name
+        self.built = False
+
+    @property
+    def weights(self):
+        return []
+
+    def get_weights(self):
+        return [w.detach().cpu().numpy() for w in self.weights]
+
+    def set_weights(self, weights):
+        ws = self.weights
+        if len(weights) != len(ws):
+            raise ValueError('Layer %s expects %d weight arrays, got %d' %
+                             (self.name, len(ws), len(weights)))
+        for w, v in zip(ws, weights):
+            v = np.asarray(v, dtype=np.float32)
+            if tuple(v.shape) != tuple(w.shape):
+                raise ValueError('Layer %s weight shape %s != provided %s' %
+                                 (self.name, tuple(w.shape), tuple(v.shape)))
+            w.copy_(torch.from_numpy(np.ascontiguousarray(v)))
+        self._weights_changed()
+
+    def _weights_changed(self):
+        pass
+
+
+class InputLayer(_Layer):
+    def __init__(self, input_shape, **kw):
+        super(InputLayer, self).__init__(**kw)
+        self.input_shape = (None,) + tuple(input_shape)
+
+
+class Masking(_Layer):
+    """keras.layers.Masking [K2.0.4-memory] (enhance.py:253): frames whose bins ALL equal
+    mask_value are masked.  Zeroing and the validity flags are computed inside the cell kernel."""
+
+    def __init__(self, mask_value=0., input_shape=None, **kw):
+        super(Masking, self).__init__(**kw)
+        self.mask_value = mask_value
+        self.input_shape = input_shape
+
+
+class Lambda(_Layer):
+    """Placeholder for the slice / square Lambda layers (enhance.py:277-300); fused in the head."""
+
+    def __init__(self, what, **kw):
+        super(Lambda, self).__init__(**kw)
+        self.what = what
+
+
+class DenseNonNegW(_Layer):
+    """custom_layers.py:15-29: inputs . exp(kernel), use_bias=False, no activation.
+    `weights=[kernel]` initialises the (input_dim, units) log-domain kernel (enhance.py:283)."""
+
+    def __init__(self, units, use_bias=False, weights=None, activation=None, device=None, **kw):
+        super(DenseNonNegW, self).__init__(**kw)
+        if use_bias or activation not in (None, 'linear'):
+            raise NotImplementedError('DenseNonNegW: only use_bias=False, linear activation '
+                                      '(the reference configuration, enhance.py:283,292)')
+        self.units = units
+        self.use_bias = use_bias
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.kernel = None
+        if weights is not None:
+            k = np.asarray(weights[0], np.float32)
+            if k.shape[1] != units:
+                raise ValueError('kernel shape %s does not match units=%d' % (k.shape, units))
+            self.kernel = torch.from_numpy(np.ascontiguousarray(k)).to(self.device)
+            self.built = True
+
+    def build(self, input_shape):
+        if self.kernel is None:   # 'glorot_uniform' default of keras Dense [K2.0.4-memory]
+            fan_in, fan_out = input_shape[-1], self.units
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            k = np.random.uniform(-lim, lim, (fan_in, fan_out)).astype(np.float32)
+            self.kernel = torch.from_numpy(k).to(self.device)
+        self.built = True
+
+    @property
+    def weights(self):
+        return [] if self.kernel is None else [self.kernel]
+
+    def __call__(self, inputs):
+        """inputs [..., r] -> inputs . exp(kernel), via the head kernel with an empty noise half
+        is wasteful; standalone use computes A through head_forward with want_ab."""
+        if not self.built:
+            self.build(tuple(inputs.shape))
+        r = self.kernel.shape[0]
+        pad = torch.zeros(inputs.shape[:-1] + (2 * r,), dtype=torch.float32,
+                          device=inputs.device)
+        pad[..., :r] = inputs
+        zk = torch.full_like(self.kernel, -80.0)   # exp(-80) ~ 0: the unused second half
+        _, A, _ = ops.head_forward(pad, self.kernel, zk, want_ab=True)
+        return A
+
+
+class TimeDistributed(_Layer):
+    def __init__(self, layer, **kw):
+        super(TimeDistributed, self).__init__(**kw)
+        self.layer = layer
+
+    @property
+    def weights(self):
+        return self.layer.weights
+
+    def _weights_changed(self):
+        self.layer._weights_changed()
+
+    def __call__(self, inputs):
+        return self.layer(inputs)
+
+
+class DivideAbyAplusB(_Layer):
+    """custom_layers.py:33-45: exp(log(1e-7+A) - log(1e-7+A+B)).  Stand-alone elementwise form
+    (inside the model it is fused into the head kernel's epilogue)."""
+
+    def __call__(self, inputs):
+        if len(inputs) != 2:
+            raise ValueError('DivideAbyAplusB takes exactly 2 inputs')
+        A, B = inputs
+        return torch.exp(torch.log(1e-7 + A) - torch.log(1e-7 + A + B))
+
+
+def divide_A_by_AplusB(inputs, **kwargs):
+    """custom_layers.py:48-56."""
+    return DivideAbyAplusB(**kwargs)(inputs)
+
+
+# ------------------------------------------------------------------------------------------
+# SimpleDeepRNN  (custom_layers.py:104-412)
+# ------------------------------------------------------------------------------------------
+class SimpleDeepRNN(_Layer):
+    """The unfolded-ISTA deep recurrent cell.  Constructor mirrors custom_layers.py:131-143;
+    **kwargs accepts the Keras Recurrent arguments the reference uses (return_sequences,
+    input_shape, stateful, name) plus `device`."""
+
+    def __init__(self, output_dim, init='glorot_uniform', inner_init='orthogonal',
+                 activation='tanh', W_regularizer=None, U_regularizer=None, b_regularizer=None,
+                 dropout_W=0., dropout_U=0., K_layers=1, alt_params=None, keys_trainable=None,
+                 maps_from_alt=None, flag_connect_input_to_layers=False, flag_nonnegative=False,
+                 flag_return_all_hidden=False, return_sequences=False, input_shape=None,
+                 stateful=False, device=None, **kwargs):
+        super(SimpleDeepRNN, self).__init__(**kwargs)
+        self.units = self.output_dim = int(output_dim)
+        self.init, self.inner_init, self.activation = init, inner_init, activation
+        self.W_regularizer, self.U_regularizer, self.b_regularizer = (W_regularizer,
+                                                                      U_regularizer,
+                                                                      b_regularizer)
+        self.dropout_W, self.dropout_U = dropout_W, dropout_U
+        self.K_layers = int(K_layers)
+        self.alt_params = OrderedDict() if alt_params is None else alt_params
+        self.keys_trainable = (list(self.alt_params.keys()) if keys_trainable is None
+                               else list(keys_trainable))                # custom_layers.py:158-161
+        self.maps_from_alt = {} if maps_from_alt is None else maps_from_alt
+        self.flag_connect_input_to_layers = flag_connect_input_to_layers
+        self.flag_nonnegative = flag_nonnegative
+        self.flag_return_all_hidden = flag_return_all_hidden
+        self.return_sequences = return_sequences
+        self.input_shape = input_shape
+        self.stateful = stateful
+        self.consume_less = 'gpu'
+        self.device = torch.device(device if device is not None else 'cuda')
+        self._params_block = None
+        self._ws = {}
+        # what the fused HIP path covers (everything the reference's enhance.py constructs)
+        problems = []
+        if not isinstance(self.maps_from_alt, AltMaps):
+            problems.append('maps_from_alt must come from build_alt (generic maps need the dense '
+                            'U/S/W path, not built)')
+        if activation != 'relu':
+            problems.append("activation must be 'relu' (enhance.py:260)")
+        if not flag_connect_input_to_layers or not flag_nonnegative:
+            problems.append('flag_connect_input_to_layers and flag_nonnegative must be True '
+                            '(enhance.py:265-266)')
+        if dropout_W or dropout_U:
+            problems.append('dropout is never enabled by the reference and is not implemented')
+        if W_regularizer or U_regularizer or b_regularizer:
+            problems.append('regularizers are not implemented')
+        if stateful:
+            problems.append('stateful=True is not implemented')
+        if problems:
+            raise NotImplementedError('SimpleDeepRNN (HIP path): ' + '; '.join(problems))
+
+    # -- Keras protocol --------------------------------------------------------------------
+    def compute_output_shape(self, input_shape):                          # custom_layers.py:175-185
+        if isinstance(input_shape, list):
+            input_shape = input_shape[0]
+        units = self.K_layers * self.units if self.flag_return_all_hidden else self.units
+        if self.return_sequences:
+            return (input_shape[0], input_shape[1], units)
+        return (input_shape[0], units)
+
+    def build(self, input_shape):                                         # custom_layers.py:187-294
+        self.input_dim = int(input_shape[2])
+        N = self.output_dim
+        # 'uniform' initializer = U(-0.05, 0.05) [K2.0.4-memory]; h0 = softplus(log_h0)
+        log_h0 = np.random.uniform(-0.05, 0.05, (N,)).astype(np.float32)
+        self.log_h0 = torch.from_numpy(log_h0).to(self.device)
+        self._alt = OrderedDict()
+        for key in self.alt_params:                                       # custom_layers.py:216-228
+            v = np.asarray(self.alt_params[key], np.float32)
+            self._alt[key] = torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
+        self.trainable_keys = [k for k in self._alt if k in self.keys_trainable]
+        lab = self.maps_from_alt.labels_per_k
+        F = self.input_dim
+        d0 = self._alt[lab['log_D'][0]]
+        if tuple(d0.shape) != (F, N):
+            raise ValueError('log_D has shape %s, expected (input_dim=%d, output_dim=%d)' %
+                             (tuple(d0.shape), F, N))
+        self.built = True
+        self._weights_changed()
+
+    @property
+    def weights(self):
+        """Order: log_h0, then the alt params in build_alt's insertion order (the reference's order
+        is Python-2 dict order, custom_layers.py:203-228)."""
+        return [self.log_h0] + list(self._alt.values())
+
+    @property
+    def weight_names(self):
+        return ['%s_log_h0' % self.name] + ['%s_%s' % (self.name, k) for k in self._alt]
+
+    def _weights_changed(self):
+        self._params_block_valid = False
+        a = {k: v.detach().cpu().numpy() for k, v in self._alt.items()
+             if k in ('log_U1', 'log_Uk')}
+        U1, Uk = np.exp(a['log_U1']), np.exp(a['log_Uk'])                 # enhance.py:163-167
+        N = U1.shape[0]
+        d = np.diag(U1)
+        off = U1[~np.eye(N, dtype=bool)] if N > 1 else np.zeros((1,), np.float32)
+        if not (np.all(d == d[0]) and np.all(off == off[0]) and np.all(Uk == Uk.flat[0])):
+            raise NotImplementedError(
+                'log_U1/log_Uk no longer have the rank-structured form (diagonal + constant); a '
+                'trained dense U needs the dense-U kernel path, which is not built. No shipped '
+                'config trains them (params_unfolded_snmf_*.yaml:10).')
+        self._u = (float(d[0]), float(off[0]) if N > 1 else 0.0, float(Uk.flat[0]))
+
+    def get_config(self):                                                 # custom_layers.py:397-412
+        return {'name': self.name, 'output_dim': self.output_dim, 'init': self.init,
+                'inner_init': self.inner_init, 'activation': self.activation,
+                'W_regularizer': None, 'U_regularizer': None, 'b_regularizer': None,
+                'dropout_W': self.dropout_W, 'dropout_U': self.dropout_U,
+                'K_layers': self.K_layers, 'return_sequences': self.return_sequences,
+                'stateful': self.stateful,
+                'flag_connect_input_to_layers': self.flag_connect_input_to_layers}
+
+    def reset_states(self):                                               # custom_layers.py:296-318
+        assert self.stateful, 'Layer must be stateful.'
+
+    # -- forward ---------------------------------------------------------------------------
+    def _stacked(self, name):
+        lab = self.maps_from_alt.labels_per_k[name]
+        if lab[0] == lab[-1] and len(set(lab)) == 1:
+            return self._alt[lab[0]].reshape((1,) + tuple(self._alt[lab[0]].shape)), 1
+        return torch.stack([self._alt[k] for k in lab], 0), len(lab)
+
+    def _desc(self, B, T):
+        _, nD = self._stacked_meta('log_D')
+        _, nA = self._stacked_meta('log_alph')
+        _, nL = self._stacked_meta('log_lam1')
+        lab = self.maps_from_alt.labels_per_k
+        alph_len = int(self._alt[lab['log_alph'][0]].numel())
+        return ops.make_desc(B, T, self.input_dim, self.output_dim, self.K_layers, nD, nA,
+                             alph_len, nL, self.flag_return_all_hidden)
+
+    def _stacked_meta(self, name):
+        lab = self.maps_from_alt.labels_per_k[name]
+        return lab, (1 if len(set(lab)) == 1 else len(lab))
+
+    def prepare(self, B, T):
+        """(Re)build the prepared parameter block if the weights changed."""
+        desc = self._desc(B, T)
+        if not self._params_block_valid:
+            logD, _ = self._stacked('log_D')
+            logA, _ = self._stacked('log_alph')
+            logL, _ = self._stacked('log_lam1')
+            self._params_block = ops.prepare_params(desc, logD, logA.reshape(logA.shape[0], -1),
+                                                    logL.reshape(-1), out=self._params_block)
+            self._params_block_valid = True
+        return desc
+
+    def call(self, x, mask_value=None, out=None):
+        """x [B,T,F] float32 CUDA tensor -> h [B,T,N] (Masking semantics if mask_value given)."""
+        if not self.built:
+            self.build(tuple(x.shape))
+        B, T, F = x.shape
+        if F != self.input_dim:
+            raise ValueError('input has %d features, layer was built for %d' % (F, self.input_dim))
+        desc = self.prepare(B, T)
+        key = (B, T)
+        if key not in self._ws:
+            self._ws.clear()
+            self._ws[key] = ops.cell_workspace(desc, x.device)
+        h = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
+                             out=out, workspace=self._ws[key])
+        return h if self.return_sequences else h[:, -1]
+
+    __call__ = call
+
+
+# ------------------------------------------------------------------------------------------
+# build_unfolded_snmf  (enhance.py:209-317)
+# ------------------------------------------------------------------------------------------
+class UnfoldedSNMFModel(object):
+    """Masking -> SimpleDeepRNN -> [:r]/[r:] -> DenseNonNegW x2 -> (square) -> A/(A+B).
+    Exposes the slice of keras.Model that enhance.py uses: layers, get/set_weights,
+    predict_on_batch; `forward` keeps everything on the device."""
+
+    def __init__(self, layers, cell, clean, noise, mask_value, square):
+        self.layers = layers
+        self.cell, self.clean, self.noise = cell, clean, noise
+        self.mask_value, self.square = mask_value, square
+
+    @property
+    def weights(self):
+        return self.cell.weights + self.clean.weights + self.noise.weights
+
+    def get_weights(self):
+        return [w.detach().cpu().numpy() for w in self.weights]
+
+    def set_weights(self, weights):
+        n = len(self.cell.weights)
+        self.cell.set_weights(weights[:n])
+        self.clean.set_weights(weights[n:n + 1])
+        self.noise.set_weights(weights[n + 1:n + 2])
+
+    def forward(self, x, want_hidden=False):
+        h = self.cell.call(x, mask_value=self.mask_value)
+        mask = ops.head_forward(h, self.clean.kernel, self.noise.kernel, square=self.square,
+                                h_off=h.shape[-1] - self.cell.output_dim)
+        return (mask, h) if want_hidden else mask
+
+    def predict_on_batch(self, x):
+        xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.cell.device)
+        return self.forward(xt).cpu().numpy()
+
+    __call__ = forward
+
+
+def build_unfolded_snmf(params_unfolded_snmf, device=None):
+    """enhance.py:209-317 with the same parameter dictionary keys."""
+    p = params_unfolded_snmf
+    input_dim, hidden_dim, output_dim = p['input_dim'], p['hidden_dim'], p['output_dim']
+    mask_value, maxseq, K_layers = p['mask_value'], p['maxseq'], p['K_layers']
+    W_noisy = np.asarray(p['W'], np.float32)
+    if W_noisy.shape != (input_dim, hidden_dim):
+        raise ValueError("params['W'] has shape %s, expected (input_dim, hidden_dim) = (%d, %d)"
+                         % (W_noisy.shape, input_dim, hidden_dim))
+    if output_dim != input_dim:
+        raise ValueError('output_dim must equal input_dim (the mask multiplies the input)')
+
+    params_const = {'W': W_noisy,                                         # enhance.py:219-223
+                    'U1': np.eye(hidden_dim).astype(np.float32),
+                    'Uk': np.zeros((hidden_dim, hidden_dim)).astype(np.float32),
+                    'alph': np.float32(p['alph']), 'lam1': np.float32(p['lam1'])}
+    if p.get('untie_alph'):                                               # enhance.py:225-226
+        params_const['alph'] = params_const['alph'] * np.ones((hidden_dim,), np.float32)
+    params_untied = p.get('params_untied', [])
+    alt_params, maps_from_alt = build_alt(hidden_dim, K_layers, params_const,
+                                          params_untied=params_untied)
+    if 'params_trainable' not in p:
+        # the reference hits a NameError here (enhance.py:239-248 -> 263); be explicit instead
+        raise ValueError("params_unfolded_snmf must contain 'params_trainable'")
+    keys_trainable = []
+    for name in p['params_trainable']:                                    # enhance.py:241-248
+        if name in params_untied:
+            keys_trainable += [name + ('_%d' % k) for k in range(K_layers)]
+        else:
+            keys_trainable.append(name)
+
+    transform = p.get('transform_before_irm')
+    if transform not in (None, 'square'):
+        raise ValueError("Unknown 'transform_before_irm' of '%s'" % transform)
+
+    inp = InputLayer((maxseq, input_dim), name='masking_1_input')
+    masking = Masking(mask_value=mask_value, input_shape=(maxseq, input_dim))
+    cell = SimpleDeepRNN(hidden_dim, input_shape=(maxseq, input_dim), return_sequences=True,
+                         activation='relu', K_layers=K_layers, alt_params=alt_params,
+                         keys_trainable=keys_trainable, maps_from_alt=maps_from_alt,
+                         flag_connect_input_to_layers=True, flag_nonnegative=True, device=device)
+    cell.build((None, maxseq, input_dim))
+    r = hidden_dim // 2
+    log_W_clean = np.log(np.float32(1e-7) + W_noisy[:, :r])               # enhance.py:282
+    log_W_noise = np.log(np.float32(1e-7) + W_noisy[:, r:])               # enhance.py:291
+    clean = DenseNonNegW(output_dim, use_bias=False, weights=[log_W_clean.T], device=device)
+    noise = DenseNonNegW(output_dim, use_bias=False, weights=[log_W_noise.T], device=device)
+    layers = [inp, masking, cell, Lambda('h[:, :, :r]', name='H_clean'),
+              Lambda('h[:, :, r:]', name='H_noise'), TimeDistributed(clean, name='clean_est'),
+              TimeDistributed(noise, name='noise_est')]
+    if transform == 'square':
+        layers += [Lambda('square', name='clean_est_xformed'),
+                   Lambda('square', name='noise_est_xformed')]
+    layers.append(DivideAbyAplusB())
+    return UnfoldedSNMFModel(layers, cell, clean, noise, mask_value, transform == 'square')

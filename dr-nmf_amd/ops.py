@@ -1,0 +1,205 @@
+"""Torch-tensor front end of the C ABI: tensors are device-memory containers only; every op
+enqueues hand-written HIP kernels on torch's current stream through libdrnmf.so."""
+import ctypes as C
+
+import torch
+
+from . import _capi
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_index(t):
+    if not t.is_cuda:
+        raise ValueError("drnmf_amd ops need CUDA(HIP) tensors; got a %s tensor. There is no CPU "
+                         "fallback." % t.device)
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise ValueError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def make_desc(B, T, F, N, K, n_D=1, n_alph=1, alph_len=1, n_lam=1, return_all_hidden=False):
+    return _capi.CellDesc(int(B), int(T), int(F), int(N), int(K), int(n_D), int(n_alph),
+                          int(alph_len), int(n_lam), int(bool(return_all_hidden)))
+
+
+def prepare_params(desc, log_D, log_alph, log_lam1, out=None):
+    """log_D [n_D,F,N], log_alph [n_alph,alph_len], log_lam1 [n_lam] -> prepared block (uint8)."""
+    L = _capi.lib()
+    dev = _dev_index(log_D)
+    h = _capi.handle(dev)
+    log_D, log_alph, log_lam1 = (_f32c(log_D, "log_D"), _f32c(log_alph, "log_alph"),
+                                 _f32c(log_lam1, "log_lam1"))
+    if log_D.numel() != desc.n_D * desc.F * desc.N:
+        raise ValueError("log_D has %d elements, expected n_D*F*N = %d" %
+                         (log_D.numel(), desc.n_D * desc.F * desc.N))
+    if log_alph.numel() != desc.n_alph * desc.alph_len or log_lam1.numel() != desc.n_lam:
+        raise ValueError("log_alph/log_lam1 sizes do not match the descriptor")
+    nbytes = L.drnmf_params_bytes(C.byref(desc))
+    if out is None or out.numel() < nbytes:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=log_D.device)
+    rc = L.drnmf_prepare_params(h, C.byref(desc), _capi.ptr(log_D), _capi.ptr(log_alph),
+                                _capi.ptr(log_lam1), _capi.ptr(out), _stream())
+    _capi.check(rc, h, "drnmf_prepare_params")
+    return out
+
+
+def unpack_params(block, desc):
+    """Views into a prepared block: (Dn [n_D,Fp,Np], colnorm [n_D,Np], inv_alpha [K,Np],
+    bias [K,Np]) -- the layout of params_layout() in csrc/common.h."""
+    Fp = (desc.F + 15) // 16 * 16
+    Np = (desc.N + 31) // 32 * 32
+    r256 = lambda v: (v + 255) // 256 * 256
+    f = block.view(torch.float32) if block.dtype != torch.float32 else block
+    o = 0
+    n = desc.n_D * Fp * Np
+    Dn = f[o:o + n].view(desc.n_D, Fp, Np); o += n
+    n = desc.n_D * Np
+    colnorm = f[o:o + n].view(desc.n_D, Np); o += r256(n * 4) // 4
+    n = desc.K * Np
+    inv_alpha = f[o:o + n].view(desc.K, Np); o += r256(n * 4) // 4
+    bias = f[o:o + n].view(desc.K, Np)
+    return Dn, colnorm, inv_alpha, bias
+
+
+def cell_workspace(desc, device):
+    nbytes = _capi.lib().drnmf_cell_workspace_bytes(C.byref(desc))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def cell_forward(x, mask_value, params, desc, log_h0, u, out=None, workspace=None):
+    """x [B,T,F] -> h [B,T,N] (or [B,T,K*N]).  mask_value None = no masking.
+    u = (u0_diag, u0_off, uk_off)."""
+    L = _capi.lib()
+    dev = _dev_index(x)
+    h = _capi.handle(dev)
+    x = _f32c(x, "x")
+    log_h0 = _f32c(log_h0, "log_h0")
+    if tuple(x.shape) != (desc.B, desc.T, desc.F):
+        raise ValueError("x has shape %s, descriptor says (%d,%d,%d)" %
+                         (tuple(x.shape), desc.B, desc.T, desc.F))
+    if log_h0.numel() != desc.N:
+        raise ValueError("log_h0 must have N=%d elements" % desc.N)
+    width = desc.N * (desc.K if desc.return_all_hidden else 1)
+    if out is None:
+        out = torch.empty((desc.B, desc.T, width), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (desc.B, desc.T, width) or not out.is_contiguous():
+        raise ValueError("out must be a contiguous (B,T,%d) float32 tensor" % width)
+    if workspace is None:
+        workspace = cell_workspace(desc, x.device)
+    mv = float("nan") if mask_value is None else float(mask_value)
+    rc = L.drnmf_cell_forward(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
+                              _capi.ptr(log_h0), float(u[0]), float(u[1]), float(u[2]),
+                              _capi.ptr(out), _capi.ptr(workspace), workspace.numel(), _stream())
+    _capi.check(rc, h, "drnmf_cell_forward")
+    return out
+
+
+def head_forward(hidden, kernel_clean, kernel_noise, square=False, want_ab=False, h_off=0,
+                 out=None):
+    """hidden [..., ld] (uses columns h_off .. h_off+2r) -> mask [..., F] (and A, Bn)."""
+    L = _capi.lib()
+    dev = _dev_index(hidden)
+    h = _capi.handle(dev)
+    hidden = _f32c(hidden, "hidden")
+    kc, kn = _f32c(kernel_clean, "kernel_clean"), _f32c(kernel_noise, "kernel_noise")
+    r, F = kc.shape
+    if tuple(kn.shape) != (r, F):
+        raise ValueError("kernel_noise shape %s != kernel_clean shape %s" %
+                         (tuple(kn.shape), (r, F)))
+    ld = hidden.shape[-1]
+    rows = hidden.numel() // ld
+    shape = tuple(hidden.shape[:-1]) + (F,)
+    mask = out if out is not None else torch.empty(shape, dtype=torch.float32,
+                                                   device=hidden.device)
+    A = torch.empty(shape, dtype=torch.float32, device=hidden.device) if want_ab else None
+    Bn = torch.empty(shape, dtype=torch.float32, device=hidden.device) if want_ab else None
+    Fp = L.drnmf_padded_f(F)
+    ecat = torch.empty(2 * ((r + 15) // 16 * 16) * Fp, dtype=torch.float32, device=hidden.device)
+    rc = L.drnmf_head_forward(h, rows, F, r, _capi.ptr(hidden), ld, int(h_off), _capi.ptr(kc),
+                              _capi.ptr(kn), int(bool(square)), _capi.ptr(mask), _capi.ptr(A),
+                              _capi.ptr(Bn), _capi.ptr(ecat), _stream())
+    _capi.check(rc, h, "drnmf_head_forward")
+    return (mask, A, Bn) if want_ab else mask
+
+
+def ista_forward(X, W, H, lam1, alph, K, divergence="ed", beta=2.0):
+    """Frame-parallel ISTA (enhance.py:402-456) in row layout: X [n,F], W [F,N], H [n,N] updated
+    IN PLACE and returned."""
+    L = _capi.lib()
+    dev = _dev_index(X)
+    h = _capi.handle(dev)
+    X, W = _f32c(X, "X"), _f32c(W, "W")
+    if H.dtype != torch.float32 or not H.is_contiguous():
+        raise ValueError("H must be a contiguous float32 tensor (updated in place)")
+    n, F = X.shape
+    N = W.shape[1]
+    if W.shape[0] != F or tuple(H.shape) != (n, N):
+        raise ValueError("shape mismatch: X %s W %s H %s" % (tuple(X.shape), tuple(W.shape),
+                                                              tuple(H.shape)))
+    div = {"ed": _capi.DIV_ED, "kl": _capi.DIV_KL, "beta": _capi.DIV_BETA}[divergence]
+    nbytes = L.drnmf_ista_workspace_bytes(n, F, N)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=X.device)
+    rc = L.drnmf_ista_forward(h, n, F, N, int(K), div, float(beta), float(lam1), float(alph),
+                              _capi.ptr(X), _capi.ptr(W), _capi.ptr(H), _capi.ptr(ws), nbytes,
+                              _stream())
+    _capi.check(rc, h, "drnmf_ista_forward")
+    return H
+
+
+def mu_forward(V, W, H, sparsity, n_iter, beta=2.0, want_irm=False):
+    """SNMF inference by multiplicative updates, W fixed (sparse_nmf_gpu.m:163-173, 210-229) in
+    row layout: V [n,F], W [F,N], H [n,N] (initial value in, result out, in place).
+    Returns (H, Wn[, irm])."""
+    L = _capi.lib()
+    dev = _dev_index(V)
+    h = _capi.handle(dev)
+    V, W = _f32c(V, "V"), _f32c(W, "W")
+    if H.dtype != torch.float32 or not H.is_contiguous():
+        raise ValueError("H must be a contiguous float32 tensor (updated in place)")
+    n, F = V.shape
+    N = W.shape[1]
+    if W.shape[0] != F or tuple(H.shape) != (n, N):
+        raise ValueError("shape mismatch: V %s W %s H %s" % (tuple(V.shape), tuple(W.shape),
+                                                              tuple(H.shape)))
+    Wn = torch.empty_like(W)
+    irm = torch.empty((n, F), dtype=torch.float32, device=V.device) if want_irm else None
+    nbytes = L.drnmf_mu_workspace_bytes(n, F, N)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=V.device)
+    rc = L.drnmf_mu_forward(h, n, F, N, int(n_iter), float(beta), float(sparsity), _capi.ptr(V),
+                            _capi.ptr(W), _capi.ptr(Wn), _capi.ptr(H), _capi.ptr(irm),
+                            _capi.ptr(ws), nbytes, _stream())
+    _capi.check(rc, h, "drnmf_mu_forward")
+    return (H, Wn, irm) if want_irm else (H, Wn)
+
+
+def stft_frames(nsampl, N, hop):
+    return int(_capi.lib().drnmf_stft_frames(int(nsampl), int(N), int(hop)))
+
+
+def stft_mag(pcm, N=1024, hop=None):
+    """pcm [n_sig, nsampl] int16 (scaled by 1/32768, util.py:29-35) or float32 ->
+    |STFT| [n_sig, n_frames, N/2+1] with the sqrt-Hann window (audio_dataset.py:194)."""
+    L = _capi.lib()
+    dev = _dev_index(pcm)
+    h = _capi.handle(dev)
+    if hop is None:
+        hop = N // 2
+    if pcm.dim() == 1:
+        pcm = pcm[None]
+    if pcm.dtype not in (torch.int16, torch.float32):
+        raise ValueError("pcm must be int16 or float32")
+    pcm = pcm.contiguous()
+    n_sig, nsampl = pcm.shape
+    nf = stft_frames(nsampl, N, hop)
+    mag = torch.empty((n_sig, nf, N // 2 + 1), dtype=torch.float32, device=pcm.device)
+    rc = L.drnmf_stft_mag(h, n_sig, nsampl, int(N), int(hop), int(pcm.dtype == torch.int16),
+                          _capi.ptr(pcm), _capi.ptr(mag), _stream())
+    _capi.check(rc, h, "drnmf_stft_mag")
+    return mag

@@ -1,0 +1,140 @@
+/*
+ * drnmf.h -- C ABI of libdrnmf.so: the MI355X (gfx950) implementation of stwisdom/dr-nmf's
+ * hot path (unfolded-ISTA sparse-NMF recurrent cell, mask head, frame-parallel ISTA / MU
+ * inference, STFT-magnitude front end).
+ *
+ * The reference has no FFI: its hot path is Keras layers executed by Theano.  Each entry point
+ * below names the reference interface it replaces (paths relative to the reference repo).
+ * A ctypes binding is shown in INTEGRATION.md; the in-tree binding is dr-nmf_amd/_capi.py.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host; the caller owns all memory;
+ *    the library allocates nothing persistent except the opaque handle (error string, cached
+ *    hipGraph executables);
+ *  - every call enqueues on the caller's `stream` (a hipStream_t passed as void*), never
+ *    synchronises the device, and returns a status (0 = OK, <0 = error; text via
+ *    drnmf_last_error).  Nothing throws or aborts across the ABI;
+ *  - all tensors are float32, dense, row-major ("C order") with the shapes given.
+ */
+#ifndef DRNMF_H
+#define DRNMF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRNMF_VERSION 100 /* 0.1.0 */
+
+enum {
+    DRNMF_OK = 0,
+    DRNMF_ERR_INVALID_ARG = -1,
+    DRNMF_ERR_UNSUPPORTED = -2,
+    DRNMF_ERR_HIP = -3,
+    DRNMF_ERR_WORKSPACE = -4
+};
+
+/* divergence selector for the frame-parallel ISTA / MU kernels */
+enum { DRNMF_DIV_ED = 0, DRNMF_DIV_KL = 1, DRNMF_DIV_BETA = 2 };
+
+typedef struct drnmf_handle_s* drnmf_handle_t;
+
+/* Problem descriptor of the recurrent cell (SimpleDeepRNN, custom_layers.py:104-412, as
+ * configured by build_unfolded_snmf, enhance.py:257-266). */
+typedef struct drnmf_cell_desc {
+    int32_t B;              /* sequences in the batch                                          */
+    int32_t T;              /* frames per sequence (maxseq)                                    */
+    int32_t F;              /* input_dim  (STFT bins)                                          */
+    int32_t N;              /* hidden_dim (atoms, = 2r)                                        */
+    int32_t K;              /* K_layers                                                        */
+    int32_t n_D;            /* 1 (tied log_D) or K (untied: log_D_0..log_D_{K-1})              */
+    int32_t n_alph;         /* 1 or K                                                          */
+    int32_t alph_len;       /* 1 (scalar alph) or N (untie_alph, enhance.py:225-226)           */
+    int32_t n_lam;          /* 1 or K                                                          */
+    int32_t return_all_hidden; /* flag_return_all_hidden (custom_layers.py:344-346,371-372)    */
+} drnmf_cell_desc_t;
+
+int32_t drnmf_version(void);
+int32_t drnmf_create(drnmf_handle_t* out, int32_t device);
+int32_t drnmf_destroy(drnmf_handle_t h);
+const char* drnmf_last_error(drnmf_handle_t h); /* h may be NULL: last create() error */
+
+/* ---- parameter maps: replaces build_alt's maps_from_alt lambdas (enhance.py:161-204) and their
+ * evaluation in SimpleDeepRNN.build (custom_layers.py:234-287).
+ *   log_D    [n_D][F][N]       log_alph [n_alph][alph_len]      log_lam1 [n_lam]
+ * writes the prepared block `params` (drnmf_params_bytes): per stored layer the unit-L2-column
+ * dictionary exp(log_D)/||.||_2 (zero-padded, [Fp][Np]), its column norms, and per layer
+ * 1/alpha[n] and b[n] = -lam/alpha[n].  Must be re-run after every weight update. */
+size_t drnmf_params_bytes(const drnmf_cell_desc_t* d);
+int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* log_D,
+                             const float* log_alph, const float* log_lam1, void* params,
+                             void* stream);
+
+/* ---- recurrent cell forward: replaces Masking (enhance.py:253) + Recurrent.call/K.rnn +
+ * SimpleDeepRNN.get_initial_state/step (custom_layers.py:336-375).
+ *   x      [B][T][F]   frames equal to mask_value in EVERY bin are masked (state held, previous
+ *                      output repeated, zeros before the first valid frame)
+ *   log_h0 [N]         initial state = softplus(log_h0)        (custom_layers.py:203-206)
+ *   u0_diag,u0_off     diagonal / off-diagonal value of U_0 = exp(log_U1)^T   (enhance.py:163)
+ *   uk_off             the constant value of U_k = exp(log_Uk)^T, k>=1        (enhance.py:165)
+ *                      (rank-structured U only; a trained dense U is DRNMF_ERR_UNSUPPORTED
+ *                      at the Python layer)
+ *   h_out  [B][T][N]   (or [B][T][K*N] with return_all_hidden)
+ *   workspace          >= drnmf_cell_workspace_bytes(d), 256-byte aligned, contents scratch */
+size_t drnmf_cell_workspace_bytes(const drnmf_cell_desc_t* d);
+int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                           float mask_value, const void* params, const float* log_h0,
+                           float u0_diag, float u0_off, float uk_off, float* h_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- mask head: replaces the H_clean/H_noise slices, TimeDistributed(DenseNonNegW) x2
+ * (custom_layers.py:23-29; enhance.py:277-292), the optional 'square' transform
+ * (enhance.py:294-300) and DivideAbyAplusB (custom_layers.py:41-45).
+ *   hidden [rows][ld_h] (the last N columns of each row are used when ld_h > N... see h_off)
+ *   kernel_clean/kernel_noise [r][F] log-domain recon kernels;  mask [rows][F]
+ *   A_out / Bn_out: optional [rows][F] (NULL to skip) -- the two reconstructions
+ *   ecat: scratch [2r][Fp] floats, Fp = drnmf_padded_f(F) */
+int32_t drnmf_padded_f(int32_t F);
+int32_t drnmf_head_forward(drnmf_handle_t h, int64_t rows, int32_t F, int32_t r,
+                           const float* hidden, int64_t ld_h, int32_t h_off,
+                           const float* kernel_clean, const float* kernel_noise, int32_t square,
+                           float* mask, float* A_out, float* Bn_out, float* ecat, void* stream);
+
+/* ---- frame-parallel ISTA: replaces ista_ed / ista_kl / ista_beta (enhance.py:402-456).
+ * Row-vector layout (frames are rows):  X [n][F], W [F][N] (used as given, NOT re-normalised),
+ * H [n][N] in/out.  K iterations of H <- max(0, H + (g(X, H W^T) W - lam1)/alph).
+ *   workspace >= drnmf_ista_workspace_bytes(n, F, N) */
+size_t drnmf_ista_workspace_bytes(int64_t n, int32_t F, int32_t N);
+int32_t drnmf_ista_forward(drnmf_handle_t h, int64_t n, int32_t F, int32_t N, int32_t K,
+                           int32_t divergence, float beta, float lam1, float alph, const float* X,
+                           const float* W, float* H, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* ---- SNMF inference by multiplicative updates with W fixed: replaces the Matlab process
+ * behind sparse_nmf_matlab (snmf.py:9-113) for the `w_update_ind` all-false call
+ * (enhance.py:838-845): sparse_nmf_gpu.m:163-173 (normalise W, rescale H), 210-229 (H update).
+ * Row-vector layout: V [n][F], W [F][N] (normalised copy written to Wn [F][N]), H [n][N] in/out
+ * (the caller supplies the initial H: Matlab's legacy rand('seed') is not reproducible).
+ * Optional irm [n][F] = WcHc/(1e-9+WcHc+WnHn) (enhance.py:848-852), r = N/2; NULL to skip. */
+size_t drnmf_mu_workspace_bytes(int64_t n, int32_t F, int32_t N);
+int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int32_t N, int32_t n_iter,
+                         float beta, float sparsity, const float* V, const float* W, float* Wn,
+                         float* H, float* irm, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* ---- STFT magnitude front end: replaces wavread scaling (util.py:29-35), stft_mc
+ * (util.py:171-201, librosa stft(center=False)), the sqrt-Hann window
+ * (audio_dataset.py:194) and the 'mag' transform (audio_dataset.py:22-23).
+ *   pcm [n_sig][nsampl] int16 (is_int16=1, scaled by 1/32768) or float32
+ *   mag [n_sig][n_frames][N/2+1],  n_frames = drnmf_stft_frames(nsampl, N, hop)
+ *   N must be a power of two in [64, 4096] */
+int32_t drnmf_stft_frames(int64_t nsampl, int32_t N, int32_t hop);
+int32_t drnmf_stft_mag(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32_t N, int32_t hop,
+                       int32_t is_int16, const void* pcm, float* mag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRNMF_H */

@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 kernels vs the fp64 oracle):
+    hidden state  max|dh| / max|h| <= 1e-4
+    mask          MSE <= 1e-8      (BASELINE.json bar: 1e-5)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import drnmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+H_TOL = 1e-4
+MASK_MSE_TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (run with -m 'not gpu' on CPU boxes)")
+    from drnmf_amd import _capi
+    _capi.handle(0)        # fails loudly if libdrnmf.so is missing or the device is not gfx950
+    return torch.device("cuda:0")
+
+
+def _problem(B, T, F, r, K, untied=("log_D", "log_alph"), untie_alph=False, ragged=False, seed=3,
+             perturb=0.05, alph=None, lam1=0.3, density=0.1):
+    P = O.synth_problem(B, T, F, r, seed=seed, ragged=ragged, density=density)
+    N = 2 * r
+    a = np.float32(N / 4.0 if alph is None else alph)
+    if untie_alph:
+        a = a * np.ones((N,), np.float32)
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=a, lam1=np.float32(lam1))
+    alt, labels = O.build_alt(N, K, params, untied)
+    rng = np.random.default_rng(seed)
+    for k in list(alt):   # untied copies that really differ per layer
+        if perturb and (k.startswith("log_D_") or k.startswith("log_alph_")):
+            alt[k] = (alt[k] + perturb * rng.standard_normal(alt[k].shape)).astype(np.float32)
+    return P, alt, labels, N
+
+
+def _run_cell(dev, P, alt, labels, N, K, mask_value=-1.0, return_all_hidden=False):
+    from drnmf_amd import ops
+    X = P["X"]
+    B, T, F = X.shape
+    stack = lambda name: np.stack([alt[k] for k in dict.fromkeys(labels[name])], 0)
+    logD, logA, logL = stack("log_D"), stack("log_alph"), stack("log_lam1")
+    desc = ops.make_desc(B, T, F, N, K, n_D=logD.shape[0], n_alph=logA.shape[0],
+                         alph_len=int(np.asarray(logA[0]).size), n_lam=logL.shape[0],
+                         return_all_hidden=return_all_hidden)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    params = ops.prepare_params(desc, t(logD), t(logA.reshape(logA.shape[0], -1)),
+                                t(logL.reshape(-1)))
+    u = O.u_scalars(alt, np.float32)
+    h = ops.cell_forward(t(X), mask_value, params, desc, t(P["log_h0"]), u)
+    torch.cuda.synchronize()
+    return h.cpu().numpy(), params, desc
+
+
+def _oracle_cell(P, alt, labels, K, mask_value=-1.0, return_all_hidden=False):
+    return O.cell_forward_factored(P["X"], O.maps_factored(alt, labels, K), O.u_scalars(alt),
+                                   P["log_h0"], mask_value=mask_value,
+                                   return_all_hidden=return_all_hidden)
+
+
+def _check_h(h, ref):
+    assert h.shape == ref.shape
+    assert np.all(np.isfinite(h))
+    err = np.max(np.abs(h - ref)) / max(np.max(np.abs(ref)), 1e-30)
+    assert err <= H_TOL, "max|dh|/max|h| = %.3e" % err
+    return err
+
+
+def test_prepare_params_matches_oracle(dev):
+    from drnmf_amd import ops
+    P, alt, labels, N = _problem(2, 2, 21, 6, 3, untie_alph=True)
+    _, params, desc = _run_cell(dev, P, alt, labels, N, 3)
+    Dn, colnorm, ia, bias = [v.cpu().numpy() for v in ops.unpack_params(params, desc)]
+    ref = O.maps_factored(alt, labels, 3)
+    for k in range(3):
+        np.testing.assert_allclose(Dn[k, :21, :N], ref[k][0], rtol=2e-6, atol=1e-9)
+        assert np.all(Dn[k, 21:, :] == 0) and np.all(Dn[k, :, N:] == 0)
+        np.testing.assert_allclose(ia[k, :N], ref[k][1], rtol=2e-6)
+        np.testing.assert_allclose(bias[k, :N], ref[k][2], rtol=2e-6)
+        assert np.all(bias[k, N:] < -1e29)
+        np.testing.assert_allclose(np.sum(Dn[k].astype(np.float64) ** 2, 0)[:N], 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, T=5, F=21, r=6, K=4),                                  # ragged dims, untied
+    dict(B=16, T=4, F=64, r=32, K=3, untied=()),                     # exact tiles, tied
+    dict(B=5, T=6, F=33, r=8, K=1),                                  # K=1: first == last layer
+    dict(B=4, T=6, F=40, r=10, K=2, untie_alph=True),                # per-atom alpha
+    dict(B=17, T=3, F=257, r=100, K=5),                              # shipped shape (C3), 2 row tiles
+    dict(B=1, T=12, F=513, r=100, K=10, untied=()),                  # BASELINE config 1 shape
+    dict(B=2, T=3, F=1025, r=24, K=2),                               # F > one operand group
+    dict(B=3, T=4, F=21, r=6, K=3, untied=("log_D", "log_alph", "log_lam1")),
+])
+def test_cell_forward_matches_oracle(dev, cfg):
+    cfg = dict(cfg)
+    K = cfg.pop("K")
+    P, alt, labels, N = _problem(K=K, **cfg)
+    h, _, _ = _run_cell(dev, P, alt, labels, N, K)
+    _check_h(h, _oracle_cell(P, alt, labels, K))
+
+
+def test_cell_forward_masking_semantics(dev):
+    """ragged lengths + a masked HEAD (outside the reference's layout contract, but defined by
+    K.rnn): repeat previous output, zeros before the first valid frame, state held."""
+    K = 3
+    P, alt, labels, N = _problem(4, 9, 21, 6, K, ragged=True)
+    P["X"][1, :2] = -1.0
+    P["X"][2, :] = -1.0          # a sequence with no valid frame at all
+    h, _, _ = _run_cell(dev, P, alt, labels, N, K)
+    ref = _oracle_cell(P, alt, labels, K)
+    _check_h(h, ref)
+    assert np.all(h[1, :2] == 0) and np.all(h[2] == 0)
+    L0 = int(P["lengths"][0])
+    if L0 < 9:
+        np.testing.assert_array_equal(h[0, L0], h[0, L0 - 1])
+    # no masking requested: -1 frames are ordinary input
+    h2, _, _ = _run_cell(dev, P, alt, labels, N, K, mask_value=None)
+    ref2 = _oracle_cell(P, alt, labels, K, mask_value=np.nan)
+    _check_h(h2, ref2)
+
+
+def test_cell_forward_return_all_hidden(dev):
+    K = 3
+    P, alt, labels, N = _problem(3, 5, 21, 6, K, ragged=True)
+    h, _, _ = _run_cell(dev, P, alt, labels, N, K, return_all_hidden=True)
+    ref = _oracle_cell(P, alt, labels, K, return_all_hidden=True)
+    assert h.shape == (3, 5, K * N)
+    _check_h(h, ref)
+
+
+def test_cell_forward_is_deterministic_and_graph_equals_plain_launches(dev, monkeypatch):
+    K = 4
+    P, alt, labels, N = _problem(5, 7, 65, 20, K)
+    h1, _, _ = _run_cell(dev, P, alt, labels, N, K)
+    h2, _, _ = _run_cell(dev, P, alt, labels, N, K)
+    np.testing.assert_array_equal(h1, h2)
+    monkeypatch.setenv("DRNMF_NO_GRAPH", "1")
+    h3, _, _ = _run_cell(dev, P, alt, labels, N, K)
+    np.testing.assert_array_equal(h1, h3)
+
+
+def test_cell_reference_dense_form_agrees(dev):
+    """HIP (factored) vs the reference's own op graph (dense U, materialised Gram S)."""
+    K = 3
+    P, alt, labels, N = _problem(2, 4, 33, 8, K)
+    h, _, _ = _run_cell(dev, P, alt, labels, N, K)
+    Wk, Uk, bk, Sk = O.maps_dense(alt, labels, K, N)
+    _check_h(h, O.cell_forward_dense(P["X"], Wk, Uk, bk, Sk, P["log_h0"]))
+
+
+def test_head_matches_oracle(dev):
+    from drnmf_amd import ops
+    rng = np.random.default_rng(0)
+    for rows_shape, r, F, square in [((3, 7), 6, 21, False), ((130,), 100, 257, False),
+                                     ((2, 5), 7, 33, True), ((257,), 16, 513, False)]:
+        h = np.abs(rng.standard_normal(rows_shape + (2 * r,))).astype(np.float32) * \
+            (rng.random(rows_shape + (2 * r,)) < 0.3)
+        kc = (rng.standard_normal((r, F)) - 2).astype(np.float32)
+        kn = (rng.standard_normal((r, F)) - 2).astype(np.float32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        m, A, Bn = ops.head_forward(t(h), t(kc), t(kn), square=square, want_ab=True)
+        torch.cuda.synchronize()
+        mr, Ar, Br = O.head_forward(h, kc, kn, square=square)
+        np.testing.assert_allclose(A.cpu().numpy(), Ar, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(Bn.cpu().numpy(), Br, rtol=2e-5, atol=1e-7)
+        mm = m.cpu().numpy()
+        assert np.mean((mm - mr) ** 2) <= MASK_MSE_TOL
+        assert np.all(mm > 0) and np.all(mm <= 1.0 + 1e-6)
+
+
+@pytest.mark.parametrize("square", [False, True])
+def test_model_predict_on_batch_matches_oracle(dev, square):
+    from drnmf_amd import layers
+    B, T, F, r, K = 6, 10, 65, 12, 4
+    P = O.synth_problem(B, T, F, r, seed=11, ragged=True, density=0.1)
+    N = 2 * r
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph"])
+    if square:
+        p["transform_before_irm"] = "square"
+    model = layers.build_unfolded_snmf(p)
+    # weights round trip (enhance.py:1187 model_irm.set_weights(model.get_weights()))
+    w = model.get_weights()
+    rng = np.random.default_rng(1)
+    w2 = [a + (0.03 * rng.standard_normal(a.shape)).astype(np.float32)
+          if i not in (0,) and a.ndim == 2 and a.shape[0] != a.shape[1] else a
+          for i, a in enumerate(w)]
+    model.set_weights(w2)
+    irm = model.predict_on_batch(P["X"])
+    names = ["log_h0"] + list(model.cell._alt.keys()) + ["kc", "kn"]
+    wd = dict(zip(names, w2))
+    alt = {k: wd[k] for k in model.cell._alt.keys()}
+    ref, _ = O.model_forward(P["X"], alt, model.cell.maps_from_alt.labels_per_k, K, wd["log_h0"],
+                             wd["kc"], wd["kn"], mask_value=-1., square=square)
+    assert irm.shape == (B, T, F)
+    mse = np.mean((irm - ref) ** 2)
+    assert mse <= MASK_MSE_TOL, "mask MSE %.3e" % mse
+    # layer indices enhance.py:311-315 relies on
+    assert model.layers[-5 if square else -3].name == "clean_est"
+    assert model.layers[-4 if square else -2].name == "noise_est"
+    assert model.layers[0].name == "masking_1_input"
+
+
+def test_full_size_layer_against_oracle(dev):
+    """BASELINE config 2 dictionary size (F=513, N=2000, K=25, B=64) on 2 frames: every kernel
+    instantiation and grid the benchmark uses, checked against the fp64 oracle."""
+    K = 25
+    P, alt, labels, N = _problem(64, 2, 513, 1000, K, perturb=0.0, alph=400.0, lam1=1.0,
+                                 density=0.02, seed=7654)
+    h, _, _ = _run_cell(dev, P, alt, labels, N, K)
+    ref = _oracle_cell(P, alt, labels, K)
+    _check_h(h, ref)
+    # size-independent properties at full size: non-negativity and exact sparsity pattern
+    assert np.all(h >= 0)
+    agree = np.mean((h > 0) == (ref > 0))
+    assert agree > 0.9999

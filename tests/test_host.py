@@ -1,0 +1,119 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol; host logic of the
+Keras-surface mirror (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import drnmf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as G
+    G.build()
+    from drnmf_amd import _capi
+    return _capi
+
+
+def test_library_exports_every_declared_symbol(capi):
+    hdr = open(os.path.join(ROOT, "include", "drnmf.h")).read()
+    declared = set(re.findall(r"\b(drnmf_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"drnmf_handle_s"}
+    assert declared, "no declarations parsed"
+    L = capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libdrnmf.so does not export %s" % name
+    assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+    assert L.drnmf_version() == 100
+
+
+def test_size_queries_and_frame_count(capi):
+    from drnmf_amd import ops
+    L = capi.lib()
+    d = ops.make_desc(64, 2000, 513, 2000, 25, n_D=25, n_alph=25)
+    pb = L.drnmf_params_bytes(ctypes.byref(d))
+    assert pb >= 25 * 528 * 2016 * 4
+    wb = L.drnmf_cell_workspace_bytes(ctypes.byref(d))
+    assert wb >= 2000 * 64 * 528 * 4
+    assert L.drnmf_padded_f(513) == 528 and L.drnmf_padded_f(257) == 272
+    for nsampl, N, hop in [(1000, 64, 16), (16000, 512, 128), (160000, 1024, 512), (1, 64, 32)]:
+        assert L.drnmf_stft_frames(nsampl, N, hop) == O.stft_frames(nsampl, N, hop)
+
+
+def test_create_fails_loudly_without_gpu(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.DrnmfError):
+        capi.handle(0)
+    from drnmf_amd import ops
+    with pytest.raises(ValueError):
+        ops.cell_forward(torch.zeros(1, 1, 4), None, None, ops.make_desc(1, 1, 4, 2, 1),
+                         torch.zeros(2), (1, 0, 0))
+
+
+def test_build_alt_matches_oracle():
+    from drnmf_amd import layers
+    P = O.synth_problem(2, 3, 21, 6, seed=5)
+    N, K = 12, 3
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(3.0), lam1=np.float32(0.3))
+    for untied in ([], ["log_D", "log_alph"], ["log_D", "log_alph", "log_lam1"]):
+        alt, maps = layers.build_alt(N, K, params, params_untied=untied)
+        oalt, olab = O.build_alt(N, K, params, untied)
+        assert set(alt) == set(oalt)
+        for k in alt:
+            np.testing.assert_array_equal(alt[k], oalt[k])
+        assert maps.labels_per_k == olab
+        Wk, Uk, bk, Sk = O.maps_dense(oalt, olab, K, N, dtype=np.float32)
+        assert len(maps["W"]) == K and len(maps["S"]) == K - 1 and len(maps["U"]) == K
+        for k in range(K):
+            np.testing.assert_allclose(maps["W"][k](alt), Wk[k], rtol=1e-6)
+            np.testing.assert_allclose(maps["U"][k](alt), Uk[k], rtol=1e-6)
+            np.testing.assert_allclose(maps["b"][k](alt), bk[k], rtol=1e-6)
+        for k in range(K - 1):
+            np.testing.assert_allclose(maps["S"][k](alt), Sk[k], rtol=1e-5, atol=1e-6)
+
+
+def test_simple_deep_rnn_rejects_uncovered_configs():
+    from drnmf_amd import layers
+    P = O.synth_problem(2, 3, 21, 6, seed=5)
+    N, K = 12, 2
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(3.0), lam1=np.float32(0.3))
+    alt, maps = layers.build_alt(N, K, params)
+    ok = dict(activation="relu", K_layers=K, alt_params=alt, maps_from_alt=maps,
+              flag_connect_input_to_layers=True, flag_nonnegative=True, return_sequences=True)
+    cell = layers.SimpleDeepRNN(N, **ok)
+    assert cell.compute_output_shape((7, 11, 21)) == (7, 11, N)
+    cell.flag_return_all_hidden = True
+    assert cell.compute_output_shape((7, 11, 21)) == (7, 11, K * N)
+    cell.return_sequences = False
+    assert cell.compute_output_shape((7, 11, 21)) == (7, K * N)
+    assert cell.get_config()["K_layers"] == K
+    for bad in (dict(activation="tanh"), dict(flag_nonnegative=False),
+                dict(flag_connect_input_to_layers=False), dict(dropout_W=0.5),
+                dict(stateful=True), dict(maps_from_alt={"W": lambda a: a})):
+        kw = dict(ok)
+        kw.update(bad)
+        with pytest.raises(NotImplementedError):
+            layers.SimpleDeepRNN(N, **kw)
+
+
+def test_build_unfolded_snmf_argument_errors():
+    from drnmf_amd import layers
+    P = O.synth_problem(2, 3, 21, 6, seed=5)
+    base = dict(input_dim=21, hidden_dim=12, output_dim=21, mask_value=-1., maxseq=3, K_layers=2,
+                W=P["W"], alph=3.0, lam1=0.3)
+    with pytest.raises(ValueError):                      # reference: NameError (enhance.py:263)
+        layers.build_unfolded_snmf(dict(base))
+    with pytest.raises(ValueError):
+        layers.build_unfolded_snmf(dict(base, params_trainable=["log_D"], W=P["W"][:, :5]))
+    with pytest.raises(ValueError):
+        layers.build_unfolded_snmf(dict(base, params_trainable=["log_D"],
+                                        transform_before_irm="cube"))
