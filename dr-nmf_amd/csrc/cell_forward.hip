@@ -7,66 +7,74 @@
 //     layer k : h' = relu(h + ((x - h Dn_k^T) Dn_k)*ia_k + b_k + uko*sum(p))
 //
 // The chain over (t, k) is strictly sequential; only the batch rows and the inside of each
-// contraction are parallel.  One layer-step is two dependent skinny GEMMs (B x N x F each) that
-// need the whole dictionary, so the dictionary is distributed over the chip by ATOM BLOCKS and
-// the only cross-workgroup exchange per layer-step is the reduction of the partial
-// reconstructions x^ = sum_blocks h[:, block] Dn[:, block]^T.  On gfx950 a kernel boundary
-// (~1.5 us) is cheaper than any in-kernel all-to-all, so the seam is cut THERE:
+// contraction are parallel.  One layer-step is two dependent skinny GEMMs (B x N x F each) with
+// an all-to-all between them (x^ contracts over every atom, g over every bin).  On gfx950 a
+// kernel boundary (~2 us) is cheaper than any in-kernel all-to-all, so each GEMM is one launch
+// sized to the whole chip and the exchange rides on the boundary:
 //
-//   cell_layer_kernel (one workgroup = 16 batch rows x 32 atoms, all F):
-//       g  = r[16 x F] . Dn_k[F x 32]            MFMA, F split over the 4 waves, LDS reduce
-//       h' = relu(...)                           fused epilogue (+ mask select, row sums, output)
-//       x^_part = h'[16 x 32] . Dn_{k+1}[F x 32]^T  MFMA, F tiles split over the 4 waves
-//   reduce_residual_kernel:  r = x_t - sum_blocks x^_part
+//   cell_a_kernel  (workgroup = 16 batch rows x 32 atoms, all bins; bins split over 4 waves):
+//       r  = sum_ks rpart[ks]                  (x_t for layer 0)
+//       g  = r[16 x F] . Dn_k[F x 32]          MFMA + LDS reduce over the 4 waves
+//       h' = relu(...)                         fused epilogue (+ mask select, row sums, output)
+//   cell_b_kernel  (workgroup = 16 rows x 16 bins x one of KS atom ranges; atoms over 4 waves):
+//       x^ = h'[16 x N/KS] . Dn_{k+1}[16 x N/KS]^T   MFMA + LDS reduce
+//       rpart[ks] = (ks==0 ? x_t : 0) - x^     (the KS partials are summed by the next cell_a)
 //
-// so a frame is 2K-1 launches (+1 frame-counter bump), captured once as a hipGraph and replayed
-// T times; kernels read the frame index from device memory.  The dictionary slice of a
-// workgroup (F x 32 floats = 128-byte rows) is read straight into MFMA operand registers: it is
-// not shared between the waves of a workgroup, so an LDS round trip would only add latency.
+// Internal layouts are TILE-PACKED: every matrix the two kernels exchange (dictionary, h, state,
+// residual partials, packed input) is stored as 1 KB blocks of 16 x 16 floats, so that each MFMA
+// operand load instruction of a wave covers contiguous full cache lines (a row-major layout makes
+// every load touch 16 half-used lines and the kernels stall on VMEM issue):
+//     Dp[ft][ac][f%16][n%16]   Hp[m][ac][row%16][n%16]   Rp[m][ft][row%16][perm(f%16)]
+// with ft = f/16, ac = n/16, m = row/16 and perm(e) = (e%4)*4 + e/4 (cell_a contracts bins in
+// the slot order f = 16c + 4s + q so that its dictionary loads cover whole lines).
+//
+// A frame is 2K-1 launches, built once as a hipGraph and replayed T times; kernels read the frame
+// index from device memory.  Dictionary operands are read straight into MFMA operand registers:
+// they are not shared between the waves of a workgroup, so an LDS round trip would only add
+// latency; all of a wave's operand loads are issued before its first MFMA.
 #include "common.h"
 
 namespace {
 
 constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
-constexpr int ATOMS = 32;   // atoms per workgroup
-constexpr int HT_LD = 36;   // LDS row stride of the h tile (floats): 16-byte pad vs bank conflicts
+constexpr int ATOMS = 32;   // atoms per cell_a workgroup
+constexpr int MAX_KS = 8;
 
-struct CellArgs {
+struct CellAArgs {
     const float* Dn;         // [Fp][Np]  this layer's unit-norm dictionary
-    const float* Dn_next;    // [Fp][Np]  next layer's (unused when last)
     const float* inv_alpha;  // [Np]
     const float* bias;       // [Np]
-    const float* rsrc;       // first layer: xp [T][Bp][Fp]; else r [Bp][Fp]
+    const float* rsrc;       // first layer: xp [T][Bp][Fp]; else rpart [KS][Bp][Fp]
     const float* h_in;       // [Bp][Np]  previous layer's h (first layer: the state p)
     float* h_out;            // [Bp][Np]  this layer's h (last layer: the state)
     float* state;            // [Bp][Np]
-    float* partial;          // [numA][Bp][Fp]
     float* rs_part;          // [2][numA][Bp] row sums of the state per atom block, by frame parity
     float* psum;             // [Bp]  sum(p) of the current frame
     const unsigned char* valid;  // [T][Bp]
     float* out;              // [B][T][out_width]
-    const int* tptr;         // device frame counter
+    const int* t_rd;         // frame counter to read
+    int* t_wr;               // counter to publish (or null)
+    int t_wr_add;
     float u0d, u0o, uko;
-    int B, T, N, Bp, Fp, Np, numA, nchunks;
+    int B, T, N, Bp, Fp, Np, numA, nchunks, KS;
     int out_width, out_off, write_out;
 };
 
-struct ReduceArgs {
-    const float* xp;       // [T][Bp][Fp]
-    const float* partial;  // [numA][Bp][Fp]
-    float* r;              // [Bp][Fp]
-    const int* tptr;
-    int n4;                // Bp*Fp/4
-    int numA;
+struct CellBArgs {
+    const float* Dn_next;    // [Fp][Np]  next layer's dictionary
+    const float* h;          // [Bp][Np]  this layer's h
+    const float* xp;         // [T][Bp][Fp]
+    float* rpart;            // [KS][Bp][Fp]
+    const int* t_rd;
+    int Bp, Fp, Np, nft, KS, nch_ks;   // nch_ks = 16-atom chunks per atom range
 };
 
-// G = chunks of 16 bins handled per wave per group (all of a group's operand loads are issued
-// before its first MFMA so that one memory round trip covers the group).
-template <int G, bool IS_FIRST, bool IS_LAST>
-__global__ void __launch_bounds__(256) cell_layer_kernel(const CellArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * ROWS * ATOMS + ROWS * HT_LD];
-    float* red = lds;                         // [4][16][32]
-    float* htile = lds + 4 * ROWS * ATOMS;    // [16][HT_LD]
+// G = 16-bin chunks handled per wave per group (all of a group's operand loads are issued before
+// its first MFMA so that one memory round trip covers the group).
+template <int G, int KS, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN>
+__global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
+    constexpr bool WRITE_OUT = IS_LAST || ALL_HIDDEN;
+    __shared__ __attribute__((aligned(16))) float red[4 * ROWS * ATOMS];   // [4][16][32]
 
     // XCD-aware block -> (atom block, row tile): blocks are dealt round-robin to the 8 XCDs, so
     // the row tiles that share one dictionary slice are given the same blockIdx % 8.
@@ -77,22 +85,62 @@ __global__ void __launch_bounds__(256) cell_layer_kernel(const CellArgs a) {
     if (ab >= a.numA) return;
 
     const int tid = threadIdx.x;
-    const int w = tid >> 6, l = tid & 63, j = l & 15, q = l >> 4;
-    const int t = *a.tptr;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int l = tid & 63, j = l & 15, q = l >> 4;
     const int Fp = a.Fp, Np = a.Np;
     const int row0 = m * ROWS, n0 = ab * ATOMS;
+    const size_t pstride = (size_t)a.Bp * Fp;     // one r partial
 
-    const float* rsrc = IS_FIRST ? a.rsrc + (size_t)t * a.Bp * Fp : a.rsrc;
-    const float* arow = rsrc + (size_t)(row0 + j) * Fp + 4 * q;         // + 16*c
-    const float* brow = a.Dn + (size_t)(4 * q) * Np + n0 + 2 * j;       // + (16*c + s)*Np
-    const float* nrow = a.Dn_next + (size_t)j * Np + n0 + 4 * q;        // + 16*ft*Np + 16*u
+    int t = 0;
+    if (IS_FIRST) {
+        t = *a.t_rd;
+        if (a.t_wr && blockIdx.x == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
+    }
+    const float* rsrc = IS_FIRST ? a.rsrc + (size_t)t * pstride : a.rsrc;
+    const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
+    // A: block (m, c) of Rp, lane (row j, slot q) reads the float4 {s = 0..3} <-> f = 16c+4s+q
+    const float* arow = rsrc + (size_t)m * nft * 256 + j * 16 + q * 4;            // + 256*c
+    // B: blocks (c, ac0 | ac0+1) of Dp, rows 4s+q, atoms 2j, 2j+1 of the 32
+    const float* brow = a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + q * 16 + (j & 7) * 2;
+    const size_t bstep = (size_t)NAC * 256;                                        // per chunk c
 
-    // ---- epilogue operands (issued first: tiny, needed last) -------------------------------
+    // ---- GEMM operands first (critical path), wave w takes chunks c = w (mod 4) -------------
+    // Loads are branch-free (out-of-range chunks are clamped to the last chunk and their A
+    // operand zeroed) so that the compiler can retire them with counted vmcnt waits and the
+    // MFMAs start as soon as the first chunk lands.
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int per_wave = (a.nchunks - w + 3) >> 2;   // chunks owned by this wave (>= 0)
+    const int clast = a.nchunks - 1;
+    constexpr int NP = IS_FIRST ? 1 : KS;
+
+    f32x4 av[G][NP];
+    f32x2 bv[G][4];
+    auto load_group = [&](int base) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            int c = w + 4 * (base + g);
+            c = c > clast ? clast : c;
+#pragma unroll
+            for (int ks = 0; ks < NP; ++ks)
+                av[g][ks] = *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
+        }
+    };
+    load_group(0);
+
+    // ---- epilogue operands (tiny, needed last; issued behind the GEMM operands) --------------
     const int erow = tid >> 4, ec = (tid & 15) * 2;
     const int rg = row0 + erow, n = n0 + ec;
-    const f32x2 hp = *(const f32x2*)(a.h_in + (size_t)rg * Np + n);
+    const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
+    const f32x2 hp = *(const f32x2*)(a.h_in + hoff);
     const f32x2 ia = *(const f32x2*)(a.inv_alpha + n);
     const f32x2 bs = *(const f32x2*)(a.bias + n);
+    if (!IS_FIRST && WRITE_OUT) {
+        t = *a.t_rd;
+        if (a.t_wr && blockIdx.x == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
+    }
     float ps;
     if (IS_FIRST) {
         // sum(p) = sum over atom blocks of the row sums left by the previous frame's last layer,
@@ -109,46 +157,33 @@ __global__ void __launch_bounds__(256) cell_layer_kernel(const CellArgs a) {
     } else {
         ps = a.psum[rg];
     }
+    bool vld = true;
+    if (WRITE_OUT) vld = a.valid[(size_t)t * a.Bp + rg] != 0;
 
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 nb[G][2];
-
-    // ---- GEMM a:  g[16 x 32] = r[16 x F] . Dn[F x 32], wave w takes chunks c = w (mod 4) ------
-    const int per_wave = (a.nchunks - w + 3) >> 2;   // chunks owned by this wave
-    for (int base = 0; base < per_wave; base += G) {
-        f32x4 av[G];
-        f32x2 bv[G][4];
+    // ---- GEMM:  g[16 x 32] = r[16 x F] . Dn[F x 32] -------------------------------------------
+    auto compute_group = [&](int base) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (base + g < per_wave) {
-                const int c = w + 4 * (base + g);
-                av[g] = *(const f32x4*)(arow + 16 * c);
+            f32x4 r4 = av[g][0];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    bv[g][s] = *(const f32x2*)(brow + (size_t)(16 * c + s) * Np);
+            for (int ks = 1; ks < NP; ++ks) r4 += av[g][ks];
+            if (base + g >= per_wave) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = mfma16(r4[s], bv[g][s][0], acc0);
+                acc1 = mfma16(r4[s], bv[g][s][1], acc1);
             }
         }
-        if (!IS_LAST && base == 0) {
-            // prefetch GEMM b's dictionary operands behind GEMM a's: in flight during GEMM a
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (g < per_wave) {
-                    const int ft = w + 4 * g;
-                    nb[g][0] = *(const f32x4*)(nrow + (size_t)(16 * ft) * Np);
-                    nb[g][1] = *(const f32x4*)(nrow + (size_t)(16 * ft) * Np + 16);
-                }
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (base + g < per_wave) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc0 = mfma16(av[g][s], bv[g][s][0], acc0);
-                    acc1 = mfma16(av[g][s], bv[g][s][1], acc1);
-                }
-            }
-        }
+    };
+    // all loads above stay above (the scheduler would otherwise sink each chunk's loads next to
+    // its MFMAs and serialise the memory round trips); the MFMAs then retire them with counted
+    // vmcnt waits in issue order
+    __builtin_amdgcn_sched_barrier(0);
+    compute_group(0);
+    for (int base = G; base < per_wave; base += G) {
+        load_group(base);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_group(base);
     }
 
     // ---- cross-wave reduction of the 4 F-splits through LDS --------------------------------
@@ -178,9 +213,7 @@ __global__ void __launch_bounds__(256) cell_layer_kernel(const CellArgs a) {
     }
 
     const bool row_live = rg < a.B;
-    bool vld = true;
-    if (IS_LAST || a.write_out) vld = a.valid[(size_t)t * a.Bp + rg] != 0;
-    if (a.write_out && row_live) {
+    if (WRITE_OUT && row_live) {
         // K.rnn masking: a masked step repeats the previous output (zeros before the first
         // valid step)
         float* orow = a.out + ((size_t)rg * a.T + t) * a.out_width + a.out_off;
@@ -196,8 +229,8 @@ __global__ void __launch_bounds__(256) cell_layer_kernel(const CellArgs a) {
     if (IS_LAST) {
         // ... and keeps the previous state
         f32x2 st = hn;
-        if (!vld) st = IS_FIRST ? hp : *(const f32x2*)(a.state + (size_t)rg * Np + n);
-        *(f32x2*)(a.state + (size_t)rg * Np + n) = st;
+        if (!vld) st = IS_FIRST ? hp : *(const f32x2*)(a.state + hoff);
+        *(f32x2*)(a.state + hoff) = st;
         float s = st[0] + st[1];
         s += __shfl_xor(s, 8, 16);
         s += __shfl_xor(s, 4, 16);
@@ -206,74 +239,91 @@ __global__ void __launch_bounds__(256) cell_layer_kernel(const CellArgs a) {
         if ((tid & 15) == 0)
             a.rs_part[((size_t)((t + 1) & 1) * a.numA + ab) * a.Bp + rg] = s;
     } else {
-        *(f32x2*)(a.h_out + (size_t)rg * Np + n) = hn;
-        *(f32x2*)(htile + erow * HT_LD + ec) = hn;
-        __syncthreads();
-
-        // ---- GEMM b: x^_part[16 x F] = h'[16 x 32] . Dn_next[F x 32]^T ---------------------
-        // contraction slot (u, q, c) <-> local atom 16u + 4q + c on both operands
-        const f32x4 ha0 = *(const f32x4*)(htile + j * HT_LD + 4 * q);
-        const f32x4 ha1 = *(const f32x4*)(htile + j * HT_LD + 16 + 4 * q);
-        float* prow = a.partial + ((size_t)ab * a.Bp + row0 + 4 * q) * Fp + j;
-        for (int base = 0; base < per_wave; base += G) {
-            if (base > 0) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (base + g < per_wave) {
-                        const int ft = w + 4 * (base + g);
-                        nb[g][0] = *(const f32x4*)(nrow + (size_t)(16 * ft) * Np);
-                        nb[g][1] = *(const f32x4*)(nrow + (size_t)(16 * ft) * Np + 16);
-                    }
-                }
-            }
-            f32x4 xa[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) xa[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-                    if (base + g < per_wave) xa[g] = mfma16(ha0[c], nb[g][0][c], xa[g]);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-                    if (base + g < per_wave) xa[g] = mfma16(ha1[c], nb[g][1][c], xa[g]);
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (base + g < per_wave) {
-                    const int ft = w + 4 * (base + g);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) prow[(size_t)v * Fp + 16 * ft] = xa[g][v];
-                }
-            }
-        }
+        *(f32x2*)(a.h_out + hoff) = hn;
     }
 }
 
-// r = x_t - sum_blocks x^_part.  256 threads = 32 float4 outputs x 8 block subsets; the subsets
-// are combined through LDS in a fixed order.
-__global__ void __launch_bounds__(256) reduce_residual_kernel(const ReduceArgs a) {
-    __shared__ f32x4 red[8][32];
-    const int el = threadIdx.x & 31, s = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + el;
-    const int t = *a.tptr;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (e < a.n4) {
-        const f32x4* p = (const f32x4*)a.partial + e;
-        for (int b = s; b < a.numA; b += 8) acc += p[(size_t)b * a.n4];
-    }
-    red[s][el] = acc;
-    __syncthreads();
-    if (s == 0 && e < a.n4) {
-        f32x4 tot = red[0][el];
+// x^ partial of one (row tile, bin tile, atom range) and the residual partial
+//   rpart[ks] = (ks == 0 ? x_t : 0) - h[16 x range] . Dn_next[16 bins x range]^T.
+// GB = 16-atom chunks per wave per group.
+template <int GB>
+__global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 16];
+    const int numM = a.Bp / ROWS;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int m = qb % numM;
+    const int rest = (qb / numM) * 8 + xcd;        // (bin tile, atom range)
+    if (rest >= a.nft * a.KS) return;
+    const int ft = rest / a.KS, ks = rest % a.KS;
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int l = tid & 63, j = l & 15, q = l >> 4;
+    const int Np = a.Np, Fp = a.Fp;
+    const int cbase = ks * a.nch_ks;                       // first chunk of this atom range
+    int nch = a.Np / 16 - cbase;                           // chunks left in the matrix
+    if (nch > a.nch_ks) nch = a.nch_ks;
+    if (nch < 1) nch = 1;                                  // (never: KS*nch_ks covers Np/16)
+    int per_wave = (nch - w + 3) >> 2;
+    const int clast = nch - 1;
+
+    const int NAC = Np / 16;
+    // blocks (m, cbase+c) of Hp and (ft, cbase+c) of Dp: lane (j, q) reads the float4 of atoms
+    // 16c + 4q + {0..3} in row j -> one contiguous 1 KB block per wave instruction
+    const float* arow = a.h + ((size_t)m * NAC + cbase) * 256 + j * 16 + q * 4;          // + 256*c
+    const float* brow = a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;   // + 256*c
+
+    // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
+    f32x4 av[GB], bv[GB];
+    auto load_group = [&](int base) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) tot += red[k][el];
-        const f32x4 xv = ((const f32x4*)a.xp)[(size_t)t * a.n4 + e];
-        ((f32x4*)a.r)[e] = xv - tot;
+        for (int g = 0; g < GB; ++g) {
+            int c = w + 4 * (base + g);
+            c = c > clast ? clast : c;
+            av[g] = *(const f32x4*)(arow + 256 * c);
+            bv[g] = *(const f32x4*)(brow + 256 * c);
+        }
+    };
+    load_group(0);
+
+    // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
+    const int erow = tid >> 4, ecol = tid & 15;
+    const size_t eoff = ((size_t)m * a.nft + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
+    float xv = 0.f;
+    if (ks == 0) {
+        const int t = *a.t_rd;
+        xv = a.xp[(size_t)t * a.Bp * Fp + eoff];
     }
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto compute_group = [&](int base) {
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            f32x4 a4 = av[g];
+            if (base + g >= per_wave) a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            // two independent accumulator chains hide the 40-cycle dependent MFMA latency
+            if (g & 1) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc1 = mfma16(a4[s], bv[g][s], acc1);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc0 = mfma16(a4[s], bv[g][s], acc0);
+            }
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);   // keep every load above its group's first MFMA
+    compute_group(0);
+    for (int base = GB; base < per_wave; base += GB) {
+        load_group(base);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_group(base);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[(w * 16 + 4 * q + v) * 16 + j] = acc0[v] + acc1[v];
+    __syncthreads();
+    const float s = (red[(0 * 16 + erow) * 16 + ecol] + red[(1 * 16 + erow) * 16 + ecol]) +
+                    (red[(2 * 16 + erow) * 16 + ecol] + red[(3 * 16 + erow) * 16 + ecol]);
+    a.rpart[(size_t)ks * a.Bp * Fp + eoff] = xv - s;
 }
 
 __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
@@ -288,15 +338,23 @@ pack_input_kernel(const float* __restrict__ x, float* __restrict__ xp,
     const size_t rowid = (size_t)blockIdx.x * 4 + wv;   // = t*Bp + b
     if (rowid >= (size_t)T * Bp) return;
     const int t = (int)(rowid / Bp), b = (int)(rowid % Bp);
-    float* dst = xp + rowid * Fp;
+    const int nft = Fp / 16;
+    // tile-packed destination: Rp[t][b/16][f/16][b%16][perm(f%16)]
+    float* dst = xp + (size_t)t * Bp * Fp + (size_t)(b >> 4) * nft * 256 + (b & 15) * 16;
     bool any = false;
     if (b < B) {
         const float* src = x + ((size_t)b * T + t) * F;
         for (int f = l; f < F; f += 64) any |= (src[f] != mask_value);
         any = __any(any);
-        for (int f = l; f < Fp; f += 64) dst[f] = (any && f < F) ? src[f] : 0.f;
+        for (int f = l; f < Fp; f += 64) {
+            const int e = f & 15;
+            dst[(size_t)(f >> 4) * 256 + ((e & 3) * 4 + (e >> 2))] = (any && f < F) ? src[f] : 0.f;
+        }
     } else {
-        for (int f = l; f < Fp; f += 64) dst[f] = 0.f;
+        for (int f = l; f < Fp; f += 64) {
+            const int e = f & 15;
+            dst[(size_t)(f >> 4) * 256 + ((e & 3) * 4 + (e >> 2))] = 0.f;
+        }
     }
     if (l == 0) valid[rowid] = any ? 1 : 0;
 }
@@ -316,20 +374,20 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
             v = (z > 20.f) ? z : log1pf(expf(z));
             s += v;
         }
-        for (int b = 0; b < Bp; ++b) state[(size_t)b * Np + n] = v;
+        for (int b = 0; b < Bp; ++b)   // tile-packed Hp[b/16][n/16][b%16][n%16]
+            state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + (b & 15) * 16 + (n & 15)] = v;
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((tid & 63) == 0) wsum[tid >> 6] = s;
     __syncthreads();
     const float tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     for (int i = tid; i < 2 * numA * Bp; i += 256) rs_part[i] = (i < Bp) ? tot : 0.f;
-    if (tid == 0) *tptr = 0;
+    if (tid == 0) { tptr[0] = 0; tptr[16] = 0; }
 }
 
 struct Workspace {
-    size_t off_xp, off_valid, off_r, off_h0, off_h1, off_state, off_partial, off_rs, off_psum,
-        off_t, total;
-    int Bp, Fp, Np, numA;
+    size_t off_xp, off_valid, off_rpart, off_h0, off_h1, off_state, off_rs, off_psum, off_t, total;
+    int Bp, Fp, Np, numA, KS, nch_ks;
 };
 
 Workspace workspace_layout(const drnmf_cell_desc_t* d) {
@@ -338,15 +396,21 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.Fp = pad_f(d->F);
     W.Np = pad_n(d->N);
     W.numA = W.Np / ATOMS;
+    // atom ranges per (row tile, bin tile) in cell_b: enough workgroups to cover the 256 CUs
+    const int tiles = (W.Bp / ROWS) * (W.Fp / 16);
+    const int nchN = W.Np / 16;
+    int KS = 1;
+    while (KS < MAX_KS && tiles * KS < 224 && nchN / (KS * 2) >= 4) KS *= 2;
+    W.KS = KS;
+    W.nch_ks = (nchN + KS - 1) / KS;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += round_up_sz(bytes, 256); return at; };
     W.off_xp = take((size_t)d->T * W.Bp * W.Fp * 4);
     W.off_valid = take((size_t)d->T * W.Bp);
-    W.off_r = take((size_t)W.Bp * W.Fp * 4);
+    W.off_rpart = take((size_t)MAX_KS * W.Bp * W.Fp * 4);
     W.off_h0 = take((size_t)W.Bp * W.Np * 4);
     W.off_h1 = take((size_t)W.Bp * W.Np * 4);
     W.off_state = take((size_t)W.Bp * W.Np * 4);
-    W.off_partial = take((size_t)W.numA * W.Bp * W.Fp * 4);
     W.off_rs = take((size_t)2 * W.numA * W.Bp * 4);
     W.off_psum = take((size_t)W.Bp * 4);
     W.off_t = take(256);
@@ -354,19 +418,43 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     return W;
 }
 
-template <int G>
-void* layer_func(bool first, bool last) {
-    if (first && last) return (void*)&cell_layer_kernel<G, true, true>;
-    if (first) return (void*)&cell_layer_kernel<G, true, false>;
-    if (last) return (void*)&cell_layer_kernel<G, false, true>;
-    return (void*)&cell_layer_kernel<G, false, false>;
+template <int G, int KS, bool AH>
+void* a_func(bool first, bool last) {
+    if (first && last) return (void*)&cell_a_kernel<G, KS, true, true, AH>;
+    if (first) return (void*)&cell_a_kernel<G, KS, true, false, AH>;
+    if (last) return (void*)&cell_a_kernel<G, KS, false, true, AH>;
+    return (void*)&cell_a_kernel<G, KS, false, false, AH>;
 }
 
-void* pick_layer_func(int nchunks, bool first, bool last) {
+template <int KS, bool AH>
+void* a_func_g(int per_wave, bool first, bool last) {
+    // keep operand registers (G * (4*KS + 8)) within budget: large KS only pairs with small G
+    if (per_wave <= 3) return a_func<3, KS, AH>(first, last);
+    if (per_wave <= 5 || KS >= 4) return a_func<5, KS, AH>(first, last);
+    return a_func<9, KS, AH>(first, last);
+}
+
+template <bool AH>
+void* pick_a_func_ah(int per_wave, int KS, bool first, bool last) {
+    switch (KS) {
+        case 1: return a_func_g<1, AH>(per_wave, first, last);
+        case 2: return a_func_g<2, AH>(per_wave, first, last);
+        case 4: return a_func_g<4, AH>(per_wave, first, last);
+        default: return a_func_g<8, AH>(per_wave, first, last);
+    }
+}
+
+void* pick_a_func(int nchunks, int KS, bool first, bool last, bool all_hidden) {
     const int per_wave = (nchunks + 3) / 4;
-    if (per_wave <= 3) return layer_func<3>(first, last);
-    if (per_wave <= 5) return layer_func<5>(first, last);
-    return layer_func<9>(first, last);
+    return all_hidden ? pick_a_func_ah<true>(per_wave, KS, first, last)
+                      : pick_a_func_ah<false>(per_wave, KS, first, last);
+}
+
+void* pick_b_func(int nch_ks) {
+    const int per_wave = (nch_ks + 3) / 4;
+    if (per_wave <= 4) return (void*)&cell_b_kernel<4>;
+    if (per_wave <= 8) return (void*)&cell_b_kernel<8>;
+    return (void*)&cell_b_kernel<16>;
 }
 
 }  // namespace
@@ -397,13 +485,13 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
     const char* pb = (const char*)params;
     float* xp = (float*)(ws + W.off_xp);
     unsigned char* valid = (unsigned char*)(ws + W.off_valid);
-    float* rbuf = (float*)(ws + W.off_r);
+    float* rpart = (float*)(ws + W.off_rpart);
     float* hb[2] = {(float*)(ws + W.off_h0), (float*)(ws + W.off_h1)};
     float* state = (float*)(ws + W.off_state);
-    float* partial = (float*)(ws + W.off_partial);
     float* rs_part = (float*)(ws + W.off_rs);
     float* psum = (float*)(ws + W.off_psum);
-    int* tptr = (int*)(ws + W.off_t);
+    int* tA = (int*)(ws + W.off_t);      // frame index read by every kernel of a frame
+    int* tB = tA + 16;                   // next frame index, published by the last kernel
     const int K = d->K;
 
     // ---- per-call prologue ------------------------------------------------------------------
@@ -412,11 +500,11 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
         hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                            stream, x, xp, valid, mask_value, d->B, d->T, d->F, W.Bp, W.Fp);
         hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
-                           rs_part, tptr, d->N, W.Np, W.Bp, W.numA);
+                           rs_part, tA, d->N, W.Np, W.Bp, W.numA);
         DRNMF_HIP(h, hipGetLastError());
     }
 
-    // ---- one frame = 2K-1 launches + counter bump, as a cached hipGraph ----------------------
+    // ---- one frame = 2K-1 launches, as a cached hipGraph -------------------------------------
     std::vector<uint64_t> key = {
         (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N, (uint64_t)d->K,
         (uint64_t)d->n_D, (uint64_t)d->return_all_hidden, (uint64_t)(uintptr_t)params,
@@ -428,51 +516,67 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
     }
     const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr;
 
-    const unsigned grid_layer = (unsigned)(round_up(W.numA, 8) * (W.Bp / ROWS));
-    const int n4 = W.Bp * W.Fp / 4;
-    const unsigned grid_reduce = (unsigned)((n4 + 31) / 32);
+    const int numM = W.Bp / ROWS, nft = W.Fp / 16;
+    const unsigned grid_a = (unsigned)(round_up(W.numA, 8) * numM);
+    const unsigned grid_b = (unsigned)(round_up(nft * W.KS, 8) * numM);
+    const float* Dn_base = (const float*)(pb + L.off_dn);
+    const size_t dstride = (size_t)L.Fp * L.Np;
+    auto Dn_of = [&](int k) { return Dn_base + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
 
-    auto make_args = [&](int k) {
-        CellArgs a;
-        const float* Dn_base = (const float*)(pb + L.off_dn);
-        const size_t dstride = (size_t)L.Fp * L.Np;
-        a.Dn = Dn_base + (d->n_D == 1 ? 0 : (size_t)k * dstride);
-        a.Dn_next = Dn_base + (d->n_D == 1 || k + 1 >= K ? 0 : (size_t)(k + 1) * dstride);
+    auto make_a = [&](int k) {
+        CellAArgs a;
+        a.Dn = Dn_of(k);
         a.inv_alpha = (const float*)(pb + L.off_inv_alpha) + (size_t)k * L.Np;
         a.bias = (const float*)(pb + L.off_bias) + (size_t)k * L.Np;
-        a.rsrc = (k == 0) ? xp : rbuf;
+        a.rsrc = (k == 0) ? xp : rpart;
         a.h_in = (k == 0) ? state : hb[(k - 1) & 1];
         a.h_out = (k == K - 1) ? state : hb[k & 1];
         a.state = state;
-        a.partial = partial;
         a.rs_part = rs_part;
         a.psum = psum;
         a.valid = valid;
         a.out = h_out;
-        a.tptr = tptr;
+        // frame counters: the first kernel of a frame reads tB and republishes it as tA; the last
+        // publishes tB = t+1; nobody reads a counter in the kernel that writes it.  K == 1 has a
+        // single kernel per frame and uses the separate advance kernel instead.
+        if (K == 1) { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
+        else if (k == 0) { a.t_rd = tB; a.t_wr = tA; a.t_wr_add = 0; }
+        else if (k == K - 1) { a.t_rd = tA; a.t_wr = tB; a.t_wr_add = 1; }
+        else { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
         a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
         a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
-        a.numA = W.numA; a.nchunks = W.Fp / 16;
+        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS;
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
         a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
         return a;
     };
-    ReduceArgs ra;
-    ra.xp = xp; ra.partial = partial; ra.r = rbuf; ra.tptr = tptr; ra.n4 = n4; ra.numA = W.numA;
+    auto make_b = [&](int k) {   // between layer k and k+1
+        CellBArgs b;
+        b.Dn_next = Dn_of(k + 1);
+        b.h = hb[k & 1];
+        b.xp = xp;
+        b.rpart = rpart;
+        b.t_rd = tA;
+        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS; b.nch_ks = W.nch_ks;
+        return b;
+    };
 
     if (!use_graph) {
         for (int t = 0; t < d->T; ++t) {
             for (int k = 0; k < K; ++k) {
-                CellArgs a = make_args(k);
+                CellAArgs a = make_a(k);
                 void* kp[1] = {&a};
-                DRNMF_HIP(h, hipLaunchKernel(pick_layer_func(a.nchunks, k == 0, k == K - 1),
-                                             dim3(grid_layer), dim3(256), kp, 0, stream));
-                if (k < K - 1)
-                    hipLaunchKernelGGL(reduce_residual_kernel, dim3(grid_reduce), dim3(256), 0,
-                                       stream, ra);
+                DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, k == 0, k == K - 1, d->return_all_hidden != 0),
+                                             dim3(grid_a), dim3(256), kp, 0, stream));
+                if (k < K - 1) {
+                    CellBArgs b = make_b(k);
+                    void* kb[1] = {&b};
+                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks), dim3(grid_b), dim3(256),
+                                                 kb, 0, stream));
+                }
             }
-            hipLaunchKernelGGL(advance_frame_kernel, dim3(1), dim3(1), 0, stream, tptr);
+            if (K == 1) hipLaunchKernelGGL(advance_frame_kernel, dim3(1), dim3(1), 0, stream, tA);
         }
         DRNMF_HIP(h, hipGetLastError());
         return DRNMF_OK;
@@ -508,12 +612,17 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
             return e;
         };
         for (int k = 0; k < K; ++k) {
-            CellArgs a = make_args(k);
-            DRNMF_HIP(h, add(pick_layer_func(a.nchunks, k == 0, k == K - 1), grid_layer, 256, &a));
-            if (k < K - 1) DRNMF_HIP(h, add((void*)&reduce_residual_kernel, grid_reduce, 256, &ra));
+            CellAArgs a = make_a(k);
+            DRNMF_HIP(h, add(pick_a_func(nft, W.KS, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 256, &a));
+            if (k < K - 1) {
+                CellBArgs b = make_b(k);
+                DRNMF_HIP(h, add(pick_b_func(W.nch_ks), grid_b, 256, &b));
+            }
         }
-        int* tp = tptr;
-        DRNMF_HIP(h, add((void*)&advance_frame_kernel, 1, 1, &tp));
+        if (K == 1) {
+            int* tp = tA;
+            DRNMF_HIP(h, add((void*)&advance_frame_kernel, 1, 1, &tp));
+        }
         DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
         h->graphs.push_back(ge);
         entry = &h->graphs.back();

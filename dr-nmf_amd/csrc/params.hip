@@ -74,18 +74,20 @@ extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
 }
 
 // One thread per (stored layer, atom column): pass 1 accumulates sum_f exp(log_D)^2 in f order,
-// pass 2 writes exp(log_D)/sqrt(sum) -- enhance.py:177-178 / 190-191.  Columns are contiguous
-// across lanes, so every row read/write is a coalesced 256-byte segment.  Padded rows/columns
-// are written as zeros.
+// pass 2 writes exp(log_D)/sqrt(sum) -- enhance.py:177-178 / 190-191 -- into the TILE-PACKED
+// dictionary Dp[ft][ac][f%16][n%16] (1 KB blocks of 16 bins x 16 atoms; see cell_forward.hip).
+// Padded rows/columns are written as zeros.
 __global__ void __launch_bounds__(256)
 prep_dict_kernel(const float* __restrict__ log_D, float* __restrict__ Dn,
                  float* __restrict__ colnorm, int F, int N, int Fp, int Np) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int layer = blockIdx.y;
     if (n >= Np) return;
-    float* dn = Dn + (size_t)layer * Fp * Np;
+    const int NAC = Np / 16;
+    float* dn = Dn + (size_t)layer * Fp * Np + (size_t)(n >> 4) * 256 + (n & 15);
+    auto at = [&](int f) -> float& { return dn[(size_t)(f >> 4) * NAC * 256 + (f & 15) * 16]; };
     if (n >= N) {
-        for (int f = 0; f < Fp; ++f) dn[(size_t)f * Np + n] = 0.f;
+        for (int f = 0; f < Fp; ++f) at(f) = 0.f;
         colnorm[(size_t)layer * Np + n] = 1.f;
         return;
     }
@@ -97,8 +99,8 @@ prep_dict_kernel(const float* __restrict__ log_D, float* __restrict__ Dn,
     }
     const float nrm = sqrtf(s);
     colnorm[(size_t)layer * Np + n] = nrm;
-    for (int f = 0; f < F; ++f) dn[(size_t)f * Np + n] = expf(ld[(size_t)f * N + n]) / nrm;
-    for (int f = F; f < Fp; ++f) dn[(size_t)f * Np + n] = 0.f;
+    for (int f = 0; f < F; ++f) at(f) = expf(ld[(size_t)f * N + n]) / nrm;
+    for (int f = F; f < Fp; ++f) at(f) = 0.f;
 }
 
 // 1/alpha[n] and b[n] = -lam/alpha[n] per layer (enhance.py:187-194, 201-203).  Padded atoms get

@@ -51,7 +51,7 @@ def prepare_params(desc, log_D, log_alph, log_lam1, out=None):
 
 
 def unpack_params(block, desc):
-    """Views into a prepared block: (Dn [n_D,Fp,Np], colnorm [n_D,Np], inv_alpha [K,Np],
+    """Unpacked copies/views of a prepared block: (Dn [n_D,Fp,Np], colnorm [n_D,Np], inv_alpha [K,Np],
     bias [K,Np]) -- the layout of params_layout() in csrc/common.h."""
     Fp = (desc.F + 15) // 16 * 16
     Np = (desc.N + 31) // 32 * 32
@@ -59,7 +59,9 @@ def unpack_params(block, desc):
     f = block.view(torch.float32) if block.dtype != torch.float32 else block
     o = 0
     n = desc.n_D * Fp * Np
-    Dn = f[o:o + n].view(desc.n_D, Fp, Np); o += n
+    # tile-packed Dp[ft][ac][f%16][n%16] -> logical [Fp][Np]
+    Dn = f[o:o + n].view(desc.n_D, Fp // 16, Np // 16, 16, 16).permute(0, 1, 3, 2, 4) \
+        .reshape(desc.n_D, Fp, Np); o += n
     n = desc.n_D * Np
     colnorm = f[o:o + n].view(desc.n_D, Np); o += r256(n * 4) // 4
     n = desc.K * Np
