@@ -505,10 +505,13 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
     }
 
     // ---- one frame = 2K-1 launches, as a cached hipGraph -------------------------------------
+    // measurement aid: DRNMF_ABLATE=1 launches the same grids but every workgroup exits at once
+    // (launch/boundary floor of the frame graph; results are garbage)
+    const bool ablate = getenv("DRNMF_ABLATE") != nullptr;
     std::vector<uint64_t> key = {
         (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N, (uint64_t)d->K,
         (uint64_t)d->n_D, (uint64_t)d->return_all_hidden, (uint64_t)(uintptr_t)params,
-        (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace};
+        (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)ablate};
     {
         uint32_t b0, b1, b2;
         memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
@@ -545,7 +548,7 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
         else { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
         a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
         a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
-        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS;
+        a.numA = ablate ? 0 : W.numA; a.nchunks = nft; a.KS = W.KS;
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
         a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
@@ -558,7 +561,8 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
         b.xp = xp;
         b.rpart = rpart;
         b.t_rd = tA;
-        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS; b.nch_ks = W.nch_ks;
+        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = ablate ? 0 : nft; b.KS = W.KS;
+        b.nch_ks = W.nch_ks;
         return b;
     };
 

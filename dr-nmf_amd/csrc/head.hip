@@ -27,6 +27,19 @@ head_exp_kernel(const float* __restrict__ kc, const float* __restrict__ kn,
     ecat[i] = v;
 }
 
+// the SNMF ratio mask uses the dictionary itself (no exp): ecat[seg][k][f] = Wn[f][seg*r + k]
+__global__ void __launch_bounds__(256)
+head_w_kernel(const float* __restrict__ Wn, float* __restrict__ ecat, int r, int rp, int F, int Fp,
+              int N) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t tot = (size_t)2 * rp * Fp;
+    if (i >= tot) return;
+    const int f = (int)(i % Fp);
+    const int k = (int)((i / Fp) % rp);
+    const int seg = (int)(i / ((size_t)Fp * rp));
+    ecat[i] = (k < r && f < F) ? Wn[(size_t)f * N + seg * r + k] : 0.f;
+}
+
 struct HeadArgs {
     const float* hidden;
     const float* ecat;
@@ -35,6 +48,7 @@ struct HeadArgs {
     float* Bn_out;
     int64_t rows, ld_h;
     int h_off, F, Fp, r, rp, square;
+    int mode;   // 0: exp(log(1e-7+A) - log(1e-7+A+B)) (custom_layers.py:44); 1: A/(1e-9+A+B) (enhance.py:852)
 };
 
 // workgroup = 4 waves x 32 rows; each wave owns 2 row tiles x FT bin tiles x {A, Bn}.
@@ -133,11 +147,33 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadArgs a) {
                 float A = acc[0][mt][ft][v], Bn = acc[1][mt][ft][v];
                 if (a.square) { A = A * A; Bn = Bn * Bn; }
                 const size_t o = (size_t)row * a.F + f;
-                a.mask[o] = expf(logf(1e-7f + A) - logf(1e-7f + A + Bn));
+                a.mask[o] = a.mode == 0 ? expf(logf(1e-7f + A) - logf(1e-7f + A + Bn))
+                                        : A / (1e-9f + A + Bn);
                 if (a.A_out) a.A_out[o] = A;
                 if (a.Bn_out) a.Bn_out[o] = Bn;
             }
         }
+}
+
+void launch_head(const HeadArgs& a, hipStream_t stream) {
+    const bool aligned = (a.ld_h % 4 == 0) && (a.h_off % 4 == 0) && (a.r % 4 == 0) &&
+                         (((uintptr_t)a.hidden & 15) == 0);
+    const int nt = a.Fp / 16;
+    // bin tiles per wave: the value in {4,3,2} that wastes the fewest padded tiles
+    int FT = 4, best = round_up(nt, 4);
+    if (round_up(nt, 3) < best) { FT = 3; best = round_up(nt, 3); }
+    if (round_up(nt, 2) < best) { FT = 2; }
+    dim3 grid((unsigned)((a.rows + 127) / 128), (unsigned)((nt + FT - 1) / FT));
+#define LAUNCH_HEAD(FT_, AL_) \
+    hipLaunchKernelGGL((head_kernel<FT_, AL_>), grid, dim3(256), 0, stream, a)
+    if (aligned) {
+        if (FT == 4) LAUNCH_HEAD(4, true); else if (FT == 3) LAUNCH_HEAD(3, true);
+        else LAUNCH_HEAD(2, true);
+    } else {
+        if (FT == 4) LAUNCH_HEAD(4, false); else if (FT == 3) LAUNCH_HEAD(3, false);
+        else LAUNCH_HEAD(2, false);
+    }
+#undef LAUNCH_HEAD
 }
 
 }  // namespace
@@ -165,25 +201,24 @@ extern "C" int32_t drnmf_head_forward(drnmf_handle_t h, int64_t rows, int32_t F,
     HeadArgs a;
     a.hidden = hidden; a.ecat = ecat; a.mask = mask; a.A_out = A_out; a.Bn_out = Bn_out;
     a.rows = rows; a.ld_h = ld_h; a.h_off = h_off; a.F = F; a.Fp = Fp; a.r = r; a.rp = rp;
-    a.square = square;
-    const bool aligned = (ld_h % 4 == 0) && (h_off % 4 == 0) && (r % 4 == 0) &&
-                         (((uintptr_t)hidden & 15) == 0);
-    const int nt = Fp / 16;
-    // bin tiles per wave: the value in {4,3,2} that wastes the fewest padded tiles
-    int FT = 4, best = round_up(nt, 4);
-    if (round_up(nt, 3) < best) { FT = 3; best = round_up(nt, 3); }
-    if (round_up(nt, 2) < best) { FT = 2; }
-    dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((nt + FT - 1) / FT));
-#define LAUNCH_HEAD(FT_, AL_) \
-    hipLaunchKernelGGL((head_kernel<FT_, AL_>), grid, dim3(256), 0, stream, a)
-    if (aligned) {
-        if (FT == 4) LAUNCH_HEAD(4, true); else if (FT == 3) LAUNCH_HEAD(3, true);
-        else LAUNCH_HEAD(2, true);
-    } else {
-        if (FT == 4) LAUNCH_HEAD(4, false); else if (FT == 3) LAUNCH_HEAD(3, false);
-        else LAUNCH_HEAD(2, false);
-    }
-#undef LAUNCH_HEAD
+    a.square = square; a.mode = 0;
+    launch_head(a, stream);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+// irm = Wc Hc / (1e-9 + Wc Hc + Wn Hn)  (enhance.py:848-852), H [rows][2r], Wn [F][2r]
+int head_irm_forward(drnmf_handle_t h, int64_t rows, int F, int r, const float* H, int64_t ld_h,
+                     const float* Wn, float* irm, float* ecat, hipStream_t stream) {
+    const int Fp = pad_f(F), rp = round_up(r, 16);
+    const size_t tot = (size_t)2 * rp * Fp;
+    hipLaunchKernelGGL(head_w_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, Wn,
+                       ecat, r, rp, F, Fp, 2 * r);
+    HeadArgs a;
+    a.hidden = H; a.ecat = ecat; a.mask = irm; a.A_out = nullptr; a.Bn_out = nullptr;
+    a.rows = rows; a.ld_h = ld_h; a.h_off = 0; a.F = F; a.Fp = Fp; a.r = r; a.rp = rp;
+    a.square = 0; a.mode = 1;
+    launch_head(a, stream);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }

@@ -1,0 +1,318 @@
+// Frame-parallel sparse-NMF inference on gfx950: K-iteration ISTA (enhance.py:402-456) and
+// multiplicative updates with a fixed dictionary (sparseNMF/sparse_nmf_gpu.m:163-173, 210-229;
+// enhance.py:838-852).  Frames are independent here, so every iteration is a pair of large-M
+// fp32-MFMA GEMMs (gemm_nt.h) whose epilogues carry the whole update:
+//     X^ = H W^T      -> residual / ratio written directly        (ISTA: g(X, X^);  MU: max(.,flr))
+//     G  = R W        -> H <- max(0, H + (G - lam1)/alph)   or    H <- H * DMH / max(G + sp, flr)
+// Row layout: frames are rows (X, V: [n][F]; H: [n][N]); W is [F][N] as in the reference.
+#include "gemm_nt.h"
+
+namespace {
+
+inline int pad4(int v) { return (v + 3) / 4 * 4; }
+
+// Wt[n][f] = W[f][n] (zero-padded to ld = Fp4): the second GEMM contracts over bins
+__global__ void __launch_bounds__(256)
+transpose_pad_kernel(const float* __restrict__ W, float* __restrict__ Wt, int F, int N, int Fp4) {
+    __shared__ float tile[32][33];
+    const int f0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int f = f0 + r, n = n0 + tx;
+        tile[r][tx] = (f < F && n < N) ? W[(size_t)f * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, f = f0 + tx;
+        if (n < N && f < Fp4) Wt[(size_t)n * Fp4 + f] = tile[tx][r];
+    }
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(float* p, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------- ISTA epilogues ----------------------------------------------------------------
+struct EpiResidual {   // R = g(X, X^): enhance.py:412 / 431 / 450
+    const float* X;
+    float* R;
+    int F, ldr, div;
+    float beta;
+    __device__ void operator()(int64_t row, int col, float xh) const {
+        const float x = X[row * F + col];
+        float r;
+        if (div == DRNMF_DIV_ED) r = x - xh;
+        else if (div == DRNMF_DIV_KL) r = x / xh - 1.f;
+        else r = x * powf(xh, beta - 2.f) - powf(xh, beta - 1.f);
+        R[row * ldr + col] = r;
+    }
+};
+
+struct EpiIstaUpdate {   // H <- max(0, -lam1/alph + H + (1/alph) G): enhance.py:412
+    float* H;
+    int N;
+    float neg_lam_over_alph, inv_alph;
+    __device__ void operator()(int64_t row, int col, float gacc) const {
+        float* p = H + row * N + col;
+        *p = fmaxf(0.f, neg_lam_over_alph + *p + inv_alph * gacc);
+    }
+};
+
+// ---------------- MU epilogues ------------------------------------------------------------------
+struct EpiStore {
+    float* C;
+    int ldc;
+    __device__ void operator()(int64_t row, int col, float v) const { C[row * ldc + col] = v; }
+};
+
+struct EpiLambda {   // lambda = max(W H, flr) and its beta-dependent derivatives
+    const float* V;
+    float* P1;   // beta==2: lambda;  beta==1: V/lambda;  else: lambda^(beta-1)
+    float* P2;   // general beta only: V * lambda^(beta-2)
+    int F, ld;
+    float beta, flr;
+    __device__ void operator()(int64_t row, int col, float acc) const {
+        const float lam = fmaxf(acc, flr);
+        const size_t o = row * ld + col;
+        if (beta == 2.f) {
+            P1[o] = lam;
+        } else if (beta == 1.f) {
+            P1[o] = V[row * F + col] / lam;
+        } else {
+            P1[o] = powf(lam, beta - 1.f);
+            P2[o] = V[row * F + col] * powf(lam, beta - 2.f);
+        }
+    }
+};
+
+struct EpiMuUpdate {   // H <- H * dmh / max(dph + sparsity, flr): sparse_nmf_gpu.m:217-227
+    float* H;
+    const float* DMH;      // [n][N] (beta != 1)
+    const float* colsum;   // [N]    (beta == 1: dph = sum_f w + sparsity, dmh = acc)
+    int N;
+    float sparsity, flr, beta;
+    __device__ void operator()(int64_t row, int col, float acc) const {
+        float* p = H + row * N + col;
+        if (beta == 1.f) {
+            *p = *p * acc / fmaxf(colsum[col] + sparsity, flr);
+        } else {
+            *p = *p * DMH[row * N + col] / fmaxf(acc + sparsity, flr);
+        }
+    }
+};
+
+// column norms of W and sums of the normalised columns: sparse_nmf_gpu.m:163-166
+__global__ void __launch_bounds__(256)
+mu_colnorm_kernel(const float* __restrict__ W, float* __restrict__ Wn, float* __restrict__ norm,
+                  float* __restrict__ colsum, int F, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float w = W[(size_t)f * N + n];
+        s = fmaf(w, w, s);
+    }
+    const float nrm = sqrtf(s);
+    float cs = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float w = W[(size_t)f * N + n] / nrm;
+        Wn[(size_t)f * N + n] = w;
+        cs += w;
+    }
+    norm[n] = nrm;
+    colsum[n] = cs;
+}
+
+__global__ void __launch_bounds__(256)
+mu_scale_h_kernel(float* __restrict__ H, const float* __restrict__ norm, int64_t total, int N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) H[i] *= norm[i % N];
+}
+
+// beta != 2: zeros of V are raised to the smallest positive entry (sparse_nmf_gpu.m:201-205)
+__global__ void __launch_bounds__(256)
+min_positive_kernel(const float* __restrict__ V, int64_t total, unsigned* out_bits) {
+    float m = __int_as_float(0x7f800000);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const float v = V[i];
+        if (v > 0.f && v < m) m = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(out_bits, __float_as_uint(m));   // positive floats
+}
+
+__global__ void __launch_bounds__(256)
+floor_zeros_kernel(const float* __restrict__ V, float* __restrict__ Vf, int64_t total,
+                   const unsigned* min_bits) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        const float v = V[i];
+        Vf[i] = (v == 0.f) ? __uint_as_float(*min_bits) : v;
+    }
+}
+
+struct IstaWs {
+    size_t off_R, off_Wt, total;
+    int Fp4;
+};
+IstaWs ista_ws(int64_t n, int F, int N) {
+    IstaWs w;
+    w.Fp4 = pad4(F);
+    size_t o = 0;
+    w.off_R = o;  o += round_up_sz((size_t)n * w.Fp4 * 4, 256);
+    w.off_Wt = o; o += round_up_sz((size_t)N * w.Fp4 * 4, 256);
+    w.total = o;
+    return w;
+}
+
+struct MuWs {
+    size_t off_P1, off_P2, off_Wt, off_DMH, off_norm, off_colsum, off_Vf, off_min, total;
+    int Fp4;
+};
+MuWs mu_ws(int64_t n, int F, int N) {
+    MuWs w;
+    w.Fp4 = pad4(F);
+    size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += round_up_sz(b, 256); return at; };
+    w.off_P1 = take((size_t)n * w.Fp4 * 4);
+    w.off_P2 = take((size_t)n * w.Fp4 * 4);
+    w.off_Wt = take((size_t)N * w.Fp4 * 4);
+    w.off_DMH = take((size_t)n * N * 4);
+    w.off_norm = take((size_t)N * 4);
+    w.off_colsum = take((size_t)N * 4);
+    w.off_Vf = take((size_t)n * F * 4);
+    w.off_min = take(256);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+int head_irm_forward(drnmf_handle_t h, int64_t rows, int F, int r, const float* H, int64_t ld_h,
+                     const float* Wn, float* irm, float* ecat, hipStream_t stream);
+
+extern "C" size_t drnmf_ista_workspace_bytes(int64_t n, int32_t F, int32_t N) {
+    if (n <= 0 || F <= 0 || N <= 0) return 0;
+    return ista_ws(n, F, N).total;
+}
+
+extern "C" int32_t drnmf_ista_forward(drnmf_handle_t h, int64_t n, int32_t F, int32_t N, int32_t K,
+                                      int32_t divergence, float beta, float lam1, float alph,
+                                      const float* X, const float* W, float* H, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n <= 0 || F <= 0 || N <= 0 || K < 0)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "ista_forward: bad shape n=%lld F=%d N=%d K=%d",
+                   (long long)n, F, N, K);
+    if (divergence < DRNMF_DIV_ED || divergence > DRNMF_DIV_BETA)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "ista_forward: unknown divergence %d", divergence);
+    if (!X || !W || !H || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "ista_forward: NULL pointer argument");
+    if (!(alph > 0.f)) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "ista_forward: alph must be > 0");
+    const IstaWs L = ista_ws(n, F, N);
+    if (workspace_bytes < L.total)
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "ista_forward: workspace %zu < required %zu",
+                   workspace_bytes, L.total);
+    hipStream_t stream = (hipStream_t)stream_;
+    float* R = (float*)((char*)workspace + L.off_R);
+    float* Wt = (float*)((char*)workspace + L.off_Wt);
+    const int Fp4 = L.Fp4;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Fp4 + 31) / 32, (N + 31) / 32), dim3(256), 0,
+                       stream, W, Wt, F, N, Fp4);
+    if (Fp4 != F) DRNMF_HIP(h, hipMemsetAsync(R, 0, (size_t)n * Fp4 * 4, stream));
+    gemm::Operands g1{H, W, n, F, N, N, N};          // X^ = H . W^T   (contract atoms)
+    gemm::Operands g2{R, Wt, n, N, Fp4, Fp4, Fp4};   // G  = R . W     (contract bins)
+    EpiResidual e1{X, R, F, Fp4, divergence, beta};
+    EpiIstaUpdate e2{H, N, -lam1 / alph, 1.f / alph};
+    for (int k = 0; k < K; ++k) {
+        DRNMF_HIP(h, gemm::launch(g1, e1, stream));
+        DRNMF_HIP(h, gemm::launch(g2, e2, stream));
+    }
+    return DRNMF_OK;
+}
+
+extern "C" size_t drnmf_mu_workspace_bytes(int64_t n, int32_t F, int32_t N) {
+    if (n <= 0 || F <= 0 || N <= 0) return 0;
+    const MuWs w = mu_ws(n, F, N);
+    // + head scratch for the optional IRM: ecat [2*rp][Fp16]
+    return w.total + round_up_sz((size_t)2 * round_up(N / 2 + 1, 16) * pad_f(F) * 4, 256);
+}
+
+extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int32_t N,
+                                    int32_t n_iter, float beta, float sparsity, const float* V,
+                                    const float* W, float* Wn, float* H, float* irm,
+                                    void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n <= 0 || F <= 0 || N <= 0 || n_iter < 0)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "mu_forward: bad shape n=%lld F=%d N=%d iters=%d",
+                   (long long)n, F, N, n_iter);
+    if (!V || !W || !Wn || !H || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "mu_forward: NULL pointer argument");
+    if (irm && (N % 2))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "mu_forward: IRM needs an even number of atoms");
+    if (workspace_bytes < drnmf_mu_workspace_bytes(n, F, N))
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "mu_forward: workspace %zu < required %zu",
+                   workspace_bytes, drnmf_mu_workspace_bytes(n, F, N));
+    hipStream_t stream = (hipStream_t)stream_;
+    const MuWs L = mu_ws(n, F, N);
+    char* ws = (char*)workspace;
+    float* P1 = (float*)(ws + L.off_P1);
+    float* P2 = (float*)(ws + L.off_P2);
+    float* Wt = (float*)(ws + L.off_Wt);
+    float* DMH = (float*)(ws + L.off_DMH);
+    float* norm = (float*)(ws + L.off_norm);
+    float* colsum = (float*)(ws + L.off_colsum);
+    float* Vf = (float*)(ws + L.off_Vf);
+    unsigned* minb = (unsigned*)(ws + L.off_min);
+    float* ecat = (float*)(ws + L.total);
+    const int Fp4 = L.Fp4;
+    const float flr = 1e-9f;                                            // sparse_nmf_gpu.m:172
+    const int64_t nH = n * (int64_t)N, nV = n * (int64_t)F;
+
+    // normalise the columns of W, rescale H (sparse_nmf_gpu.m:163-166)
+    hipLaunchKernelGGL(mu_colnorm_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, W, Wn, norm,
+                       colsum, F, N);
+    hipLaunchKernelGGL(mu_scale_h_kernel, dim3((unsigned)((nH + 255) / 256)), dim3(256), 0, stream,
+                       H, norm, nH, N);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Fp4 + 31) / 32, (N + 31) / 32), dim3(256), 0,
+                       stream, Wn, Wt, F, N, Fp4);
+    const float* Vuse = V;
+    if (beta != 2.f) {   // sparse_nmf_gpu.m:201-205
+        DRNMF_HIP(h, hipMemsetAsync(minb, 0x7f, 4, stream));   // 0x7f7f7f7f: a huge positive float
+        hipLaunchKernelGGL(min_positive_kernel, dim3(1024), dim3(256), 0, stream, V, nV, minb);
+        hipLaunchKernelGGL(floor_zeros_kernel, dim3((unsigned)((nV + 255) / 256)), dim3(256), 0,
+                           stream, V, Vf, nV, minb);
+        Vuse = Vf;
+    }
+    if (Fp4 != F) {
+        DRNMF_HIP(h, hipMemsetAsync(P1, 0, (size_t)n * Fp4 * 4, stream));
+        DRNMF_HIP(h, hipMemsetAsync(P2, 0, (size_t)n * Fp4 * 4, stream));
+    }
+    gemm::Operands gl{H, Wn, n, F, N, N, N};            // W H  (row layout: H . Wn^T)
+    EpiLambda el{Vuse, P1, P2, F, Fp4, beta, flr};
+    if (beta == 2.f) {
+        // dmh = W^T V is loop invariant: one GEMM V . W up front (V copied to a padded buffer so
+        // the contraction over bins can use 16-byte loads)
+        DRNMF_HIP(h, hipMemcpy2DAsync(P2, (size_t)Fp4 * 4, V, (size_t)F * 4, (size_t)F * 4,
+                                      (size_t)n, hipMemcpyDeviceToDevice, stream));
+        gemm::Operands gd{P2, Wt, n, N, Fp4, Fp4, Fp4};
+        DRNMF_HIP(h, gemm::launch(gd, EpiStore{DMH, N}, stream));
+    }
+    DRNMF_HIP(h, gemm::launch(gl, el, stream));         // lambda before the loop (:173)
+    for (int it = 0; it < n_iter; ++it) {
+        if (beta != 2.f && beta != 1.f) {
+            gemm::Operands gd{P2, Wt, n, N, Fp4, Fp4, Fp4};
+            DRNMF_HIP(h, gemm::launch(gd, EpiStore{DMH, N}, stream));
+        }
+        gemm::Operands gu{P1, Wt, n, N, Fp4, Fp4, Fp4};
+        DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate{H, DMH, colsum, N, sparsity, flr, beta}, stream));
+        DRNMF_HIP(h, gemm::launch(gl, el, stream));     // lambda = max(w*h, flr)  (:228)
+    }
+    if (irm) {
+        int rc = head_irm_forward(h, n, F, N / 2, H, N, Wn, irm, ecat, stream);
+        if (rc) return rc;
+    }
+    return DRNMF_OK;
+}

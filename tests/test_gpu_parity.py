@@ -223,3 +223,66 @@ def test_full_size_layer_against_oracle(dev):
     assert np.all(h >= 0)
     agree = np.mean((h > 0) == (ref > 0))
     assert agree > 0.9999
+
+
+# ------------------------------------------------------------------ frame-parallel ISTA / MU
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("name", ["ed", "kl", "beta"])
+def test_ista_matches_reference_golden_vectors(dev, golden, tag, name):
+    """HIP frame-parallel ISTA vs the outputs of the reference's own ista_* (golden fixtures)."""
+    from drnmf_amd import ops
+    g = golden
+    W, x, H0 = g["ista_%s_W" % tag], g["ista_%s_x" % tag], g["ista_%s_H0" % tag]
+    lam1, K = float(g["ista_%s_lam1" % tag]), int(g["ista_%s_K" % tag])
+    alph = float(g["ista_%s_alph" % tag] if name == "ed" else g["ista_%s_alph_kl" % tag])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    H = t(H0.T)                                   # row layout: frames are rows
+    ops.ista_forward(t(x.T), t(W), H, lam1, alph, K, divergence=name,
+                     beta=float(g["ista_beta_value"]))
+    torch.cuda.synchronize()
+    ref = g["ista_%s_%s_H" % (tag, name)].T.astype(np.float64)
+    got = H.cpu().numpy()
+    err = np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-30)
+    assert err <= 2e-5, "ista_%s %s: rel err %.3e" % (name, tag, err)
+
+
+def test_ista_large_ragged_shape_vs_oracle(dev):
+    """several 128x128 GEMM tiles with ragged edges (n=300, F=257, N=200)."""
+    from drnmf_amd import ops
+    rng = np.random.default_rng(5)
+    n, F, N, K = 300, 257, 200, 7
+    W = rng.random((F, N)) ** 4
+    W = (W / np.sqrt((W * W).sum(0, keepdims=True))).astype(np.float32)
+    Ht = ((rng.random((N, n)) < 0.05) * rng.random((N, n)) * 3).astype(np.float32)
+    x = (W @ Ht + 0.01 * rng.random((F, n))).astype(np.float32)
+    H0 = (0.1 * rng.random((N, n))).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    H = t(H0.T)
+    ops.ista_forward(t(x.T), t(W), H, 0.5, 50.0, K)
+    torch.cuda.synchronize()
+    ref = O.ista_ed(x.astype(np.float64), W.astype(np.float64), H0.astype(np.float64), 0.5, 50.0, K)
+    err = np.max(np.abs(H.cpu().numpy() - ref.T)) / np.max(np.abs(ref))
+    assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("beta", [2.0, 1.0, 1.5])
+def test_mu_inference_and_irm_vs_oracle(dev, beta):
+    from drnmf_amd import ops
+    rng = np.random.default_rng(6)
+    n, F, N, iters = 150, 65, 24, 30
+    W = rng.random((F, N)).astype(np.float32) * 3            # deliberately NOT normalised
+    V = (W @ ((rng.random((N, n)) < 0.3) * rng.random((N, n))) + 1e-3).astype(np.float32)
+    if beta != 2.0:
+        V[rng.random(V.shape) < 0.02] = 0.0                  # zeros get floored for beta != 2
+    H0 = rng.random((N, n)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    H = t(H0.T)
+    H, Wn, irm = ops.mu_forward(t(V.T), t(W), H, 0.1, iters, beta=beta, want_irm=True)
+    torch.cuda.synchronize()
+    Hr, Wr = O.mu_infer(V.astype(np.float64), W.astype(np.float64), H0.astype(np.float64), 0.1,
+                        iters, beta=beta)
+    np.testing.assert_allclose(Wn.cpu().numpy(), Wr, rtol=1e-5)
+    err = np.max(np.abs(H.cpu().numpy() - Hr.T)) / np.max(np.abs(Hr))
+    assert err <= 2e-4, "beta=%g rel err %.3e" % (beta, err)
+    irm_r = O.snmf_irm(Wr, Hr, N // 2)
+    assert np.mean((irm.cpu().numpy() - irm_r.T) ** 2) <= MASK_MSE_TOL
