@@ -286,3 +286,31 @@ def test_mu_inference_and_irm_vs_oracle(dev, beta):
     assert err <= 2e-4, "beta=%g rel err %.3e" % (beta, err)
     irm_r = O.snmf_irm(Wr, Hr, N // 2)
     assert np.mean((irm.cpu().numpy() - irm_r.T) ** 2) <= MASK_MSE_TOL
+
+
+# ------------------------------------------------------------------ STFT-magnitude front end
+@pytest.mark.parametrize("N,hop,nsampl,int16", [(64, 16, 1000, False), (512, 128, 16000, True),
+                                                (1024, 512, 40000, True), (1024, 256, 777, False),
+                                                (4096, 1024, 20000, True)])
+def test_stft_mag_vs_oracle(dev, N, hop, nsampl, int16):
+    from drnmf_amd import ops
+    rng = np.random.default_rng(N + hop)
+    n_sig = 3
+    if int16:
+        pcm = rng.integers(-20000, 20000, size=(n_sig, nsampl)).astype(np.int16)
+        xf = O.wav_int16_to_float(pcm)
+        tp = torch.from_numpy(pcm).to(dev)
+    else:
+        xf = rng.standard_normal((n_sig, nsampl)).astype(np.float32)
+        tp = torch.from_numpy(xf).to(dev)
+    mag = ops.stft_mag(tp, N=N, hop=hop)
+    torch.cuda.synchronize()
+    w = O.sqrt_hann(N)
+    nf = O.stft_frames(nsampl, N, hop)
+    assert tuple(mag.shape) == (n_sig, nf, N // 2 + 1)
+    got = mag.cpu().numpy()
+    for s in range(n_sig):
+        ref = O.stft_mag(xf[s], N, hop, w).T          # (frames, bins)
+        err = np.max(np.abs(got[s] - ref)) / np.max(np.abs(ref))
+        assert err <= 2e-5, "N=%d rel err %.3e" % (N, err)
+    assert np.all(got[:, 0, :] == 0)                   # the all-zero leading frame
