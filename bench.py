@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=25)
     ap.add_argument("--tied", action="store_true", help="tie log_D/log_alph across layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ista", action="store_true", help="skip the frame-parallel ISTA line")
     ap.add_argument("--cpu-frames", type=int, default=0,
                     help="frame-steps of the CPU baseline sample (0 = auto, ~15-25 s)")
     return ap.parse_args()
@@ -60,6 +61,31 @@ def synth_on_device(torch, dev, B, T, F, r, seed):
             torch.rand((T, N), generator=g, device=dev) * 5.0
         X[b] = Ht @ Wt.t() + 0.01 * torch.rand((T, F), generator=g, device=dev)
     return W, log_h0, X
+
+
+def ista_bench(torch, dev, F, N, K, W, n=32768):
+    """Frame-parallel K-iteration ISTA-ED (enhance.py:402-418) on n frames: the MFMA-bound sibling
+    of the recurrent cell (no dependence between frames).  4*F*N flops per frame per iteration."""
+    from drnmf_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    Wt = torch.from_numpy(W).to(dev)
+    Ht = (torch.rand((n, N), generator=g, device=dev) < 0.02) * \
+        torch.rand((n, N), generator=g, device=dev) * 5.0
+    Xf = Ht @ Wt.t() + 0.01 * torch.rand((n, F), generator=g, device=dev)
+    H = torch.full((n, N), 0.1, dtype=torch.float32, device=dev)
+    ops.ista_forward(Xf, Wt, H, 1.0, 400.0, 2)        # warm-up
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.ista_forward(Xf, Wt, H, 1.0, 400.0, K)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3
+    tf = n * 4.0 * F * N * K / sec / 1e12
+    return {"frames": n, "K": K, "frames_per_s": n / sec, "tflops": tf,
+            "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,
+            "gemm_launch_us": sec / (2 * K) * 1e6}
 
 
 def cpu_baseline(F, r, K, B, frames, tied):
@@ -136,9 +162,19 @@ def main():
     m_buf = torch.empty((B, T, F), dtype=torch.float32, device=dev)
     from drnmf_amd import ops
 
-    def step():
+    cell_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    cell_ms = []
+
+    def step(timed=False):
+        if timed:
+            cell_ev[0].record()
         h = model.cell.call(X, mask_value=-1., out=h_buf)
+        if timed:
+            cell_ev[1].record()
         ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
+        if timed:          # rank-local bookkeeping after the step's work is enqueued
+            cell_ev[1].synchronize()
+            cell_ms.append(cell_ev[0].elapsed_time(cell_ev[1]))
 
     def barrier():
         if dist is not None:
@@ -152,8 +188,8 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(a.steps):
-        step()
+    for i in range(a.steps):
+        step(timed=(i == a.steps - 1))
     e1.record()
     torch.cuda.synchronize()
     barrier()
@@ -168,9 +204,30 @@ def main():
     ok = bool(torch.isfinite(m_buf).all().item()) and float(m_buf.min()) > 0.0
     frames_total = world * B * T * a.steps
     value = frames_total / wall
-    # algorithmic MFMA work per frame: fwd = 4*F*N*K
+    # algorithmic MFMA work: fwd = 4*F*N*K per frame = two B x F x N
+    # contractions per layer-step; one cell_a / cell_b launch carries one of them for all B rows.
     flops_per_frame = 4.0 * F * N * K
-    achieved = (B * T * a.steps) * flops_per_frame / (ev_ms * 1e-3) / 1e12
+    whole = (B * T * a.steps) * flops_per_frame / (ev_ms * 1e-3) / 1e12
+    flops_per_launch = 2.0 * B * F * N
+    # Dominant kernels: cell_a / cell_b (2K-1 launches per frame, each one B x F x N contraction =
+    # 2*B*F*N algorithmic flops, near-equal durations).  Average launch duration = HIP-event time
+    # of the cell's launches on the launch stream / number of launches (the hipGraph replays run
+    # back to back, so this includes the ~1.7 us launch boundary, as rocprofv3's kernel trace of
+    # the same command does: it reports zero gaps between consecutive kernels).
+    n_launch = T * (2 * K - 1)
+    launch_us = (sum(cell_ms) / len(cell_ms)) * 1e3 / n_launch
+    ach = flops_per_launch / (launch_us * 1e-6) / 1e12
+    roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "kernel": "cell_a_kernel / cell_b_kernel (mean over the 2K-1 launches of a frame)",
+            "launch_us": launch_us, "flops_per_launch": flops_per_launch}
+    extra = {}
+    if rank == 0:
+        extra = {"frame_us": launch_us * (2 * K - 1), "cell_ms_per_step": sum(cell_ms) / len(cell_ms),
+                 "whole_forward_tflops": whole,
+                 "whole_forward_frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS}
+        if not a.no_ista:
+            extra["ista_frame_parallel"] = ista_bench(torch, dev, F, N, K, W)
     out = {
         "metric": "STFT frames/sec (K=%d unrolled DR-NMF forward, %d-bin x %d-frame)" % (K, F, T),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
@@ -180,11 +237,9 @@ def main():
                                "mask head), W %dx%d, %s log_D/log_alph, batch %d x %d frames per "
                                "GPU" % (K, F, N, "tied" if a.tied else "untied", B, T),
                    "B_per_gpu": B, "T": T, "F": F, "N": N, "K": K, "untied": not a.tied},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                     "kernel": "whole forward (all launches of one step), rank 0, HIP events on "
-                               "the launch stream"},
+        "roofline": roof,
         "finite_positive_masks": ok,
+        "extra": extra,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(F, r, K, B, a.cpu_frames, a.tied)

@@ -464,10 +464,11 @@ extern "C" size_t drnmf_cell_workspace_bytes(const drnmf_cell_desc_t* d) {
     return workspace_layout(d).total;
 }
 
-extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
-                                      float mask_value, const void* params, const float* log_h0,
-                                      float u0_diag, float u0_off, float uk_off, float* h_out,
-                                      void* workspace, size_t workspace_bytes, void* stream_) {
+static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                 float mask_value, const void* params, const float* log_h0,
+                                 float u0_diag, float u0_off, float uk_off, float* h_out,
+                                 void* workspace, size_t workspace_bytes, void* stream_,
+                                 int profile_frames, float* out_us) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;
@@ -517,7 +518,7 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
         memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
         key.push_back(b0); key.push_back(b1); key.push_back(b2);
     }
-    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr;
+    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0;
 
     const int numM = W.Bp / ROWS, nft = W.Fp / 16;
     const unsigned grid_a = (unsigned)(round_up(W.numA, 8) * numM);
@@ -567,22 +568,63 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
     };
 
     if (!use_graph) {
-        for (int t = 0; t < d->T; ++t) {
+        // plain launches; in profile mode every launch is bracketed by HIP events on the stream
+        const int T_run = profile_frames > 0 ? (profile_frames < d->T ? profile_frames : d->T)
+                                             : d->T;
+        std::vector<hipEvent_t> ev;
+        std::vector<int> kind;   // 0 = cell_a middle layer, 1 = cell_b, 2 = other
+        auto mark = [&](int k_) -> hipError_t {
+            if (profile_frames <= 0) return hipSuccess;
+            hipEvent_t e;
+            hipError_t er = hipEventCreate(&e);
+            if (er != hipSuccess) return er;
+            ev.push_back(e);
+            kind.push_back(k_);
+            return hipEventRecord(e, stream);
+        };
+        for (int t = 0; t < T_run; ++t) {
             for (int k = 0; k < K; ++k) {
                 CellAArgs a = make_a(k);
                 void* kp[1] = {&a};
-                DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, k == 0, k == K - 1, d->return_all_hidden != 0),
+                DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
+                DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, k == 0, k == K - 1,
+                                                         d->return_all_hidden != 0),
                                              dim3(grid_a), dim3(256), kp, 0, stream));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     void* kb[1] = {&b};
+                    DRNMF_HIP(h, mark(1));
                     DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks), dim3(grid_b), dim3(256),
                                                  kb, 0, stream));
                 }
             }
-            if (K == 1) hipLaunchKernelGGL(advance_frame_kernel, dim3(1), dim3(1), 0, stream, tA);
+            if (K == 1) {
+                DRNMF_HIP(h, mark(2));
+                hipLaunchKernelGGL(advance_frame_kernel, dim3(1), dim3(1), 0, stream, tA);
+            }
         }
+        DRNMF_HIP(h, mark(3));
         DRNMF_HIP(h, hipGetLastError());
+        if (profile_frames > 0) {
+            DRNMF_HIP(h, hipStreamSynchronize(stream));
+            double sum[3] = {0, 0, 0};
+            long cnt[3] = {0, 0, 0};
+            const size_t per_frame = (ev.size() - 1) / (size_t)T_run;
+            const size_t skip = T_run > 1 ? per_frame : 0;          // first frame = warm-up
+            for (size_t i = skip; i + 1 < ev.size(); ++i) {
+                float ms = 0.f;
+                DRNMF_HIP(h, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+                if (kind[i] < 2) { sum[kind[i]] += ms; cnt[kind[i]]++; }
+                sum[2] += ms;
+            }
+            const int frames_timed = T_run > 1 ? T_run - 1 : 1;
+            if (out_us) {
+                out_us[0] = cnt[0] ? (float)(sum[0] / cnt[0] * 1e3) : 0.f;
+                out_us[1] = cnt[1] ? (float)(sum[1] / cnt[1] * 1e3) : 0.f;
+                out_us[2] = (float)(sum[2] / frames_timed * 1e3);
+            }
+            for (auto e : ev) (void)hipEventDestroy(e);
+        }
         return DRNMF_OK;
     }
 
@@ -633,4 +675,25 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
     }
     for (int t = 0; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(entry->exec, stream));
     return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                      float mask_value, const void* params, const float* log_h0,
+                                      float u0_diag, float u0_off, float uk_off, float* h_out,
+                                      void* workspace, size_t workspace_bytes, void* stream_) {
+    return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
+                             workspace, workspace_bytes, stream_, 0, nullptr);
+}
+
+extern "C" int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                      float mask_value, const void* params, const float* log_h0,
+                                      float u0_diag, float u0_off, float uk_off, float* h_out,
+                                      void* workspace, size_t workspace_bytes, void* stream_,
+                                      int32_t frames, float* out_us_host) {
+    if (frames <= 0 || !out_us_host) {
+        if (h) snprintf(h->err, sizeof(h->err), "cell_profile: frames must be > 0, out non-NULL");
+        return DRNMF_ERR_INVALID_ARG;
+    }
+    return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
+                             workspace, workspace_bytes, stream_, frames, out_us_host);
 }

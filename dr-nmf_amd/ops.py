@@ -103,6 +103,21 @@ def cell_forward(x, mask_value, params, desc, log_h0, u, out=None, workspace=Non
     return out
 
 
+def cell_profile(x, mask_value, params, desc, log_h0, u, out, workspace, frames=8):
+    """Measurement aid: per-kernel mean durations (us) of the first `frames` frames, HIP events on
+    the launch stream.  Returns dict(cell_a_us, cell_b_us, frame_us)."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(x))
+    res = (C.c_float * 3)()
+    mv = float("nan") if mask_value is None else float(mask_value)
+    rc = L.drnmf_cell_profile(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
+                              _capi.ptr(log_h0), float(u[0]), float(u[1]), float(u[2]),
+                              _capi.ptr(out), _capi.ptr(workspace), workspace.numel(), _stream(),
+                              int(frames), res)
+    _capi.check(rc, h, "drnmf_cell_profile")
+    return {"cell_a_us": float(res[0]), "cell_b_us": float(res[1]), "frame_us": float(res[2])}
+
+
 def head_forward(hidden, kernel_clean, kernel_noise, square=False, want_ab=False, h_off=0,
                  out=None):
     """hidden [..., ld] (uses columns h_off .. h_off+2r) -> mask [..., F] (and A, Bn)."""

@@ -89,6 +89,17 @@ int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const f
                            float u0_diag, float u0_off, float uk_off, float* h_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement aid (no reference counterpart; used by bench.py only): runs the first `frames`
+ * frames of the same forward with plain launches, every launch bracketed by HIP events on
+ * `stream`, SYNCHRONISES the stream, and returns mean durations in microseconds:
+ *   out_us_host[0] = cell_a kernel (middle layers), [1] = cell_b kernel, [2] = one whole frame.
+ * h_out holds only those frames afterwards. */
+int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                           float mask_value, const void* params, const float* log_h0,
+                           float u0_diag, float u0_off, float uk_off, float* h_out,
+                           void* workspace, size_t workspace_bytes, void* stream, int32_t frames,
+                           float* out_us_host);
+
 /* ---- mask head: replaces the H_clean/H_noise slices, TimeDistributed(DenseNonNegW) x2
  * (custom_layers.py:23-29; enhance.py:277-292), the optional 'square' transform
  * (enhance.py:294-300) and DivideAbyAplusB (custom_layers.py:41-45).
