@@ -38,6 +38,15 @@ SIGNATURES = {
     "drnmf_padded_f": (_i32, [_i32]),
     "drnmf_head_forward": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp,
                                   _vp, _vp, _vp, _vp]),
+    "drnmf_loss_head_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "drnmf_loss_head_backward": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                        _vp]),
+    "drnmf_cell_backward_workspace_bytes": (_sz, [_DP]),
+    "drnmf_cell_backward": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _sz,
+                                   _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "drnmf_adam_step": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "drnmf_sumsq": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "drnmf_ista_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "drnmf_ista_forward": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp,
                                   _vp, _vp, _sz, _vp]),

@@ -1,0 +1,673 @@
+// Backward pass (BPTT) of the recurrent DR-NMF cell on gfx950.
+//
+// The reference obtains this by Theano autodiff of the scan (enhance.py:1071-1073, 1152); here it
+// is written out.  With dz_k = dh_k * [h_k > 0] and dG_k = dz_k * ia_k (forward: cell_forward.hip):
+//     d r_k     = dG_k Dn_k^T                         (contract atoms   -> cell_b_kernel, no x)
+//     dh_{k-1}  = dz_k - d r_k Dn_k                   (contract bins    -> bwd_a_kernel)
+//     layer 0   : dp = u0d dz_0 + u0o (sum(dz_0) - dz_0) + uko sum_{k>=1} sum(dz_k)
+// so the sequential chain has the forward's shape (two skinny launches per layer-step, replayed
+// as a per-frame hipGraph in reverse time), and only dz / d r are stored per (t, k).  Everything
+// that contracts over frames is time-batched afterwards and off the critical chain:
+//     d Dn_k = (R_k^T dz_k) * ia_k - dR_k^T H_{k-1},   R_k = X - H_{k-1} Dn_k^T   (gemm_tn.h, split-K)
+//     d b_k = sum dz_k,  d ia_k = sum dz_k * G_k  (G_k recovered from the stored hiddens)
+// followed by the parameter maps: d log_D = Dn * (dDn - Dn * colsum(dDn * Dn)), log_alph, log_lam1,
+// log_h0.  Masked steps follow K.rnn: no gradient enters a masked frame; the gradient of its
+// (repeated) output is handed to the last valid frame and the state gradient passes through.
+#include "cell_shared.h"
+#include "gemm_nt.h"
+#include "gemm_tn.h"
+
+namespace {
+
+constexpr int TN_SPLITS = 8;
+constexpr int CR_SPLITS = 64;
+
+struct EdgeArgs {
+    const float* hall;       // [B][T][K*N]
+    const float* d_out;      // [B][T][N]
+    float* dz_all;           // [B][T][K*N]
+    const float* ia_last;    // [Np] of layer K-1
+    float* dstate;           // packed [Bp][Np]
+    float* gq;               // packed
+    float* dzp_top;          // packed dz buffer of layer K-1
+    float* dGp_top;
+    const float* dzp0;       // packed dz buffer of layer 0
+    float* dz0s_part;        // [2][numA][Bp]
+    float* dps_part;         // [2][numA][Bp]
+    float* dh0_part;         // [numM][Np]
+    const unsigned char* valid;
+    const int* c_rd;
+    int* c_wr;
+    float u0d, u0o;
+    int B, T, N, K, Bp, Np, numA;
+};
+
+__global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
+    __shared__ float sm[ROWS][ATOMS + 1];
+    const int numM = a.Bp / ROWS;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int m = qb % numM;
+    const int ab = (qb / numM) * 8 + xcd;
+    if (ab >= a.numA) return;
+    const int tid = threadIdx.x;
+    const int c = *a.c_rd;
+    if (a.c_wr && blockIdx.x == 0 && tid == 0) *a.c_wr = c;
+    const int t = a.T - 1 - c;
+    const int NAC = a.Np / 16, ac0 = ab * 2;
+    const int erow = tid >> 4, ec = (tid & 15) * 2;
+    const int rg = m * ROWS + erow, n = ab * ATOMS + ec;
+    const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
+    const int KN = a.K * a.N;
+    const size_t pstride = (size_t)a.numA * a.Bp;
+
+    f32x2 ds = *(const f32x2*)(a.dstate + hoff);
+    if (c > 0) {
+        // ---- bottom of frame t+1: gradient w.r.t. the state that entered it -------------------
+        const int par = (c - 1) & 1;
+        const float* z0 = a.dz0s_part + par * pstride + rg;
+        const float* dp_ = a.dps_part + par * pstride + rg;
+        float s0 = 0.f, sp = 0.f;
+        for (int b2 = (tid & 15); b2 < a.numA; b2 += 16) {
+            s0 += z0[(size_t)b2 * a.Bp];
+            sp += dp_[(size_t)b2 * a.Bp];
+        }
+        for (int o = 8; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 16);
+            sp += __shfl_xor(sp, o, 16);
+        }
+        const f32x2 dz0 = *(const f32x2*)(a.dzp0 + hoff);
+        if (a.valid[(size_t)(t + 1) * a.Bp + rg]) {
+            ds[0] = a.u0d * dz0[0] + a.u0o * (s0 - dz0[0]) + sp;
+            ds[1] = a.u0d * dz0[1] + a.u0o * (s0 - dz0[1]) + sp;
+        }
+    }
+    if (t >= 0) {
+        // ---- top of frame t -------------------------------------------------------------------
+        const bool v = a.valid[(size_t)t * a.Bp + rg] != 0;
+        f32x2 g = *(const f32x2*)(a.gq + hoff);
+        f32x2 dz = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool live = rg < a.B && n + e < a.N;
+            const float dout = live ? a.d_out[((size_t)rg * a.T + t) * a.N + n + e] : 0.f;
+            float dh = 0.f;
+            if (v) { dh = dout + g[e] + ds[e]; g[e] = 0.f; }
+            else g[e] += dout;
+            const float h = live ? a.hall[((size_t)rg * a.T + t) * KN + (size_t)(a.K - 1) * a.N +
+                                          n + e] : 0.f;
+            dz[e] = h > 0.f ? dh : 0.f;
+            if (live) a.dz_all[((size_t)rg * a.T + t) * KN + (size_t)(a.K - 1) * a.N + n + e] = dz[e];
+        }
+        *(f32x2*)(a.gq + hoff) = g;
+        *(f32x2*)(a.dstate + hoff) = ds;
+        *(f32x2*)(a.dzp_top + hoff) = dz;
+        const f32x2 ia = *(const f32x2*)(a.ia_last + n);
+        f32x2 dG = {dz[0] * ia[0], dz[1] * ia[1]};
+        *(f32x2*)(a.dGp_top + hoff) = dG;
+        const int par = c & 1;
+        float s = dz[0] + dz[1];
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        if ((tid & 15) == 0) {
+            a.dps_part[par * pstride + (size_t)ab * a.Bp + rg] = 0.f;
+            if (a.K == 1) a.dz0s_part[par * pstride + (size_t)ab * a.Bp + rg] = s;
+        }
+    } else {
+        // ---- after frame 0: ds = gradient w.r.t. the initial state of every row ---------------
+        *(f32x2*)(a.dstate + hoff) = ds;
+        sm[erow][ec] = rg < a.B ? ds[0] : 0.f;
+        sm[erow][ec + 1] = rg < a.B ? ds[1] : 0.f;
+        __syncthreads();
+        if (tid < ATOMS) {
+            float s = 0.f;
+            for (int r2 = 0; r2 < ROWS; ++r2) s += sm[r2][tid];
+            a.dh0_part[(size_t)m * a.Np + ab * ATOMS + tid] = s;
+        }
+    }
+}
+
+struct BwdAArgs {
+    const float* Dn;         // packed dictionary of layer k
+    const float* ia_prev;    // [Np] 1/alpha of layer k-1
+    const float* drpart;     // [KS][Bp][Fp] packed partials of d r_k
+    const float* dzp_in;     // packed dz_k
+    float* dzp_out;          // packed dz_{k-1}
+    float* dGp_out;          // packed dG_{k-1}
+    const float* hall;
+    float* dz_all;
+    float* dR;               // [B*T][Fp] row-major d r_k of this layer
+    float* dz0s_part;
+    float* dps_part;
+    const int* c_rd;
+    int* c_wr;
+    float uko;
+    int k, B, T, N, K, Bp, Fp, Np, numA, nchunks;
+};
+
+template <int G, int KS>
+__global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4 * ROWS * ATOMS];
+    const int numM = a.Bp / ROWS;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int m = qb % numM;
+    const int ab = (qb / numM) * 8 + xcd;
+    if (ab >= a.numA) return;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63, j = l & 15, q = l >> 4;
+    const int Fp = a.Fp, Np = a.Np;
+    const int row0 = m * ROWS, n0 = ab * ATOMS;
+    const size_t pstride = (size_t)a.Bp * Fp;
+    const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
+    const float* arow = a.drpart + (size_t)m * nft * 256 + j * 16 + q * 4;
+    const float* brow = a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + q * 16 + (j & 7) * 2;
+    const size_t bstep = (size_t)NAC * 256;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int per_wave = (a.nchunks - w + 3) >> 2;
+    const int clast = a.nchunks - 1;
+    f32x4 av[G][KS];
+    f32x2 bv[G][4];
+    auto load_group = [&](int base) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            int c = w + 4 * (base + g);
+            c = c > clast ? clast : c;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                av[g][ks] = *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
+        }
+    };
+    load_group(0);
+
+    const int cnt = *a.c_rd;
+    if (a.c_wr && blockIdx.x == 0 && tid == 0) *a.c_wr = cnt + 1;
+    const int t = a.T - 1 - cnt;
+    const int erow = tid >> 4, ec = (tid & 15) * 2;
+    const int rg = row0 + erow, n = n0 + ec;
+    const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
+    const int KN = a.K * a.N;
+    const f32x2 dzk = *(const f32x2*)(a.dzp_in + hoff);
+    const f32x2 ia = *(const f32x2*)(a.ia_prev + n);
+    f32x2 hprev = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        if (rg < a.B && n + e < a.N)
+            hprev[e] = a.hall[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n + e];
+
+    auto compute_group = [&](int base) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f32x4 r4 = av[g][0];
+#pragma unroll
+            for (int ks = 1; ks < KS; ++ks) r4 += av[g][ks];
+            const bool ok = base + g < per_wave;
+            if (!ok) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ab == 0 && ok && row0 + j < a.B) {
+                // the summed d r_k of this row tile goes out row-major for the weight gradients
+                const int c = w + 4 * (base + g);
+                float* dr = a.dR + ((size_t)(row0 + j) * a.T + t) * Fp + 16 * c + q;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dr[4 * s] = r4[s];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = mfma16(r4[s], bv[g][s][0], acc0);
+                acc1 = mfma16(r4[s], bv[g][s][1], acc1);
+            }
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    compute_group(0);
+    for (int base = G; base < per_wave; base += G) {
+        load_group(base);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_group(base);
+    }
+
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        f32x2 pr = {acc0[v], acc1[v]};
+        *(f32x2*)(red + (w * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
+    }
+    __syncthreads();
+    f32x2 gsum = *(const f32x2*)(red + (0 * ROWS + erow) * ATOMS + ec);
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) {
+        const f32x2 p2 = *(const f32x2*)(red + (ww * ROWS + erow) * ATOMS + ec);
+        gsum[0] += p2[0];
+        gsum[1] += p2[1];
+    }
+
+    f32x2 dzn;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dh = dzk[e] - gsum[e];
+        dzn[e] = hprev[e] > 0.f ? dh : 0.f;
+        if (rg < a.B && n + e < a.N)
+            a.dz_all[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n + e] = dzn[e];
+    }
+    *(f32x2*)(a.dzp_out + hoff) = dzn;
+    f32x2 dG = {dzn[0] * ia[0], dzn[1] * ia[1]};
+    *(f32x2*)(a.dGp_out + hoff) = dG;
+    float s = dzk[0] + dzk[1], s0 = dzn[0] + dzn[1];
+    for (int o = 8; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 16);
+        s0 += __shfl_xor(s0, o, 16);
+    }
+    if ((tid & 15) == 0) {
+        const size_t po = (size_t)(cnt & 1) * a.numA * a.Bp + (size_t)ab * a.Bp + rg;
+        a.dps_part[po] += a.uko * s;
+        if (a.k == 1) a.dz0s_part[po] = s0;
+    }
+}
+
+template <int KS>
+void* bwd_a_func(int per_wave) {
+    if (per_wave <= 3) return (void*)&bwd_a_kernel<3, KS>;
+    if (per_wave <= 5 || KS >= 4) return (void*)&bwd_a_kernel<5, KS>;
+    return (void*)&bwd_a_kernel<9, KS>;
+}
+void* pick_bwd_a(int nchunks, int KS) {
+    const int per_wave = (nchunks + 3) / 4;
+    switch (KS) {
+        case 1: return bwd_a_func<1>(per_wave);
+        case 2: return bwd_a_func<2>(per_wave);
+        case 4: return bwd_a_func<4>(per_wave);
+        default: return bwd_a_func<8>(per_wave);
+    }
+}
+
+// ---------------- time-batched phase --------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+unpack_dn_kernel(const float* __restrict__ Dp, float* __restrict__ Dn, int Fp, int Np) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Fp * Np) return;
+    const int f = (int)(i / Np), n = (int)(i % Np);
+    Dn[i] = Dp[((size_t)(f >> 4) * (Np / 16) + (n >> 4)) * 256 + (f & 15) * 16 + (n & 15)];
+}
+
+struct EpiResid {   // R = X - H Dn^T
+    const float* X;
+    float* R;
+    int F, ldr;
+    __device__ void operator()(int64_t row, int col, float xh) const {
+        R[row * ldr + col] = X[row * F + col] - xh;
+    }
+};
+struct EpiP1 {      // partial[split] = acc * ia[n]
+    float* P;
+    const float* ia;
+    int Np;
+    size_t stride;
+    __device__ void operator()(int split, int m, int n, float acc) const {
+        P[split * stride + (size_t)m * Np + n] = acc * ia[n];
+    }
+};
+struct EpiP2 {      // partial[split] -= acc
+    float* P;
+    int Np;
+    size_t stride;
+    __device__ void operator()(int split, int m, int n, float acc) const {
+        P[split * stride + (size_t)m * Np + n] -= acc;
+    }
+};
+
+// d log_D (+)= Dn * (dDn - Dn * c),  c[n] = sum_f dDn[f][n] Dn[f][n],  dDn = sum of the partials
+__global__ void __launch_bounds__(256)
+dlogd_kernel(const float* __restrict__ P, const float* __restrict__ Dn, float* __restrict__ dlogD,
+             int F, int N, int Np, int splits, size_t stride, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float c = 0.f;
+    for (int f = 0; f < F; ++f) {
+        float g = 0.f;
+        for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)f * Np + n];
+        c = fmaf(g, Dn[(size_t)f * Np + n], c);
+    }
+    for (int f = 0; f < F; ++f) {
+        float g = 0.f;
+        for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)f * Np + n];
+        const float dn = Dn[(size_t)f * Np + n];
+        const float v = dn * (g - dn * c);
+        float* o = dlogD + (size_t)f * N + n;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+// per-atom sums over all frames of layer k: Sb = sum dz, Sgi = sum dz * (h_k - base) (= ia * sum dz G)
+struct ColRedArgs {
+    const float* hall;
+    const float* dz_all;
+    const float* bias;       // [Np] of layer k
+    const float* psum_all;   // [T][Bp]
+    const unsigned char* seen;
+    const float* log_h0;
+    float* part;             // [CR_SPLITS][2][Np]
+    float u0d, u0o, uko;
+    int k, B, T, N, K, Bp, Np;
+};
+__global__ void __launch_bounds__(256) colreduce_kernel(const ColRedArgs a) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int sp = blockIdx.y;
+    if (n >= a.N) return;
+    const int64_t BT = (int64_t)a.B * a.T;
+    const int64_t per = (BT + CR_SPLITS - 1) / CR_SPLITS;
+    const int64_t r0 = sp * per;
+    int64_t r1 = r0 + per;
+    if (r1 > BT) r1 = BT;
+    const int KN = a.K * a.N;
+    const float bk = a.bias[n];
+    float h0v = 0.f;
+    if (a.k == 0) {
+        const float z = a.log_h0[n];
+        h0v = (z > 20.f) ? z : log1pf(expf(z));
+    }
+    float sb = 0.f, sg = 0.f;
+    for (int64_t bt = r0; bt < r1; ++bt) {
+        const float dz = a.dz_all[bt * KN + (size_t)a.k * a.N + n];
+        if (dz == 0.f) continue;
+        const int b = (int)(bt / a.T), t = (int)(bt % a.T);
+        const float ps = a.psum_all[(size_t)t * a.Bp + b];
+        const float hk = a.hall[bt * KN + (size_t)a.k * a.N + n];
+        float base;
+        if (a.k == 0) {
+            const float p = a.seen[(size_t)t * a.Bp + b]
+                                ? a.hall[(bt - 1) * KN + (size_t)(a.K - 1) * a.N + n] : h0v;
+            base = a.u0d * p + a.u0o * (ps - p) + bk;
+        } else {
+            base = a.hall[bt * KN + (size_t)(a.k - 1) * a.N + n] + bk + a.uko * ps;
+        }
+        sb += dz;
+        sg = fmaf(dz, hk - base, sg);
+    }
+    a.part[((size_t)sp * 2 + 0) * a.Np + n] = sb;
+    a.part[((size_t)sp * 2 + 1) * a.Np + n] = sg;
+}
+
+// d log_alph / d log_lam1 of layer k from the per-atom sums: ia = exp(-log_alph), b = -lam * ia
+//   d log_alph[n] = -Sgi[n] - b[n] Sb[n];   d log_lam1 = sum_n b[n] Sb[n]
+__global__ void __launch_bounds__(256)
+scalar_grads_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                    float* __restrict__ d_alph, float* __restrict__ d_lam, int N, int Np,
+                    int alph_len, int acc_alph, int acc_lam) {
+    __shared__ float sa[256], sl[256];
+    float ta = 0.f, tl = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float sb = 0.f, sg = 0.f;
+        for (int s = 0; s < CR_SPLITS; ++s) {
+            sb += part[((size_t)s * 2 + 0) * Np + n];
+            sg += part[((size_t)s * 2 + 1) * Np + n];
+        }
+        const float b = bias[n];
+        const float va = -sg - b * sb;
+        tl += b * sb;
+        if (alph_len > 1) d_alph[n] = acc_alph ? d_alph[n] + va : va;
+        else ta += va;
+    }
+    sa[threadIdx.x] = ta;
+    sl[threadIdx.x] = tl;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sa[threadIdx.x] += sa[threadIdx.x + o];
+            sl[threadIdx.x] += sl[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (alph_len == 1) d_alph[0] = acc_alph ? d_alph[0] + sa[0] : sa[0];
+        d_lam[0] = acc_lam ? d_lam[0] + sl[0] : sl[0];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+dlogh0_kernel(const float* __restrict__ dh0_part, const float* __restrict__ log_h0,
+              float* __restrict__ d_log_h0, int N, int Np, int numM) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < numM; ++m) s += dh0_part[(size_t)m * Np + n];
+    d_log_h0[n] = s / (1.f + expf(-log_h0[n]));   // d softplus = sigmoid
+}
+
+struct BwdWs {
+    size_t off_dstate, off_gq, off_dzp0, off_dzp1, off_dGp0, off_dGp1, off_drpart, off_z0s, off_dps,
+        off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_P, off_cr, total;
+};
+BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
+    BwdWs L;
+    size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += round_up_sz(b, 256); return at; };
+    const size_t hp = (size_t)W.Bp * W.Np * 4;
+    const int64_t BT = (int64_t)d->B * d->T;
+    L.off_dstate = take(hp); L.off_gq = take(hp);
+    L.off_dzp0 = take(hp); L.off_dzp1 = take(hp); L.off_dGp0 = take(hp); L.off_dGp1 = take(hp);
+    L.off_drpart = take((size_t)MAX_KS * W.Bp * W.Fp * 4);
+    L.off_z0s = take((size_t)2 * W.numA * W.Bp * 4);
+    L.off_dps = take((size_t)2 * W.numA * W.Bp * 4);
+    L.off_cnt = take(256);
+    L.off_dh0 = take((size_t)(W.Bp / ROWS) * W.Np * 4);
+    L.off_dzall = take((size_t)BT * d->K * d->N * 4);
+    L.off_dR = take((size_t)d->K * BT * W.Fp * 4);
+    L.off_xpad = take((size_t)BT * W.Fp * 4);
+    L.off_R = take((size_t)BT * W.Fp * 4);
+    L.off_dn = take((size_t)W.Fp * W.Np * 4);
+    L.off_P = take((size_t)TN_SPLITS * W.Fp * W.Np * 4);
+    L.off_cr = take((size_t)CR_SPLITS * 2 * W.Np * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t drnmf_cell_backward_workspace_bytes(const drnmf_cell_desc_t* d) {
+    if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    return bwd_layout(d, workspace_layout(d)).total;
+}
+
+extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                       const void* params, const float* log_h0, float u0_diag,
+                                       float u0_off, float uk_off, const float* hall,
+                                       const float* d_out, const void* fwd_workspace,
+                                       size_t fwd_workspace_bytes, void* bwd_workspace,
+                                       size_t bwd_workspace_bytes, float* d_log_D,
+                                       float* d_log_alph, float* d_log_lam1, float* d_log_h0,
+                                       void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    int rc = validate_cell_desc(h, d);
+    if (rc) return rc;
+    if (!d->return_all_hidden)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG,
+                   "cell_backward needs the forward run with return_all_hidden=1 (all K hiddens)");
+    if (!x || !params || !log_h0 || !hall || !d_out || !fwd_workspace || !bwd_workspace ||
+        !d_log_D || !d_log_alph || !d_log_lam1 || !d_log_h0)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_backward: NULL pointer argument");
+    const Workspace W = workspace_layout(d);
+    const BwdWs L = bwd_layout(d, W);
+    if (fwd_workspace_bytes < W.total || bwd_workspace_bytes < L.total)
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "cell_backward: workspace too small (fwd %zu/%zu, bwd "
+                   "%zu/%zu)", fwd_workspace_bytes, W.total, bwd_workspace_bytes, L.total);
+    if (((uintptr_t)bwd_workspace & 255) || ((uintptr_t)fwd_workspace & 255))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "workspaces must be 256-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const ParamsLayout PL = params_layout(d);
+    const char* pb = (const char*)params;
+    const char* fw = (const char*)fwd_workspace;
+    char* bw = (char*)bwd_workspace;
+    const int K = d->K, N = d->N, F = d->F, T = d->T, B = d->B;
+    const int64_t BT = (int64_t)B * T;
+    const int numM = W.Bp / ROWS, nft = W.Fp / 16;
+    const float* Dp_base = (const float*)(pb + PL.off_dn);
+    const size_t dstride = (size_t)PL.Fp * PL.Np;
+    auto Dp_of = [&](int k) { return Dp_base + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
+    auto ia_of = [&](int k) { return (const float*)(pb + PL.off_inv_alpha) + (size_t)k * PL.Np; };
+    auto b_of = [&](int k) { return (const float*)(pb + PL.off_bias) + (size_t)k * PL.Np; };
+    const unsigned char* valid = (const unsigned char*)(fw + W.off_valid);
+    const unsigned char* seen = (const unsigned char*)(fw + W.off_seen);
+    const float* psum_all = (const float*)(fw + W.off_psum_all);
+
+    float* dstate = (float*)(bw + L.off_dstate);
+    float* gq = (float*)(bw + L.off_gq);
+    float* dzp[2] = {(float*)(bw + L.off_dzp0), (float*)(bw + L.off_dzp1)};
+    float* dGp[2] = {(float*)(bw + L.off_dGp0), (float*)(bw + L.off_dGp1)};
+    float* drpart = (float*)(bw + L.off_drpart);
+    float* z0s = (float*)(bw + L.off_z0s);
+    float* dps = (float*)(bw + L.off_dps);
+    int* cA = (int*)(bw + L.off_cnt);
+    int* cB = cA + 16;
+    float* dh0_part = (float*)(bw + L.off_dh0);
+    float* dz_all = (float*)(bw + L.off_dzall);
+    float* dR_all = (float*)(bw + L.off_dR);
+    float* xpad = (float*)(bw + L.off_xpad);
+    float* Rk = (float*)(bw + L.off_R);
+    float* Dn_rm = (float*)(bw + L.off_dn);
+    float* P = (float*)(bw + L.off_P);
+    float* crp = (float*)(bw + L.off_cr);
+
+    // ---- sequential pass: T replays of the per-frame graph in reverse time ---------------------
+    DRNMF_HIP(h, hipMemsetAsync(bw, 0, L.off_dh0, stream));   // dstate .. counters
+    const unsigned grid_a = (unsigned)(round_up(W.numA, 8) * numM);
+    const unsigned grid_b = (unsigned)(round_up(nft * W.KS, 8) * numM);
+
+    EdgeArgs ea;
+    ea.hall = hall; ea.d_out = d_out; ea.dz_all = dz_all; ea.ia_last = ia_of(K - 1);
+    ea.dstate = dstate; ea.gq = gq; ea.dzp_top = dzp[(K - 1) & 1]; ea.dGp_top = dGp[(K - 1) & 1];
+    ea.dzp0 = dzp[0]; ea.dz0s_part = z0s; ea.dps_part = dps; ea.dh0_part = dh0_part;
+    ea.valid = valid;
+    ea.c_rd = (K == 1) ? cA : cB;
+    ea.c_wr = (K == 1) ? nullptr : cA;
+    ea.u0d = u0_diag; ea.u0o = u0_off;
+    ea.B = B; ea.T = T; ea.N = N; ea.K = K; ea.Bp = W.Bp; ea.Np = W.Np; ea.numA = W.numA;
+
+    auto make_b = [&](int k) {
+        CellBArgs b;
+        b.Dn_next = Dp_of(k);
+        b.h = dGp[k & 1];
+        b.xp = nullptr;
+        b.rpart = drpart;
+        b.t_rd = cA;
+        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS; b.nch_ks = W.nch_ks;
+        return b;
+    };
+    auto make_a = [&](int k) {
+        BwdAArgs a;
+        a.Dn = Dp_of(k);
+        a.ia_prev = ia_of(k - 1);
+        a.drpart = drpart;
+        a.dzp_in = dzp[k & 1];
+        a.dzp_out = dzp[(k - 1) & 1];
+        a.dGp_out = dGp[(k - 1) & 1];
+        a.hall = hall; a.dz_all = dz_all;
+        a.dR = dR_all + (size_t)k * BT * W.Fp;
+        a.dz0s_part = z0s; a.dps_part = dps;
+        a.c_rd = cA;
+        a.c_wr = (k == 1) ? cB : nullptr;
+        a.uko = uk_off;
+        a.k = k; a.B = B; a.T = T; a.N = N; a.K = K; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
+        a.numA = W.numA; a.nchunks = nft;
+        return a;
+    };
+
+    std::vector<uint64_t> key = {0xB00Bull, (uint64_t)B, (uint64_t)T, (uint64_t)F, (uint64_t)N,
+                                 (uint64_t)K, (uint64_t)d->n_D, (uint64_t)(uintptr_t)params,
+                                 (uint64_t)(uintptr_t)hall, (uint64_t)(uintptr_t)d_out,
+                                 (uint64_t)(uintptr_t)fwd_workspace,
+                                 (uint64_t)(uintptr_t)bwd_workspace};
+    {
+        uint32_t b0, b1, b2;
+        memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
+        key.push_back(b0); key.push_back(b1); key.push_back(b2);
+    }
+    GraphEntry* entry = nullptr;
+    for (auto& g : h->graphs)
+        if (g.key == key) { entry = &g; break; }
+    if (!entry) {
+        if (h->graphs.size() >= 8) {
+            (void)hipGraphExecDestroy(h->graphs.front().exec);
+            (void)hipGraphDestroy(h->graphs.front().graph);
+            h->graphs.erase(h->graphs.begin());
+        }
+        GraphEntry ge;
+        ge.key = key;
+        DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
+        hipGraphNode_t last = nullptr;
+        auto add = [&](void* func, unsigned grid, unsigned block, void* argp) -> hipError_t {
+            hipKernelNodeParams p;
+            memset(&p, 0, sizeof(p));
+            void* kp[1] = {argp};
+            p.func = func; p.gridDim = dim3(grid); p.blockDim = dim3(block);
+            p.sharedMemBytes = 0; p.kernelParams = kp; p.extra = nullptr;
+            hipGraphNode_t node;
+            hipError_t e = hipGraphAddKernelNode(&node, ge.graph, last ? &last : nullptr,
+                                                 last ? 1 : 0, &p);
+            last = node;
+            return e;
+        };
+        DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, &ea));
+        for (int k = K - 1; k >= 1; --k) {
+            CellBArgs b = make_b(k);
+            DRNMF_HIP(h, add(pick_b_func(W.nch_ks), grid_b, 256, &b));
+            BwdAArgs a = make_a(k);
+            DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, &a));
+        }
+        if (K == 1) {
+            int* cp = cA;
+            DRNMF_HIP(h, add((void*)&advance_frame_kernel, 1, 1, &cp));
+        }
+        DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+        h->graphs.push_back(ge);
+        entry = &h->graphs.back();
+    }
+    for (int t = 0; t < T; ++t) DRNMF_HIP(h, hipGraphLaunch(entry->exec, stream));
+    hipLaunchKernelGGL(bwd_edge_kernel, dim3(grid_a), dim3(256), 0, stream, ea);   // t = -1
+    hipLaunchKernelGGL(dlogh0_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dh0_part,
+                       log_h0, d_log_h0, N, W.Np, numM);
+    DRNMF_HIP(h, hipGetLastError());
+
+    // ---- time-batched phase ----------------------------------------------------------------------
+    DRNMF_HIP(h, hipMemsetAsync(xpad, 0, (size_t)BT * W.Fp * 4, stream));
+    DRNMF_HIP(h, hipMemcpy2DAsync(xpad, (size_t)W.Fp * 4, x, (size_t)F * 4, (size_t)F * 4,
+                                  (size_t)BT, hipMemcpyDeviceToDevice, stream));
+    if (W.Fp != F) DRNMF_HIP(h, hipMemsetAsync(Rk, 0, (size_t)BT * W.Fp * 4, stream));
+    const size_t pstr = (size_t)W.Fp * W.Np;
+    const int KN = K * N;
+    for (int k = 0; k < K; ++k) {
+        const size_t tot = (size_t)W.Fp * W.Np;
+        hipLaunchKernelGGL(unpack_dn_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                           stream, Dp_of(k), Dn_rm, W.Fp, W.Np);
+        const float* Aop = xpad;
+        if (k >= 1) {
+            gemm::Operands g1{hall + (size_t)(k - 1) * N, Dn_rm, BT, F, N, KN, W.Np};
+            DRNMF_HIP(h, gemm::launch(g1, EpiResid{x, Rk, F, W.Fp}, stream));
+            Aop = Rk;
+        }
+        gemm_tn::Operands t1{Aop, dz_all + (size_t)k * N, BT, F, N, W.Fp, KN};
+        DRNMF_HIP(h, gemm_tn::launch(t1, EpiP1{P, ia_of(k), W.Np, pstr}, TN_SPLITS, stream));
+        if (k >= 1) {
+            gemm_tn::Operands t2{dR_all + (size_t)k * BT * W.Fp, hall + (size_t)(k - 1) * N, BT, F,
+                                 N, W.Fp, KN};
+            DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, TN_SPLITS, stream));
+        }
+        const int kd = d->n_D == 1 ? 0 : k;
+        hipLaunchKernelGGL(dlogd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, P, Dn_rm,
+                           d_log_D + (size_t)kd * F * N, F, N, W.Np, TN_SPLITS, pstr,
+                           (d->n_D == 1 && k > 0) ? 1 : 0);
+        ColRedArgs ca;
+        ca.hall = hall; ca.dz_all = dz_all; ca.bias = b_of(k); ca.psum_all = psum_all;
+        ca.seen = seen; ca.log_h0 = log_h0; ca.part = crp;
+        ca.u0d = u0_diag; ca.u0o = u0_off; ca.uko = uk_off;
+        ca.k = k; ca.B = B; ca.T = T; ca.N = N; ca.K = K; ca.Bp = W.Bp; ca.Np = W.Np;
+        hipLaunchKernelGGL(colreduce_kernel, dim3((N + 255) / 256, CR_SPLITS), dim3(256), 0, stream,
+                           ca);
+        const int ka = d->n_alph == 1 ? 0 : k, kl = d->n_lam == 1 ? 0 : k;
+        hipLaunchKernelGGL(scalar_grads_kernel, dim3(1), dim3(256), 0, stream, crp, b_of(k),
+                           d_log_alph + (size_t)ka * d->alph_len, d_log_lam1 + kl, N, W.Np,
+                           d->alph_len, (d->n_alph == 1 && k > 0) ? 1 : 0,
+                           (d->n_lam == 1 && k > 0) ? 1 : 0);
+    }
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}

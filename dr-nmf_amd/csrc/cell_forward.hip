@@ -32,13 +32,9 @@
 // index from device memory.  Dictionary operands are read straight into MFMA operand registers:
 // they are not shared between the waves of a workgroup, so an LDS round trip would only add
 // latency; all of a wave's operand loads are issued before its first MFMA.
-#include "common.h"
+#include "cell_shared.h"
 
 namespace {
-
-constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
-constexpr int ATOMS = 32;   // atoms per cell_a workgroup
-constexpr int MAX_KS = 8;
 
 struct CellAArgs {
     const float* Dn;         // [Fp][Np]  this layer's unit-norm dictionary
@@ -50,6 +46,7 @@ struct CellAArgs {
     float* state;            // [Bp][Np]
     float* rs_part;          // [2][numA][Bp] row sums of the state per atom block, by frame parity
     float* psum;             // [Bp]  sum(p) of the current frame
+    float* psum_all;         // [T][Bp] the same, kept for the backward pass
     const unsigned char* valid;  // [T][Bp]
     float* out;              // [B][T][out_width]
     const int* t_rd;         // frame counter to read
@@ -58,15 +55,6 @@ struct CellAArgs {
     float u0d, u0o, uko;
     int B, T, N, Bp, Fp, Np, numA, nchunks, KS;
     int out_width, out_off, write_out;
-};
-
-struct CellBArgs {
-    const float* Dn_next;    // [Fp][Np]  next layer's dictionary
-    const float* h;          // [Bp][Np]  this layer's h
-    const float* xp;         // [T][Bp][Fp]
-    float* rpart;            // [KS][Bp][Fp]
-    const int* t_rd;
-    int Bp, Fp, Np, nft, KS, nch_ks;   // nch_ks = 16-atom chunks per atom range
 };
 
 // G = 16-bin chunks handled per wave per group (all of a group's operand loads are issued before
@@ -153,7 +141,10 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
         s += __shfl_xor(s, 2, 16);
         s += __shfl_xor(s, 1, 16);
         ps = s;
-        if (ab == 0 && (tid & 15) == 0) a.psum[rg] = ps;
+        if (ab == 0 && (tid & 15) == 0) {
+            a.psum[rg] = ps;
+            a.psum_all[(size_t)t * a.Bp + rg] = ps;
+        }
     } else {
         ps = a.psum[rg];
     }
@@ -243,91 +234,6 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
     }
 }
 
-// x^ partial of one (row tile, bin tile, atom range) and the residual partial
-//   rpart[ks] = (ks == 0 ? x_t : 0) - h[16 x range] . Dn_next[16 bins x range]^T.
-// GB = 16-atom chunks per wave per group.
-template <int GB>
-__global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 16];
-    const int numM = a.Bp / ROWS;
-    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int m = qb % numM;
-    const int rest = (qb / numM) * 8 + xcd;        // (bin tile, atom range)
-    if (rest >= a.nft * a.KS) return;
-    const int ft = rest / a.KS, ks = rest % a.KS;
-
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
-    const int l = tid & 63, j = l & 15, q = l >> 4;
-    const int Np = a.Np, Fp = a.Fp;
-    const int cbase = ks * a.nch_ks;                       // first chunk of this atom range
-    int nch = a.Np / 16 - cbase;                           // chunks left in the matrix
-    if (nch > a.nch_ks) nch = a.nch_ks;
-    if (nch < 1) nch = 1;                                  // (never: KS*nch_ks covers Np/16)
-    int per_wave = (nch - w + 3) >> 2;
-    const int clast = nch - 1;
-
-    const int NAC = Np / 16;
-    // blocks (m, cbase+c) of Hp and (ft, cbase+c) of Dp: lane (j, q) reads the float4 of atoms
-    // 16c + 4q + {0..3} in row j -> one contiguous 1 KB block per wave instruction
-    const float* arow = a.h + ((size_t)m * NAC + cbase) * 256 + j * 16 + q * 4;          // + 256*c
-    const float* brow = a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;   // + 256*c
-
-    // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
-    f32x4 av[GB], bv[GB];
-    auto load_group = [&](int base) {
-#pragma unroll
-        for (int g = 0; g < GB; ++g) {
-            int c = w + 4 * (base + g);
-            c = c > clast ? clast : c;
-            av[g] = *(const f32x4*)(arow + 256 * c);
-            bv[g] = *(const f32x4*)(brow + 256 * c);
-        }
-    };
-    load_group(0);
-
-    // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
-    const int erow = tid >> 4, ecol = tid & 15;
-    const size_t eoff = ((size_t)m * a.nft + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
-    float xv = 0.f;
-    if (ks == 0) {
-        const int t = *a.t_rd;
-        xv = a.xp[(size_t)t * a.Bp * Fp + eoff];
-    }
-
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    auto compute_group = [&](int base) {
-#pragma unroll
-        for (int g = 0; g < GB; ++g) {
-            f32x4 a4 = av[g];
-            if (base + g >= per_wave) a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            // two independent accumulator chains hide the 40-cycle dependent MFMA latency
-            if (g & 1) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc1 = mfma16(a4[s], bv[g][s], acc1);
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc0 = mfma16(a4[s], bv[g][s], acc0);
-            }
-        }
-    };
-    __builtin_amdgcn_sched_barrier(0);   // keep every load above its group's first MFMA
-    compute_group(0);
-    for (int base = GB; base < per_wave; base += GB) {
-        load_group(base);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_group(base);
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) red[(w * 16 + 4 * q + v) * 16 + j] = acc0[v] + acc1[v];
-    __syncthreads();
-    const float s = (red[(0 * 16 + erow) * 16 + ecol] + red[(1 * 16 + erow) * 16 + ecol]) +
-                    (red[(2 * 16 + erow) * 16 + ecol] + red[(3 * 16 + erow) * 16 + ecol]);
-    a.rpart[(size_t)ks * a.Bp * Fp + eoff] = xv - s;
-}
-
-__global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
-
 // Masking + relayout: x [B][T][F] -> xp [T][Bp][Fp] (masked frames and all padding zero) and
 // valid [T][Bp].  One wave per (t, row).  [K2.0.4-memory: keras.layers.Masking]
 __global__ void __launch_bounds__(256)
@@ -359,6 +265,20 @@ pack_input_kernel(const float* __restrict__ x, float* __restrict__ xp,
     if (l == 0) valid[rowid] = any ? 1 : 0;
 }
 
+// seen[t][row] = 1 iff some frame before t was valid (then the state entering frame t is the last
+// valid output, else softplus(log_h0)); used by the backward pass
+__global__ void __launch_bounds__(256)
+seen_kernel(const unsigned char* __restrict__ valid, unsigned char* __restrict__ seen, int T,
+            int Bp) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= Bp) return;
+    unsigned char s = 0;
+    for (int t = 0; t < T; ++t) {
+        seen[(size_t)t * Bp + row] = s;
+        s |= valid[(size_t)t * Bp + row];
+    }
+}
+
 // state = softplus(log_h0) for every row (custom_layers.py:203-206, 336-341); row sums of the
 // initial state go to atom block 0 of parity 0; frame counter = 0.
 __global__ void __launch_bounds__(256)
@@ -383,39 +303,6 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
     const float tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     for (int i = tid; i < 2 * numA * Bp; i += 256) rs_part[i] = (i < Bp) ? tot : 0.f;
     if (tid == 0) { tptr[0] = 0; tptr[16] = 0; }
-}
-
-struct Workspace {
-    size_t off_xp, off_valid, off_rpart, off_h0, off_h1, off_state, off_rs, off_psum, off_t, total;
-    int Bp, Fp, Np, numA, KS, nch_ks;
-};
-
-Workspace workspace_layout(const drnmf_cell_desc_t* d) {
-    Workspace W;
-    W.Bp = pad_b(d->B);
-    W.Fp = pad_f(d->F);
-    W.Np = pad_n(d->N);
-    W.numA = W.Np / ATOMS;
-    // atom ranges per (row tile, bin tile) in cell_b: enough workgroups to cover the 256 CUs
-    const int tiles = (W.Bp / ROWS) * (W.Fp / 16);
-    const int nchN = W.Np / 16;
-    int KS = 1;
-    while (KS < MAX_KS && tiles * KS < 224 && nchN / (KS * 2) >= 4) KS *= 2;
-    W.KS = KS;
-    W.nch_ks = (nchN + KS - 1) / KS;
-    size_t o = 0;
-    auto take = [&](size_t bytes) { size_t at = o; o += round_up_sz(bytes, 256); return at; };
-    W.off_xp = take((size_t)d->T * W.Bp * W.Fp * 4);
-    W.off_valid = take((size_t)d->T * W.Bp);
-    W.off_rpart = take((size_t)MAX_KS * W.Bp * W.Fp * 4);
-    W.off_h0 = take((size_t)W.Bp * W.Np * 4);
-    W.off_h1 = take((size_t)W.Bp * W.Np * 4);
-    W.off_state = take((size_t)W.Bp * W.Np * 4);
-    W.off_rs = take((size_t)2 * W.numA * W.Bp * 4);
-    W.off_psum = take((size_t)W.Bp * 4);
-    W.off_t = take(256);
-    W.total = o;
-    return W;
 }
 
 template <int G, int KS, bool AH>
@@ -448,13 +335,6 @@ void* pick_a_func(int nchunks, int KS, bool first, bool last, bool all_hidden) {
     const int per_wave = (nchunks + 3) / 4;
     return all_hidden ? pick_a_func_ah<true>(per_wave, KS, first, last)
                       : pick_a_func_ah<false>(per_wave, KS, first, last);
-}
-
-void* pick_b_func(int nch_ks) {
-    const int per_wave = (nch_ks + 3) / 4;
-    if (per_wave <= 4) return (void*)&cell_b_kernel<4>;
-    if (per_wave <= 8) return (void*)&cell_b_kernel<8>;
-    return (void*)&cell_b_kernel<16>;
 }
 
 }  // namespace
@@ -500,6 +380,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         const size_t rows = (size_t)d->T * W.Bp;
         hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                            stream, x, xp, valid, mask_value, d->B, d->T, d->F, W.Bp, W.Fp);
+        hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 255) / 256), dim3(256), 0, stream, valid,
+                           (unsigned char*)(ws + W.off_seen), d->T, W.Bp);
         hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
                            rs_part, tA, d->N, W.Np, W.Bp, W.numA);
         DRNMF_HIP(h, hipGetLastError());
@@ -538,6 +420,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.state = state;
         a.rs_part = rs_part;
         a.psum = psum;
+        a.psum_all = (float*)(ws + W.off_psum_all);
         a.valid = valid;
         a.out = h_out;
         // frame counters: the first kernel of a frame reads tB and republishes it as tA; the last

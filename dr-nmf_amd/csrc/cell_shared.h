@@ -1,0 +1,150 @@
+// Pieces of the recurrent cell shared by the forward (cell_forward.hip) and backward
+// (cell_backward.hip) translation units: tile geometry, the bin-tile contraction kernel
+// (x^ = h Dn^T in the forward, d r = dG Dn^T in the backward) and the workspace layout.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
+constexpr int ATOMS = 32;   // atoms per cell_a workgroup
+constexpr int MAX_KS = 8;
+
+struct CellBArgs {
+    const float* Dn_next;    // [Fp][Np]  next layer's dictionary
+    const float* h;          // [Bp][Np]  this layer's h
+    const float* xp;         // [T][Bp][Fp]; NULL: plain product, rpart[ks] = +acc (backward)
+    float* rpart;            // [KS][Bp][Fp]
+    const int* t_rd;
+    int Bp, Fp, Np, nft, KS, nch_ks;   // nch_ks = 16-atom chunks per atom range
+};
+
+// x^ partial of one (row tile, bin tile, atom range) and the residual partial
+//   rpart[ks] = (ks == 0 ? x_t : 0) - h[16 x range] . Dn_next[16 bins x range]^T.
+// GB = 16-atom chunks per wave per group.
+template <int GB>
+__global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 16];
+    const int numM = a.Bp / ROWS;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int m = qb % numM;
+    const int rest = (qb / numM) * 8 + xcd;        // (bin tile, atom range)
+    if (rest >= a.nft * a.KS) return;
+    const int ft = rest / a.KS, ks = rest % a.KS;
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int l = tid & 63, j = l & 15, q = l >> 4;
+    const int Np = a.Np, Fp = a.Fp;
+    const int cbase = ks * a.nch_ks;                       // first chunk of this atom range
+    int nch = a.Np / 16 - cbase;                           // chunks left in the matrix
+    if (nch > a.nch_ks) nch = a.nch_ks;
+    if (nch < 1) nch = 1;                                  // (never: KS*nch_ks covers Np/16)
+    int per_wave = (nch - w + 3) >> 2;
+    const int clast = nch - 1;
+
+    const int NAC = Np / 16;
+    // blocks (m, cbase+c) of Hp and (ft, cbase+c) of Dp: lane (j, q) reads the float4 of atoms
+    // 16c + 4q + {0..3} in row j -> one contiguous 1 KB block per wave instruction
+    const float* arow = a.h + ((size_t)m * NAC + cbase) * 256 + j * 16 + q * 4;          // + 256*c
+    const float* brow = a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;   // + 256*c
+
+    // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
+    f32x4 av[GB], bv[GB];
+    auto load_group = [&](int base) {
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            int c = w + 4 * (base + g);
+            c = c > clast ? clast : c;
+            av[g] = *(const f32x4*)(arow + 256 * c);
+            bv[g] = *(const f32x4*)(brow + 256 * c);
+        }
+    };
+    load_group(0);
+
+    // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
+    const int erow = tid >> 4, ecol = tid & 15;
+    const size_t eoff = ((size_t)m * a.nft + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
+    float xv = 0.f;
+    if (a.xp != nullptr && ks == 0) {
+        const int t = *a.t_rd;
+        xv = a.xp[(size_t)t * a.Bp * Fp + eoff];
+    }
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto compute_group = [&](int base) {
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            f32x4 a4 = av[g];
+            if (base + g >= per_wave) a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            // two independent accumulator chains hide the 40-cycle dependent MFMA latency
+            if (g & 1) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc1 = mfma16(a4[s], bv[g][s], acc1);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc0 = mfma16(a4[s], bv[g][s], acc0);
+            }
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);   // keep every load above its group's first MFMA
+    compute_group(0);
+    for (int base = GB; base < per_wave; base += GB) {
+        load_group(base);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_group(base);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[(w * 16 + 4 * q + v) * 16 + j] = acc0[v] + acc1[v];
+    __syncthreads();
+    const float s = (red[(0 * 16 + erow) * 16 + ecol] + red[(1 * 16 + erow) * 16 + ecol]) +
+                    (red[(2 * 16 + erow) * 16 + ecol] + red[(3 * 16 + erow) * 16 + ecol]);
+    a.rpart[(size_t)ks * a.Bp * Fp + eoff] = (a.xp != nullptr) ? xv - s : s;
+}
+
+__global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
+
+struct Workspace {
+    size_t off_xp, off_valid, off_seen, off_psum_all, off_rpart, off_h0, off_h1, off_state, off_rs,
+        off_psum, off_t, total;
+    int Bp, Fp, Np, numA, KS, nch_ks;
+};
+
+Workspace workspace_layout(const drnmf_cell_desc_t* d) {
+    Workspace W;
+    W.Bp = pad_b(d->B);
+    W.Fp = pad_f(d->F);
+    W.Np = pad_n(d->N);
+    W.numA = W.Np / ATOMS;
+    // atom ranges per (row tile, bin tile) in cell_b: enough workgroups to cover the 256 CUs
+    const int tiles = (W.Bp / ROWS) * (W.Fp / 16);
+    const int nchN = W.Np / 16;
+    int KS = 1;
+    while (KS < MAX_KS && tiles * KS < 224 && nchN / (KS * 2) >= 4) KS *= 2;
+    W.KS = KS;
+    W.nch_ks = (nchN + KS - 1) / KS;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += round_up_sz(bytes, 256); return at; };
+    W.off_xp = take((size_t)d->T * W.Bp * W.Fp * 4);
+    W.off_valid = take((size_t)d->T * W.Bp);
+    W.off_seen = take((size_t)d->T * W.Bp);          // any valid frame before t (backward)
+    W.off_psum_all = take((size_t)d->T * W.Bp * 4);  // sum(p) of every frame (backward)
+    W.off_rpart = take((size_t)MAX_KS * W.Bp * W.Fp * 4);
+    W.off_h0 = take((size_t)W.Bp * W.Np * 4);
+    W.off_h1 = take((size_t)W.Bp * W.Np * 4);
+    W.off_state = take((size_t)W.Bp * W.Np * 4);
+    W.off_rs = take((size_t)2 * W.numA * W.Bp * 4);
+    W.off_psum = take((size_t)W.Bp * 4);
+    W.off_t = take(256);
+    W.total = o;
+    return W;
+}
+
+void* pick_b_func(int nch_ks) {
+    const int per_wave = (nch_ks + 3) / 4;
+    if (per_wave <= 4) return (void*)&cell_b_kernel<4>;
+    if (per_wave <= 8) return (void*)&cell_b_kernel<8>;
+    return (void*)&cell_b_kernel<16>;
+}
+
+}  // namespace

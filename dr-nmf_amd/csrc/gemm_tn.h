@@ -1,0 +1,139 @@
+// C[M x N] (+)= A^T B with A [Kdim][M], B [Kdim][N] both row-major: the contraction runs over the
+// ROW index (frames).  This is the shape of every time-batched weight gradient of the cell
+// (d Dn_k = R_k^T dG_k - dR_k^T H_{k-1}, contraction over B*T rows): large Kdim, small output, so
+// the contraction is additionally split over gridDim.y and each split hands its partial tile to
+// the epilogue functor (partial buffers are summed afterwards in a fixed order: deterministic).
+//
+//   block tile 128 x 128, BK = 32 rows, 256 threads = 2 x 2 waves, v_mfma_f32_32x32x2_f32
+//   both tiles land in LDS exactly as they sit in memory ([k][m], [k][n]: coalesced 512-byte rows);
+//   MFMA fragments are single-dword reads of 32 consecutive columns (conflict-free).
+#pragma once
+#include "common.h"
+
+namespace gemm_tn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int BM = 128, BN = 128, BK = 32;
+
+struct Operands {
+    const float* A;   // [Kdim][lda], columns = M
+    const float* B;   // [Kdim][ldb], columns = N
+    int64_t Kdim;
+    int M, N;
+    int64_t lda, ldb;
+};
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* base, int64_t k, int64_t Kend, int64_t ld,
+                                       int c, int C) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k < Kend) {
+        const float* p = base + k * ld + c;
+        if (VEC && c + 3 < C) {
+            v = *(const f32x4*)p;
+        } else {
+            if (c + 0 < C) v[0] = p[0];
+            if (c + 1 < C) v[1] = p[1];
+            if (c + 2 < C) v[2] = p[2];
+            if (c + 3 < C) v[3] = p[3];
+        }
+    }
+    return v;
+}
+
+// Epi: __device__ void operator()(int split, int m, int n, float acc) const
+template <class Epi, bool VEC>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Epi epi) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * BM];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    const int li = l & 31, kk = l >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int split = blockIdx.y, splits = gridDim.y;
+    const int64_t nkt = (g.Kdim + BK - 1) / BK;
+    const int64_t per = (nkt + splits - 1) / splits;
+    const int64_t kt0 = split * per;
+    int64_t kt1 = kt0 + per;
+    if (kt1 > nkt) kt1 = nkt;
+
+    const int kr = tid >> 5, c4 = (tid & 31) * 4;   // staging: row kr + 8*i, 4 columns at c4
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int64_t kt) {
+        const int64_t k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = load4<VEC>(g.A, k0 + kr + 8 * i, g.Kdim, g.lda, m0 + c4, g.M);
+            rb[i] = load4<VEC>(g.B, k0 + kr + 8 * i, g.Kdim, g.ldb, n0 + c4, g.N);
+        }
+    };
+    auto swrite = [&](int buf) {
+        float* As = lds + buf * 2 * BK * BM;
+        float* Bs = As + BK * BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(f32x4*)(As + (kr + 8 * i) * BM + c4) = ra[i];
+            *(f32x4*)(Bs + (kr + 8 * i) * BN + c4) = rb[i];
+        }
+    };
+
+    if (kt0 < kt1) {
+        gload(kt0);
+        swrite(0);
+        __syncthreads();
+        for (int64_t kt = kt0; kt < kt1; ++kt) {
+            const int buf = (int)((kt - kt0) & 1);
+            if (kt + 1 < kt1) gload(kt + 1);
+            const float* As = lds + buf * 2 * BK * BM + kk * BM + wm * 64 + li;
+            const float* Bs = lds + buf * 2 * BK * BM + BK * BM + kk * BN + wn * 64 + li;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float a0 = As[2 * s * BM], a1 = As[2 * s * BM + 32];
+                const float b0 = Bs[2 * s * BN], b1 = Bs[2 * s * BN + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (kt + 1 < kt1) swrite(buf ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 64 + b * 32 + li;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+                if (m < g.M) epi(split, m, n, acc[a][b][v]);
+            }
+        }
+}
+
+template <class Epi>
+inline hipError_t launch(const Operands& g, const Epi& epi, int splits, hipStream_t stream) {
+    const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
+                     (((uintptr_t)g.B & 15) == 0);
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    if (vec)
+        hipLaunchKernelGGL((gemm_tn_kernel<Epi, true>), grid, dim3(256), 0, stream, g, epi);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<Epi, false>), grid, dim3(256), 0, stream, g, epi);
+    return hipGetLastError();
+}
+
+}  // namespace gemm_tn

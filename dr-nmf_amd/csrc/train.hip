@@ -1,0 +1,257 @@
+// Training-side pieces around the cell's BPTT: the loss head + mask-head backward and the Adam
+// update.  Reference: y_pred = x_raw * mask, loss 'mse' with temporal sample weights
+// (enhance.py:1040-1048, 1071-1073, 1152), Adam(lr, clipnorm, decay) (enhance.py:1052-1057).
+//
+// Gradients are produced UNNORMALISED (loss' = sum_{b,t} w * mean_f (x*mask - y)^2) together with
+// (sum, count): data-parallel ranks all-reduce the flat gradient and the two scalars and apply the
+// 1/count normalisation afterwards (Keras normalises by batch-level statistics, so averaging
+// per-rank normalised gradients would be wrong when ranks hold different numbers of valid frames).
+#include "gemm_nt.h"
+#include "gemm_tn.h"
+
+namespace {
+
+constexpr int HB_SPLITS = 8;
+inline int pad4i(int v) { return (v + 3) / 4 * 4; }
+
+__global__ void __launch_bounds__(256)
+exp_pad_kernel(const float* __restrict__ kc, const float* __restrict__ kn, float* __restrict__ E,
+               int r, int F, int Fp4) {   // E[seg][k][f], ld Fp4, zero padded
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)2 * r * Fp4) return;
+    const int f = (int)(i % Fp4);
+    const int k = (int)((i / Fp4) % r);
+    const int seg = (int)(i / ((size_t)Fp4 * r));
+    E[i] = f < F ? expf((seg ? kn : kc)[(size_t)k * F + f]) : 0.f;
+}
+
+// per element: err = x*m - y; partial sums of w*err^2/F; dA, dBn of the unnormalised loss
+__global__ void __launch_bounds__(256)
+loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                 const float* __restrict__ A, const float* __restrict__ Bn,
+                 const float* __restrict__ y, const float* __restrict__ w, float* __restrict__ dA,
+                 float* __restrict__ dBn, float* __restrict__ part, int64_t rows, int F, int Fp4,
+                 int square) {
+    __shared__ float ssum[4], scnt[4];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    float acc = 0.f, cnt = 0.f;
+    if (row < rows) {
+        const float wt = w[row];
+        const float invF = 1.f / (float)F;
+        for (int f = l; f < Fp4; f += 64) {
+            float da = 0.f, db = 0.f;
+            if (f < F) {
+                const size_t o = (size_t)row * F + f;
+                const float xv = x[o], m = mask[o], a = A[o], b = Bn[o];
+                const float err = xv * m - y[o];
+                acc += wt * err * err * invF;
+                const float dm = 2.f * wt * err * xv * invF;
+                const float S = 1e-7f + a + b;
+                const float iS2 = 1.f / (S * S);
+                da = dm * b * iS2;                 // d mask / dA  =  Bn / S^2
+                db = -dm * (1e-7f + a) * iS2;      // d mask / dBn = -(eps + A) / S^2
+                if (square) {                      // A = A0^2 (enhance.py:298-299)
+                    da *= 2.f * sqrtf(a);
+                    db *= 2.f * sqrtf(b);
+                }
+            }
+            dA[(size_t)row * Fp4 + f] = da;
+            dBn[(size_t)row * Fp4 + f] = db;
+        }
+        cnt = (l == 0 && wt != 0.f) ? 1.f : 0.f;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    if (l == 0) { ssum[wv] = acc; scnt[wv] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * (size_t)blockIdx.x + 0] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        part[2 * (size_t)blockIdx.x + 1] = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+final_sums_kernel(const float* __restrict__ part, int64_t nblocks, float* __restrict__ sums) {
+    __shared__ double s0[256], s1[256];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < nblocks; i += 256) {
+        a += (double)part[2 * i];
+        b += (double)part[2 * i + 1];
+    }
+    s0[threadIdx.x] = a;
+    s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            s0[threadIdx.x] += s0[threadIdx.x + o];
+            s1[threadIdx.x] += s1[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[0] = (float)s0[0]; sums[1] = (float)s1[0]; }
+}
+
+struct EpiStoreOff {
+    float* C;
+    int64_t ldc;
+    int coloff;
+    __device__ void operator()(int64_t row, int col, float v) const {
+        C[row * ldc + coloff + col] = v;
+    }
+};
+struct EpiPart {
+    float* P;
+    int ld;
+    size_t stride;
+    __device__ void operator()(int split, int m, int n, float acc) const {
+        P[split * stride + (size_t)m * ld + n] = acc;
+    }
+};
+
+// dK[n][f] = (sum of partials) * exp(K[n][f])
+__global__ void __launch_bounds__(256)
+dkernel_kernel(const float* __restrict__ P, const float* __restrict__ E, float* __restrict__ dK,
+               int r, int F, int Fp4, int splits, size_t stride) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)r * F) return;
+    const int n = (int)(i / F), f = (int)(i % F);
+    float g = 0.f;
+    for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)n * Fp4 + f];
+    dK[i] = g * E[(size_t)n * Fp4 + f];
+}
+
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+            float* __restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps,
+            float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+__global__ void __launch_bounds__(256)
+sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+    __shared__ double s[256];
+    double a = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        a += (double)g[i] * (double)g[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)s[0];
+}
+
+struct LhWs {
+    size_t off_E, off_dA, off_dB, off_part, off_P, total;
+    int Fp4;
+    int64_t nblocks;
+};
+LhWs lh_layout(int64_t rows, int F, int r) {
+    LhWs L;
+    L.Fp4 = pad4i(F);
+    L.nblocks = (rows + 3) / 4;
+    size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += round_up_sz(b, 256); return at; };
+    L.off_E = take((size_t)2 * r * L.Fp4 * 4);
+    L.off_dA = take((size_t)rows * L.Fp4 * 4);
+    L.off_dB = take((size_t)rows * L.Fp4 * 4);
+    L.off_part = take((size_t)L.nblocks * 2 * 4);
+    L.off_P = take((size_t)HB_SPLITS * r * L.Fp4 * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t drnmf_loss_head_workspace_bytes(int64_t rows, int32_t F, int32_t r) {
+    if (rows <= 0 || F <= 0 || r <= 0) return 0;
+    return lh_layout(rows, F, r).total;
+}
+
+extern "C" int32_t drnmf_loss_head_backward(drnmf_handle_t h, int64_t rows, int32_t F, int32_t r,
+                                            const float* x_raw, const float* hidden, int64_t ld_h,
+                                            int32_t h_off, const float* kernel_clean,
+                                            const float* kernel_noise, int32_t square,
+                                            const float* mask, const float* A, const float* Bn,
+                                            const float* y, const float* w, float* sums,
+                                            float* d_hidden, float* d_kernel_clean,
+                                            float* d_kernel_noise, void* workspace,
+                                            size_t workspace_bytes, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (rows <= 0 || F <= 0 || r <= 0 || h_off < 0 || ld_h < h_off + 2 * (int64_t)r)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "loss_head_backward: bad shape");
+    if (!x_raw || !hidden || !kernel_clean || !kernel_noise || !mask || !A || !Bn || !y || !w ||
+        !sums || !d_hidden || !d_kernel_clean || !d_kernel_noise || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "loss_head_backward: NULL pointer argument");
+    const LhWs L = lh_layout(rows, F, r);
+    if (workspace_bytes < L.total)
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "loss_head_backward: workspace %zu < required %zu",
+                   workspace_bytes, L.total);
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float* E = (float*)(ws + L.off_E);
+    float* dA = (float*)(ws + L.off_dA);
+    float* dB = (float*)(ws + L.off_dB);
+    float* part = (float*)(ws + L.off_part);
+    float* P = (float*)(ws + L.off_P);
+    const int Fp4 = L.Fp4;
+    {
+        const size_t tot = (size_t)2 * r * Fp4;
+        hipLaunchKernelGGL(exp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                           stream, kernel_clean, kernel_noise, E, r, F, Fp4);
+    }
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)L.nblocks), dim3(256), 0, stream, x_raw,
+                       mask, A, Bn, y, w, dA, dB, part, rows, F, Fp4, square);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(1), dim3(256), 0, stream, part, L.nblocks, sums);
+    DRNMF_HIP(h, hipGetLastError());
+    const int N2 = 2 * r;
+    for (int seg = 0; seg < 2; ++seg) {
+        const float* dX = seg ? dB : dA;
+        const float* Es = E + (size_t)seg * r * Fp4;
+        // d hidden[:, seg*r + n] = sum_f dX[row][f] E[n][f]
+        gemm::Operands g1{dX, Es, rows, r, Fp4, Fp4, Fp4};
+        DRNMF_HIP(h, gemm::launch(g1, EpiStoreOff{d_hidden, N2, seg * r}, stream));
+        // dE[n][f] = sum_rows hidden[row][seg*r + n] dX[row][f];  dK = dE * E
+        gemm_tn::Operands t1{hidden + h_off + (size_t)seg * r, dX, rows, r, F, ld_h, Fp4};
+        const size_t pstr = (size_t)r * Fp4;
+        DRNMF_HIP(h, gemm_tn::launch(t1, EpiPart{P, Fp4, pstr}, HB_SPLITS, stream));
+        const size_t tot = (size_t)r * F;
+        hipLaunchKernelGGL(dkernel_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                           P, Es, seg ? d_kernel_noise : d_kernel_clean, r, F, Fp4, HB_SPLITS, pstr);
+    }
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_adam_step(drnmf_handle_t h, int64_t n, float* param, const float* grad,
+                                   float* m, float* v, float lr_t, float beta1, float beta2,
+                                   float eps, float grad_scale, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n <= 0 || !param || !grad || !m || !v)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step: bad argument");
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream_, param, grad, m, v, n, lr_t, beta1, beta2, eps,
+                       grad_scale);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_sumsq(drnmf_handle_t h, int64_t n, const float* g, float* out256,
+                               void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n <= 0 || !g || !out256) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "sumsq: bad argument");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream_, g, n, out256);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}

@@ -413,6 +413,49 @@ class SimpleDeepRNN(_Layer):
 
     __call__ = call
 
+    # -- training (BPTT) -------------------------------------------------------------------
+    def forward_train(self, x, mask_value=None):
+        """Forward that keeps every layer's hidden state: returns hall [B,T,K*N] (the last N
+        columns are the layer output) and leaves the workspace ready for `backward`."""
+        if not self.built:
+            self.build(tuple(x.shape))
+        B, T, F = x.shape
+        self.prepare(B, T)
+        lab = self.maps_from_alt.labels_per_k
+        _, nD = self._stacked_meta('log_D')
+        _, nA = self._stacked_meta('log_alph')
+        _, nL = self._stacked_meta('log_lam1')
+        desc = ops.make_desc(B, T, self.input_dim, self.output_dim, self.K_layers, nD, nA,
+                             int(self._alt[lab['log_alph'][0]].numel()), nL, True)
+        key = ('train', B, T)
+        if key not in self._ws:
+            self._ws.clear()
+            self._ws[key] = ops.cell_workspace(desc, x.device)
+        hall = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
+                                workspace=self._ws[key])
+        self._train_ctx = (desc, key, mask_value)
+        return hall
+
+    def backward(self, x, hall, d_out, grads=None):
+        """Gradients w.r.t. the stacked log-domain parameters (see ops.cell_backward)."""
+        desc, key, _ = self._train_ctx
+        return ops.cell_backward(x, self._params_block, desc, self.log_h0, self._u, hall, d_out,
+                                 self._ws[key], grads=grads)
+
+    def grad_slices(self):
+        """[(weight name, stacked-gradient key, index)] mapping each alt parameter to its slice
+        of the stacked gradients returned by `backward`."""
+        out = []
+        lab = self.maps_from_alt.labels_per_k
+        for name, gkey in (('log_D', 'd_log_D'), ('log_alph', 'd_log_alph'),
+                           ('log_lam1', 'd_log_lam1')):
+            labels = lab[name]
+            if len(set(labels)) == 1:
+                out.append((labels[0], gkey, 0))
+            else:
+                out += [(lk, gkey, k) for k, lk in enumerate(labels)]
+        return out
+
 
 # ------------------------------------------------------------------------------------------
 # build_unfolded_snmf  (enhance.py:209-317)
@@ -451,6 +494,131 @@ class UnfoldedSNMFModel(object):
         return self.forward(xt).cpu().numpy()
 
     __call__ = forward
+
+    # -- training: loss 'mse_of_masked' + Adam (enhance.py:1040-1073, 1152) -----------------
+    def compile(self, loss='mse', optimizer='adam', lr=1e-3, clipnorm=0., decay=0., beta_1=0.9,
+                beta_2=0.999, epsilon=1e-8, sample_weight_mode='temporal'):
+        """model.compile(loss='mse', optimizer=Adam(lr, clipnorm, decay),
+        sample_weight_mode='temporal') applied to output_masked = input * mask
+        (enhance.py:1042, 1057, 1071-1073)."""
+        if loss != 'mse' or optimizer != 'adam' or sample_weight_mode != 'temporal':
+            raise NotImplementedError("only loss='mse', optimizer='adam', temporal sample weights "
+                                      "(the reference's training configuration)")
+        self.opt = dict(lr=float(lr), clipnorm=float(clipnorm), decay=float(decay),
+                        b1=float(beta_1), b2=float(beta_2), eps=float(epsilon), iterations=0)
+        cell = self.cell
+        self._train_items = [('log_h0', cell.log_h0)]
+        self._train_items += [(k, cell._alt[k]) for k in cell._alt if k in cell.keys_trainable]
+        self._train_items += [('kernel_clean', self.clean.kernel), ('kernel_noise', self.noise.kernel)]
+        self._opt_state = {n: (torch.zeros_like(t), torch.zeros_like(t))
+                           for n, t in self._train_items}
+        total = sum(int(t.numel()) for _, t in self._train_items)
+        self._flat = torch.zeros(total + 2, dtype=torch.float32, device=cell.device)
+        self._gview, o = {}, 0
+        for n, t in self._train_items:
+            self._gview[n] = self._flat[o:o + t.numel()].view(t.shape)
+            o += t.numel()
+        return self
+
+    def loss_and_grads(self, x, y, sample_weight):
+        """Unnormalised loss/gradients of one (local) batch into the flat buffer; returns the
+        flat tensor [grads..., sum w*mse, count]."""
+        cell = self.cell
+        N, K = cell.output_dim, cell.K_layers
+        hall = cell.forward_train(x, mask_value=self.mask_value)
+        h_off = (K - 1) * N
+        mask, A, Bn = ops.head_forward(hall, self.clean.kernel, self.noise.kernel,
+                                       square=self.square, want_ab=True, h_off=h_off)
+        sums, d_hidden, dkc, dkn = ops.loss_head_backward(
+            x, hall, self.clean.kernel, self.noise.kernel, mask, A, Bn, y, sample_weight,
+            square=self.square, h_off=h_off)
+        g = cell.backward(x, hall, d_hidden)
+        self._flat.zero_()
+        gv = self._gview
+        gv['log_h0'].copy_(g['d_log_h0'])
+        for wname, gkey, idx in cell.grad_slices():
+            if wname in gv:
+                gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
+        gv['kernel_clean'].copy_(dkc)
+        gv['kernel_noise'].copy_(dkn)
+        self._flat[-2:].copy_(sums)
+        return self._flat
+
+    def apply_gradients(self, flat):
+        """Adam step from the (already all-reduced) flat buffer; returns the normalised loss."""
+        o = self.opt
+        sse, cnt = float(flat[-2]), float(flat[-1])
+        scale = 1.0 / max(cnt, 1.0)
+        if o['clipnorm'] > 0:                       # global-norm clip [K2.0.4-memory]
+            norm = float(torch.sqrt(ops.sumsq(flat[:-2]))) * scale
+            if norm > o['clipnorm']:
+                scale *= o['clipnorm'] / norm
+        lr = o['lr']
+        if o['decay'] > 0:
+            lr *= 1.0 / (1.0 + o['decay'] * o['iterations'])
+        t = o['iterations'] + 1
+        lr_t = lr * np.sqrt(1.0 - o['b2'] ** t) / (1.0 - o['b1'] ** t)
+        for n, p in self._train_items:
+            m, v = self._opt_state[n]
+            ops.adam_step(p, self._gview[n].contiguous(), m, v, lr_t, o['b1'], o['b2'], o['eps'],
+                          grad_scale=scale)
+        o['iterations'] = t
+        self.cell._weights_changed()
+        return sse * (1.0 / max(cnt, 1.0))
+
+    def train_on_batch(self, x, y, sample_weight=None):
+        """One optimiser step.  x, y: (B,T,F); sample_weight: (B,T) (the data mask,
+        enhance.py:1148-1152).  Under torch.distributed the flat gradient + (sum, count) are
+        all-reduced (RCCL) before the update, so every rank applies the same step."""
+        from . import dp
+        dev = self.cell.device
+        tt = lambda a: a if isinstance(a, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        x, y = tt(x), tt(y)
+        if sample_weight is None:
+            sample_weight = torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
+        flat = self.loss_and_grads(x, y, tt(sample_weight))
+        dp.allreduce_sum_(flat)
+        return self.apply_gradients(flat)
+
+    def test_on_batch(self, x, y, sample_weight=None):
+        from . import dp
+        dev = self.cell.device
+        tt = lambda a: a if isinstance(a, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        x, y = tt(x), tt(y)
+        w = tt(sample_weight) if sample_weight is not None else \
+            torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
+        m = self.forward(x)
+        mse = ((x * m - y) ** 2).mean(-1)
+        s = torch.stack([(mse * w).sum(), (w != 0).float().sum()])
+        dp.allreduce_sum_(s)
+        return float(s[0]) / max(float(s[1]), 1.0)
+
+    def fit(self, x, y, sample_weight=None, batch_size=32, epochs=1, validation_data=None,
+            shuffle=True, seed=7654, verbose=0):
+        """Minimal keras.Model.fit: shuffled mini-batches (np.random.seed(7654), enhance.py:7),
+        returns {'loss': [...], 'val_loss': [...]} per epoch.  Under torch.distributed every rank
+        passes ITS shard of the data; batches are all-reduced per step."""
+        n = x.shape[0]
+        rng = np.random.RandomState(seed)
+        hist = {'loss': [], 'val_loss': []}
+        for ep in range(epochs):
+            idx = rng.permutation(n) if shuffle else np.arange(n)
+            tot, cnt = 0.0, 0
+            for s0 in range(0, n, batch_size):
+                b = idx[s0:s0 + batch_size]
+                sw = None if sample_weight is None else sample_weight[b]
+                tot += self.train_on_batch(x[b], y[b], sw)
+                cnt += 1
+            hist['loss'].append(tot / max(cnt, 1))
+            if validation_data is not None:
+                xv, yv, wv = validation_data
+                hist['val_loss'].append(self.test_on_batch(xv, yv, wv))
+            if verbose:
+                print('epoch %d loss %.6f%s' % (ep + 1, hist['loss'][-1],
+                      (' val_loss %.6f' % hist['val_loss'][-1]) if validation_data else ''))
+        return hist
 
 
 def build_unfolded_snmf(params_unfolded_snmf, device=None):

@@ -146,6 +146,94 @@ def head_forward(hidden, kernel_clean, kernel_noise, square=False, want_ab=False
     return (mask, A, Bn) if want_ab else mask
 
 
+def loss_head_backward(x_raw, hidden, kernel_clean, kernel_noise, mask, A, Bn, y, w, square=False,
+                       h_off=0):
+    """Unnormalised loss + gradients of the mask head (see drnmf_loss_head_backward).
+    Returns (sums[2] device tensor, d_hidden [..., 2r], d_kernel_clean, d_kernel_noise)."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(hidden))
+    x_raw, hidden, mask, A, Bn, y = (_f32c(t, n) for t, n in
+                                     ((x_raw, "x_raw"), (hidden, "hidden"), (mask, "mask"),
+                                      (A, "A"), (Bn, "Bn"), (y, "y")))
+    w = _f32c(w, "w")
+    kc, kn = _f32c(kernel_clean, "kernel_clean"), _f32c(kernel_noise, "kernel_noise")
+    r, F = kc.shape
+    ld = hidden.shape[-1]
+    rows = hidden.numel() // ld
+    if x_raw.numel() != rows * F or w.numel() != rows:
+        raise ValueError("loss_head_backward: shape mismatch")
+    dev = hidden.device
+    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    d_hidden = torch.empty(tuple(hidden.shape[:-1]) + (2 * r,), dtype=torch.float32, device=dev)
+    dkc, dkn = torch.empty_like(kc), torch.empty_like(kn)
+    nbytes = L.drnmf_loss_head_workspace_bytes(rows, F, r)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rc = L.drnmf_loss_head_backward(h, rows, F, r, _capi.ptr(x_raw), _capi.ptr(hidden), ld,
+                                    int(h_off), _capi.ptr(kc), _capi.ptr(kn), int(bool(square)),
+                                    _capi.ptr(mask), _capi.ptr(A), _capi.ptr(Bn), _capi.ptr(y),
+                                    _capi.ptr(w), _capi.ptr(sums), _capi.ptr(d_hidden),
+                                    _capi.ptr(dkc), _capi.ptr(dkn), _capi.ptr(ws), nbytes,
+                                    _stream())
+    _capi.check(rc, h, "drnmf_loss_head_backward")
+    return sums, d_hidden, dkc, dkn
+
+
+def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=None):
+    """BPTT through the cell (forward must have been run with return_all_hidden=True on the same
+    workspace).  Returns dict(d_log_D [n_D,F,N], d_log_alph [n_alph,alph_len], d_log_lam1 [n_lam],
+    d_log_h0 [N]); `grads` may supply preallocated output tensors."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(x))
+    x, hall, d_out = _f32c(x, "x"), _f32c(hall, "hall"), _f32c(d_out, "d_out")
+    if tuple(hall.shape) != (desc.B, desc.T, desc.K * desc.N):
+        raise ValueError("hall must be (B,T,K*N) = (%d,%d,%d)" % (desc.B, desc.T, desc.K * desc.N))
+    if tuple(d_out.shape) != (desc.B, desc.T, desc.N):
+        raise ValueError("d_out must be (B,T,N)")
+    dev = x.device
+    g = grads or {}
+    out = {
+        "d_log_D": g.get("d_log_D", None) if g.get("d_log_D") is not None else
+        torch.empty((desc.n_D, desc.F, desc.N), dtype=torch.float32, device=dev),
+        "d_log_alph": g.get("d_log_alph") if g.get("d_log_alph") is not None else
+        torch.empty((desc.n_alph, desc.alph_len), dtype=torch.float32, device=dev),
+        "d_log_lam1": g.get("d_log_lam1") if g.get("d_log_lam1") is not None else
+        torch.empty((desc.n_lam,), dtype=torch.float32, device=dev),
+        "d_log_h0": g.get("d_log_h0") if g.get("d_log_h0") is not None else
+        torch.empty((desc.N,), dtype=torch.float32, device=dev),
+    }
+    nbytes = L.drnmf_cell_backward_workspace_bytes(C.byref(desc))
+    bws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rc = L.drnmf_cell_backward(h, C.byref(desc), _capi.ptr(x), _capi.ptr(params),
+                               _capi.ptr(log_h0), float(u[0]), float(u[1]), float(u[2]),
+                               _capi.ptr(hall), _capi.ptr(d_out), _capi.ptr(fwd_workspace),
+                               fwd_workspace.numel(), _capi.ptr(bws), nbytes,
+                               _capi.ptr(out["d_log_D"]), _capi.ptr(out["d_log_alph"]),
+                               _capi.ptr(out["d_log_lam1"]), _capi.ptr(out["d_log_h0"]), _stream())
+    _capi.check(rc, h, "drnmf_cell_backward")
+    return out
+
+
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(param))
+    for t in (param, grad, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("adam_step needs contiguous float32 tensors")
+    rc = L.drnmf_adam_step(h, param.numel(), _capi.ptr(param), _capi.ptr(grad), _capi.ptr(m),
+                           _capi.ptr(v), float(lr_t), float(beta1), float(beta2), float(eps),
+                           float(grad_scale), _stream())
+    _capi.check(rc, h, "drnmf_adam_step")
+
+
+def sumsq(g):
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(g))
+    out = torch.empty(256, dtype=torch.float32, device=g.device)
+    rc = L.drnmf_sumsq(h, g.numel(), _capi.ptr(_f32c(g, "g")), _capi.ptr(out), _stream())
+    _capi.check(rc, h, "drnmf_sumsq")
+    return out.double().sum()
+
+
 def ista_forward(X, W, H, lam1, alph, K, divergence="ed", beta=2.0):
     """Frame-parallel ISTA (enhance.py:402-456) in row layout: X [n,F], W [F,N], H [n,N] updated
     IN PLACE and returned."""

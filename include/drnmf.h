@@ -113,6 +113,47 @@ int32_t drnmf_head_forward(drnmf_handle_t h, int64_t rows, int32_t F, int32_t r,
                            const float* kernel_clean, const float* kernel_noise, int32_t square,
                            float* mask, float* A_out, float* Bn_out, float* ecat, void* stream);
 
+/* ---- training: loss head + mask-head backward.  Replaces y_pred = x_raw * mask, loss 'mse' with
+ * temporal sample weights (enhance.py:1040-1048, 1071-1073, 1152) and Theano's autodiff of the
+ * head (custom_layers.py:23-45).  Gradients are UNNORMALISED: they belong to
+ * loss' = sum_rows w * mean_f (x*mask - y)^2; sums[0] = loss', sums[1] = #rows with w != 0, so that
+ * data-parallel ranks can all-reduce (gradient, sums) and normalise afterwards.
+ *   x_raw, mask, A, Bn, y [rows][F]; w [rows]; hidden [rows][ld_h] (columns h_off .. h_off+2r);
+ *   d_hidden [rows][2r]; d_kernel_clean / d_kernel_noise [r][F]; sums [2] (device) */
+size_t drnmf_loss_head_workspace_bytes(int64_t rows, int32_t F, int32_t r);
+int32_t drnmf_loss_head_backward(drnmf_handle_t h, int64_t rows, int32_t F, int32_t r,
+                                 const float* x_raw, const float* hidden, int64_t ld_h,
+                                 int32_t h_off, const float* kernel_clean,
+                                 const float* kernel_noise, int32_t square, const float* mask,
+                                 const float* A, const float* Bn, const float* y, const float* w,
+                                 float* sums, float* d_hidden, float* d_kernel_clean,
+                                 float* d_kernel_noise, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
+/* ---- training: BPTT through the recurrent cell.  Replaces Theano's autodiff of the scan
+ * (enhance.py:1071-1073, 1152).  Requires the forward to have been run with
+ * return_all_hidden = 1 on the same x / params / workspace:
+ *   hall  [B][T][K*N]  the forward output (every layer's hidden state)
+ *   d_out [B][T][N]    gradient w.r.t. the LAST layer's output (drnmf_loss_head_backward)
+ * Outputs (overwritten): d_log_D [n_D][F][N], d_log_alph [n_alph][alph_len], d_log_lam1 [n_lam],
+ * d_log_h0 [N].  Masked frames follow K.rnn (no gradient enters them). */
+size_t drnmf_cell_backward_workspace_bytes(const drnmf_cell_desc_t* d);
+int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                            const void* params, const float* log_h0, float u0_diag, float u0_off,
+                            float uk_off, const float* hall, const float* d_out,
+                            const void* fwd_workspace, size_t fwd_workspace_bytes,
+                            void* bwd_workspace, size_t bwd_workspace_bytes, float* d_log_D,
+                            float* d_log_alph, float* d_log_lam1, float* d_log_h0, void* stream);
+
+/* ---- training: Adam (enhance.py:1052-1057; keras.optimizers.Adam [K2.0.4-memory]):
+ *   g = grad*grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps)
+ * lr_t (bias correction, decay) and grad_scale (1/count, clipnorm factor) are host-computed.
+ * drnmf_sumsq writes 256 partial sums of g^2 (for the global-norm clip). */
+int32_t drnmf_adam_step(drnmf_handle_t h, int64_t n, float* param, const float* grad, float* m,
+                        float* v, float lr_t, float beta1, float beta2, float eps, float grad_scale,
+                        void* stream);
+int32_t drnmf_sumsq(drnmf_handle_t h, int64_t n, const float* g, float* out256, void* stream);
+
 /* ---- frame-parallel ISTA: replaces ista_ed / ista_kl / ista_beta (enhance.py:402-456).
  * Row-vector layout (frames are rows):  X [n][F], W [F][N] (used as given, NOT re-normalised),
  * H [n][N] in/out.  K iterations of H <- max(0, H + (g(X, H W^T) W - lam1)/alph).

@@ -1,0 +1,59 @@
+"""TEST INFRASTRUCTURE ONLY -- torch (CPU, fp64) restatement of the DR-NMF model + loss, used to
+obtain reference GRADIENTS by autograd (the reference relies on Theano autodiff of the same graph:
+enhance.py:1040-1073, 1152).  Forward values are cross-checked against oracle/drnmf_oracle.py in
+tests/test_oracle.py; never imported by the product package."""
+import torch
+
+EPS = 1e-7
+
+
+def unit_cols(logD):
+    D = torch.exp(logD)
+    return D / torch.sqrt((D * D).sum(0, keepdim=True))
+
+
+def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, square=False,
+               normalise=True):
+    """x, y: (B,T,F) float64 tensors; w: (B,T) sample weights (= validity mask in the reference).
+    alt: dict name -> tensor (requires_grad where wanted).  Returns (loss, mask, h)."""
+    B, T, F = x.shape
+    N = log_h0.shape[0]
+    r = N // 2
+    valid = (x != mask_value).any(-1)
+    xm = x * valid[..., None].to(x.dtype)
+    U1 = torch.exp(alt['log_U1'])
+    Uk = torch.exp(alt['log_Uk'])
+    u0d, u0o, uko = U1[0, 0], (U1[0, 1] if N > 1 else U1[0, 0] * 0), Uk[0, 0]
+    h0 = torch.nn.functional.softplus(log_h0)
+    state = h0[None, :].expand(B, N)
+    out_prev = torch.zeros(B, N, dtype=x.dtype)
+    outs = []
+    for t in range(T):
+        p = state
+        ps = p.sum(1, keepdim=True)
+        xt = xm[:, t]
+        Dn = unit_cols(alt[labels_per_k['log_D'][0]])
+        ia = torch.exp(-alt[labels_per_k['log_alph'][0]])
+        lam = torch.exp(alt[labels_per_k['log_lam1'][0]])
+        h = torch.relu(u0d * p + u0o * (ps - p) + (xt @ Dn) * ia - lam * ia)
+        for k in range(1, K):
+            Dn = unit_cols(alt[labels_per_k['log_D'][k]])
+            ia = torch.exp(-alt[labels_per_k['log_alph'][k]])
+            lam = torch.exp(alt[labels_per_k['log_lam1'][k]])
+            rr = xt - h @ Dn.t()
+            h = torch.relu(h + (rr @ Dn) * ia - lam * ia + uko * ps)
+        v = valid[:, t][:, None]
+        out_prev = torch.where(v, h, out_prev)
+        state = torch.where(v, h, state)
+        outs.append(out_prev)
+    hs = torch.stack(outs, 1)
+    A = hs[..., :r] @ torch.exp(kc)
+    Bn = hs[..., r:] @ torch.exp(kn)
+    if square:
+        A, Bn = A * A, Bn * Bn
+    mask = torch.exp(torch.log(EPS + A) - torch.log(EPS + A + Bn))
+    mse = ((x * mask - y) ** 2).mean(-1)                # y_pred = x_raw * mask (enhance.py:1042)
+    sse = (mse * w).sum()
+    cnt = (w != 0).to(x.dtype).sum()
+    loss = sse / cnt if normalise else sse
+    return loss, mask, hs

@@ -200,3 +200,22 @@ def test_stft_framing_and_magnitude():
     # sqrt-Hann is COLA at hop = N/4 for the squared window (istft_noDiv relies on it)
     ola = sum(np.roll(w.astype(np.float64) ** 2, k * hop) for k in range(N // hop))
     np.testing.assert_allclose(ola, ola[0], rtol=1e-6)
+
+
+def test_torch_autograd_restatement_matches_numpy_oracle():
+    import torch
+    from oracle import drnmf_torch_ref as TR
+    P, alt, labels, N, K = _small(B=3, T=5, ragged=True)
+    r = N // 2
+    kc = np.log(1e-7 + P["W"][:, :r]).T
+    kn = np.log(1e-7 + P["W"][:, r:]).T
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    w = (P["X"] != -1.0).any(-1).astype(np.float64)
+    loss, mask, hs = TR.model_loss(t64(P["X"]), t64(P["Y"]), t64(w), {k: t64(v) for k, v in alt.items()},
+                                   labels, K, t64(P["log_h0"]), t64(kc), t64(kn))
+    mref, href = O.model_forward(P["X"], alt, labels, K, P["log_h0"], kc, kn)
+    np.testing.assert_allclose(hs.numpy(), href, atol=1e-12)
+    np.testing.assert_allclose(mask.numpy(), mref, atol=1e-12)
+    np.testing.assert_allclose(float(loss), O.loss_mse_of_masked(P["X"].astype(np.float64), mref,
+                                                                 P["Y"].astype(np.float64), w),
+                               rtol=1e-12)
