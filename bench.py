@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--tied", action="store_true", help="tie log_D/log_alph across layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ista", action="store_true", help="skip the frame-parallel ISTA line")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step line")
     ap.add_argument("--cpu-frames", type=int, default=0,
                     help="frame-steps of the CPU baseline sample (0 = auto, ~15-25 s)")
     return ap.parse_args()
@@ -86,6 +87,39 @@ def ista_bench(torch, dev, F, N, K, W, n=32768):
     return {"frames": n, "K": K, "frames_per_s": n / sec, "tflops": tf,
             "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,
             "gemm_launch_us": sec / (2 * K) * 1e6}
+
+
+def train_bench(torch, dev, steps=3):
+    """BASELINE configs[2]: the shipped training configuration (downsample1: F=257, maxlen=500,
+    batch 32, K=5, r=1000, untied log_D/log_alph) -- forward + BPTT + Adam per step, synthetic
+    ragged batch.  Algorithmic flops fwd+bwd = 12*F*N*K - 2*F*N per frame."""
+    from drnmf_amd import layers
+    from oracle import drnmf_oracle as O
+    B, T, F, r, K = 32, 500, 257, 1000, 5
+    N = 2 * r
+    P = O.synth_problem(B, T, F, r, seed=7654, ragged=True)
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=400.0, lam1=1.0, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph"])
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.compile(lr=1e-3)
+    x = torch.from_numpy(P["X"]).to(dev)
+    y = torch.from_numpy(P["Y"]).to(dev)
+    w = torch.from_numpy((P["X"] != -1.0).any(-1).astype(np.float32)).to(dev)
+    losses = [model.train_on_batch(x, y, w)]          # warm-up (graph build)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(model.train_on_batch(x, y, w))
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / steps
+    valid = float(w.sum().item())
+    flops = (12.0 * F * N * K - 2.0 * F * N) * B * T
+    return {"config": "F=%d N=%d K=%d B=%d T=%d untied, ragged (%.0f%% valid)" %
+                      (F, N, K, B, T, 100.0 * valid / (B * T)),
+            "ms_per_step": sec * 1e3, "frames_per_s": B * T / sec,
+            "valid_frames_per_s": valid / sec, "tflops": flops / sec / 1e12,
+            "loss_first": losses[0], "loss_last": losses[-1]}
 
 
 def cpu_baseline(F, r, K, B, frames, tied):
@@ -214,20 +248,32 @@ def main():
     # of the cell's launches on the launch stream / number of launches (the hipGraph replays run
     # back to back, so this includes the ~1.7 us launch boundary, as rocprofv3's kernel trace of
     # the same command does: it reports zero gaps between consecutive kernels).
-    n_launch = T * (2 * K - 1)
+    import ctypes
+    from drnmf_amd import _capi
+    chains = int(_capi.lib().drnmf_cell_chains(ctypes.byref(model.cell._desc(B, T))))
+    # the batch runs as `chains` concurrent row groups, each with its own 2K-1 launches per frame;
+    # launch_us is the mean time the chip spends per launch (cell time / launches): concurrent
+    # launches overlap, so it is a throughput figure, not one kernel's latency
+    n_launch = T * (2 * K - 1) * chains
+    flops_per_launch = 2.0 * (B / chains) * F * N
     launch_us = (sum(cell_ms) / len(cell_ms)) * 1e3 / n_launch
     ach = flops_per_launch / (launch_us * 1e-6) / 1e12
     roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
             "kernel": "cell_a_kernel / cell_b_kernel (mean over the 2K-1 launches of a frame)",
-            "launch_us": launch_us, "flops_per_launch": flops_per_launch}
+            "launch_us": launch_us, "flops_per_launch": flops_per_launch,
+            "concurrent_chains": chains}
     extra = {}
     if rank == 0:
-        extra = {"frame_us": launch_us * (2 * K - 1), "cell_ms_per_step": sum(cell_ms) / len(cell_ms),
+        extra = {"frame_us": launch_us * (2 * K - 1) * chains, "cell_ms_per_step": sum(cell_ms) / len(cell_ms),
                  "whole_forward_tflops": whole,
                  "whole_forward_frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS}
         if not a.no_ista:
             extra["ista_frame_parallel"] = ista_bench(torch, dev, F, N, K, W)
+        if not a.no_train and world == 1:
+            del X
+            torch.cuda.empty_cache()
+            extra["train_step_configs2"] = train_bench(torch, dev)
     out = {
         "metric": "STFT frames/sec (K=%d unrolled DR-NMF forward, %d-bin x %d-frame)" % (K, F, T),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps,

@@ -44,14 +44,12 @@ struct EdgeArgs {
 
 __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
     __shared__ float sm[ROWS][ATOMS + 1];
-    const int numM = a.Bp / ROWS;
-    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int m = qb % numM;
-    const int ab = (qb / numM) * 8 + xcd;
+    const int m = blockIdx.y;
+    const int ab = blockIdx.x;
     if (ab >= a.numA) return;
     const int tid = threadIdx.x;
     const int c = *a.c_rd;
-    if (a.c_wr && blockIdx.x == 0 && tid == 0) *a.c_wr = c;
+    if (a.c_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.c_wr = c;
     const int t = a.T - 1 - c;
     const int NAC = a.Np / 16, ac0 = ab * 2;
     const int erow = tid >> 4, ec = (tid & 15) * 2;
@@ -146,11 +144,9 @@ struct BwdAArgs {
 template <int G, int KS>
 __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4 * ROWS * ATOMS];
-    const int numM = a.Bp / ROWS;
-    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int m = qb % numM;
-    const int ab = (qb / numM) * 8 + xcd;
-    if (ab >= a.numA) return;
+    const int m = blockIdx.y;
+    const bool live = (int)blockIdx.x < a.numA;
+    const int ab = live ? (int)blockIdx.x : a.numA - 1;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63, j = l & 15, q = l >> 4;
@@ -183,7 +179,7 @@ __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
     load_group(0);
 
     const int cnt = *a.c_rd;
-    if (a.c_wr && blockIdx.x == 0 && tid == 0) *a.c_wr = cnt + 1;
+    if (a.c_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.c_wr = cnt + 1;
     const int t = a.T - 1 - cnt;
     const int erow = tid >> 4, ec = (tid & 15) * 2;
     const int rg = row0 + erow, n = n0 + ec;
@@ -205,7 +201,7 @@ __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
             for (int ks = 1; ks < KS; ++ks) r4 += av[g][ks];
             const bool ok = base + g < per_wave;
             if (!ok) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ab == 0 && ok && row0 + j < a.B) {
+            if (blockIdx.x == 0 && ok && row0 + j < a.B) {
                 // the summed d r_k of this row tile goes out row-major for the weight gradients
                 const int c = w + 4 * (base + g);
                 float* dr = a.dR + ((size_t)(row0 + j) * a.T + t) * Fp + 16 * c + q;
@@ -241,6 +237,7 @@ __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
         gsum[1] += p2[1];
     }
 
+    if (!live) return;
     f32x2 dzn;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -529,8 +526,8 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
 
     // ---- sequential pass: T replays of the per-frame graph in reverse time ---------------------
     DRNMF_HIP(h, hipMemsetAsync(bw, 0, L.off_dh0, stream));   // dstate .. counters
-    const unsigned grid_a = (unsigned)(round_up(W.numA, 8) * numM);
-    const unsigned grid_b = (unsigned)(round_up(nft * W.KS, 8) * numM);
+    const dim3 grid_a((unsigned)round_up(W.numA, 8), (unsigned)numM);
+    const dim3 grid_b((unsigned)round_up(nft * W.KS, 8), (unsigned)numM);
 
     EdgeArgs ea;
     ea.hall = hall; ea.d_out = d_out; ea.dz_all = dz_all; ea.ia_last = ia_of(K - 1);
@@ -550,6 +547,8 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         b.rpart = drpart;
         b.t_rd = cA;
         b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS; b.nch_ks = W.nch_ks;
+        b.logKS = 0;
+        while ((1 << b.logKS) < W.KS) ++b.logKS;
         return b;
     };
     auto make_a = [&](int k) {
@@ -594,11 +593,11 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         ge.key = key;
         DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
         hipGraphNode_t last = nullptr;
-        auto add = [&](void* func, unsigned grid, unsigned block, void* argp) -> hipError_t {
+        auto add = [&](void* func, dim3 grid, unsigned block, void* argp) -> hipError_t {
             hipKernelNodeParams p;
             memset(&p, 0, sizeof(p));
             void* kp[1] = {argp};
-            p.func = func; p.gridDim = dim3(grid); p.blockDim = dim3(block);
+            p.func = func; p.gridDim = grid; p.blockDim = dim3(block);
             p.sharedMemBytes = 0; p.kernelParams = kp; p.extra = nullptr;
             hipGraphNode_t node;
             hipError_t e = hipGraphAddKernelNode(&node, ge.graph, last ? &last : nullptr,
@@ -615,14 +614,14 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         }
         if (K == 1) {
             int* cp = cA;
-            DRNMF_HIP(h, add((void*)&advance_frame_kernel, 1, 1, &cp));
+            DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, &cp));
         }
         DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
         h->graphs.push_back(ge);
         entry = &h->graphs.back();
     }
     for (int t = 0; t < T; ++t) DRNMF_HIP(h, hipGraphLaunch(entry->exec, stream));
-    hipLaunchKernelGGL(bwd_edge_kernel, dim3(grid_a), dim3(256), 0, stream, ea);   // t = -1
+    hipLaunchKernelGGL(bwd_edge_kernel, grid_a, dim3(256), 0, stream, ea);   // t = -1
     hipLaunchKernelGGL(dlogh0_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dh0_part,
                        log_h0, d_log_h0, N, W.Np, numM);
     DRNMF_HIP(h, hipGetLastError());

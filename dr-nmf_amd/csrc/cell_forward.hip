@@ -64,13 +64,14 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
     constexpr bool WRITE_OUT = IS_LAST || ALL_HIDDEN;
     __shared__ __attribute__((aligned(16))) float red[4 * ROWS * ATOMS];   // [4][16][32]
 
-    // XCD-aware block -> (atom block, row tile): blocks are dealt round-robin to the 8 XCDs, so
-    // the row tiles that share one dictionary slice are given the same blockIdx % 8.
-    const int numM = a.Bp / ROWS;
-    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int m = qb % numM;
-    const int ab = (qb / numM) * 8 + xcd;
-    if (ab >= a.numA) return;
+    // 2-D grid (atom block [padded to a multiple of 8], row tile): workgroups are dealt
+    // round-robin to the 8 XCDs by linear id = x + y * gridDim.x, gridDim.x % 8 == 0, so the row
+    // tiles that share one dictionary slice (same x) land on the same XCD / L2.  The padded
+    // blocks redo the last atom block with every store predicated off: no early exit, so all
+    // kernel arguments arrive in ONE scalar-load round trip ahead of the operand loads.
+    const int m = blockIdx.y;
+    const bool live = (int)blockIdx.x < a.numA;
+    const int ab = live ? (int)blockIdx.x : a.numA - 1;
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
     int t = 0;
     if (IS_FIRST) {
         t = *a.t_rd;
-        if (a.t_wr && blockIdx.x == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
+        if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
     }
     const float* rsrc = IS_FIRST ? a.rsrc + (size_t)t * pstride : a.rsrc;
     const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
@@ -103,20 +104,23 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
 
     f32x4 av[G][NP];
     f32x2 bv[G][4];
-    auto load_group = [&](int base) {
+    auto load_chunk = [&](int base, int g) {
+        int c = w + 4 * (base + g);
+        c = c > clast ? clast : c;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            int c = w + 4 * (base + g);
-            c = c > clast ? clast : c;
+        for (int ks = 0; ks < NP; ++ks)
+            av[g][ks] = *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
 #pragma unroll
-            for (int ks = 0; ks < NP; ++ks)
-                av[g][ks] = *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
-        }
+        for (int s = 0; s < 4; ++s)
+            bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
     };
-    load_group(0);
+    // Software pipeline: the texture path of a CU moves 64 B/clk and is shared by the 4 waves, so
+    // issuing one chunk's operand loads for all waves takes about as long as one wave's MFMAs on
+    // that chunk.  Loads run PF chunks ahead of the MFMAs (enough to cover the L2/fabric latency)
+    // and the two streams overlap instead of adding up.
+    constexpr int PF = G < 4 ? G : 4;
+#pragma unroll
+    for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
     // ---- epilogue operands (tiny, needed last; issued behind the GEMM operands) --------------
     const int erow = tid >> 4, ec = (tid & 15) * 2;
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
     const f32x2 bs = *(const f32x2*)(a.bias + n);
     if (!IS_FIRST && WRITE_OUT) {
         t = *a.t_rd;
-        if (a.t_wr && blockIdx.x == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
+        if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
     }
     float ps;
     if (IS_FIRST) {
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
         s += __shfl_xor(s, 2, 16);
         s += __shfl_xor(s, 1, 16);
         ps = s;
-        if (ab == 0 && (tid & 15) == 0) {
+        if (blockIdx.x == 0 && (tid & 15) == 0) {
             a.psum[rg] = ps;
             a.psum_all[(size_t)t * a.Bp + rg] = ps;
         }
@@ -152,29 +156,31 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
     if (WRITE_OUT) vld = a.valid[(size_t)t * a.Bp + rg] != 0;
 
     // ---- GEMM:  g[16 x 32] = r[16 x F] . Dn[F x 32] -------------------------------------------
-    auto compute_group = [&](int base) {
+    auto compute_chunk = [&](int base, int g) {
+        f32x4 r4 = av[g][0];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            f32x4 r4 = av[g][0];
+        for (int ks = 1; ks < NP; ++ks) r4 += av[g][ks];
+        if (base + g >= per_wave) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 1; ks < NP; ++ks) r4 += av[g][ks];
-            if (base + g >= per_wave) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc0 = mfma16(r4[s], bv[g][s][0], acc0);
-                acc1 = mfma16(r4[s], bv[g][s][1], acc1);
-            }
+        for (int s = 0; s < 4; ++s) {
+            acc0 = mfma16(r4[s], bv[g][s][0], acc0);
+            acc1 = mfma16(r4[s], bv[g][s][1], acc1);
         }
     };
-    // all loads above stay above (the scheduler would otherwise sink each chunk's loads next to
-    // its MFMAs and serialise the memory round trips); the MFMAs then retire them with counted
-    // vmcnt waits in issue order
-    __builtin_amdgcn_sched_barrier(0);
-    compute_group(0);
-    for (int base = G; base < per_wave; base += G) {
-        load_group(base);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_group(base);
+    // sched_barriers pin the interleave (the scheduler would otherwise regroup loads and MFMAs);
+    // the MFMAs retire their operands with counted vmcnt waits in issue order
+    for (int base = 0; base < per_wave; base += G) {
+        if (base > 0) {
+#pragma unroll
+            for (int g = 0; g < PF; ++g) load_chunk(base, g);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g + PF < G) load_chunk(base, g + PF);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_chunk(base, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- cross-wave reduction of the 4 F-splits through LDS --------------------------------
@@ -203,7 +209,7 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
         hn[e] = fmaxf(pre, 0.f);
     }
 
-    const bool row_live = rg < a.B;
+    const bool row_live = live && rg < a.B;
     if (WRITE_OUT && row_live) {
         // K.rnn masking: a masked step repeats the previous output (zeros before the first
         // valid step)
@@ -217,6 +223,7 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
             }
         }
     }
+    if (!live) return;
     if (IS_LAST) {
         // ... and keeps the previous state
         f32x2 st = hn;
@@ -233,6 +240,8 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
         *(f32x2*)(a.h_out + hoff) = hn;
     }
 }
+
+__global__ void noop_kernel() {}
 
 // Masking + relayout: x [B][T][F] -> xp [T][Bp][Fp] (masked frames and all padding zero) and
 // valid [T][Bp].  One wave per (t, row).  [K2.0.4-memory: keras.layers.Masking]
@@ -339,16 +348,26 @@ void* pick_a_func(int nchunks, int KS, bool first, bool last, bool all_hidden) {
 
 }  // namespace
 
+static size_t chained_workspace_bytes(const drnmf_cell_desc_t* d, int G);
+
 extern "C" size_t drnmf_cell_workspace_bytes(const drnmf_cell_desc_t* d) {
     if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0) return 0;
-    return workspace_layout(d).total;
+    size_t best = workspace_layout(d).total;
+    for (int G = 2; G <= 8; ++G) {
+        const size_t t = chained_workspace_bytes(d, G);
+        if (t > best) best = t;
+    }
+    return best;
 }
 
 static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
                                  float mask_value, const void* params, const float* log_h0,
                                  float u0_diag, float u0_off, float uk_off, float* h_out,
                                  void* workspace, size_t workspace_bytes, void* stream_,
-                                 int profile_frames, float* out_us) {
+                                 int profile_frames, float* out_us,
+                                 hipGraphExec_t* out_exec = nullptr) {
+    // out_exec != NULL: enqueue the prologue and build/find the frame graph, but leave the T
+    // replays to the caller (who interleaves them with other chains)
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;
@@ -400,11 +419,12 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
         key.push_back(b0); key.push_back(b1); key.push_back(b2);
     }
-    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0;
+    const bool use_graph = (getenv("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0) ||
+                           out_exec != nullptr;
 
     const int numM = W.Bp / ROWS, nft = W.Fp / 16;
-    const unsigned grid_a = (unsigned)(round_up(W.numA, 8) * numM);
-    const unsigned grid_b = (unsigned)(round_up(nft * W.KS, 8) * numM);
+    const dim3 grid_a((unsigned)round_up(W.numA, 8), (unsigned)numM);
+    const dim3 grid_b((unsigned)round_up(nft * W.KS, 8), (unsigned)numM);
     const float* Dn_base = (const float*)(pb + L.off_dn);
     const size_t dstride = (size_t)L.Fp * L.Np;
     auto Dn_of = [&](int k) { return Dn_base + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
@@ -432,7 +452,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         else { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
         a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
         a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
-        a.numA = ablate ? 0 : W.numA; a.nchunks = nft; a.KS = W.KS;
+        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS;
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
         a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
@@ -445,7 +465,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         b.xp = xp;
         b.rpart = rpart;
         b.t_rd = tA;
-        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = ablate ? 0 : nft; b.KS = W.KS;
+        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS;
+        b.logKS = 0;
+        while ((1 << b.logKS) < W.KS) ++b.logKS;
         b.nch_ks = W.nch_ks;
         return b;
     };
@@ -472,13 +494,13 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
                 DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, k == 0, k == K - 1,
                                                          d->return_all_hidden != 0),
-                                             dim3(grid_a), dim3(256), kp, 0, stream));
+                                             grid_a, dim3(256), kp, 0, stream));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     void* kb[1] = {&b};
                     DRNMF_HIP(h, mark(1));
-                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks), dim3(grid_b), dim3(256),
-                                                 kb, 0, stream));
+                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks), grid_b, dim3(256), kb, 0,
+                                                 stream));
                 }
             }
             if (K == 1) {
@@ -515,7 +537,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     for (auto& g : h->graphs)
         if (g.key == key) { entry = &g; break; }
     if (!entry) {
-        if (h->graphs.size() >= 8) {   // bounded cache: drop the oldest
+        if (h->graphs.size() >= 24) {   // bounded cache: drop the oldest
             (void)hipGraphExecDestroy(h->graphs.front().exec);
             (void)hipGraphDestroy(h->graphs.front().graph);
             h->graphs.erase(h->graphs.begin());
@@ -524,12 +546,12 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         ge.key = key;
         DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
         hipGraphNode_t last = nullptr;
-        auto add = [&](void* func, unsigned grid, unsigned block, void* argp) -> hipError_t {
+        auto add = [&](void* func, dim3 grid, unsigned block, void* argp) -> hipError_t {
             hipKernelNodeParams p;
             memset(&p, 0, sizeof(p));
             void* kp[1] = {argp};
             p.func = func;
-            p.gridDim = dim3(grid);
+            p.gridDim = grid;
             p.blockDim = dim3(block);
             p.sharedMemBytes = 0;
             p.kernelParams = kp;
@@ -542,30 +564,132 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         };
         for (int k = 0; k < K; ++k) {
             CellAArgs a = make_a(k);
-            DRNMF_HIP(h, add(pick_a_func(nft, W.KS, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 256, &a));
+            DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 256, &a));
             if (k < K - 1) {
                 CellBArgs b = make_b(k);
-                DRNMF_HIP(h, add(pick_b_func(W.nch_ks), grid_b, 256, &b));
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks), grid_b, 256, &b));
             }
         }
         if (K == 1) {
             int* tp = tA;
-            DRNMF_HIP(h, add((void*)&advance_frame_kernel, 1, 1, &tp));
+            DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, &tp));
         }
         DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
         h->graphs.push_back(ge);
         entry = &h->graphs.back();
     }
+    if (out_exec) {
+        *out_exec = entry->exec;
+        return DRNMF_OK;
+    }
     for (int t = 0; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(entry->exec, stream));
     return DRNMF_OK;
+}
+
+// ---- concurrent utterance chains ------------------------------------------------------------------
+// The frame kernels are latency-bound (launch boundary + cold-L2 fill; MFMA and L2 bandwidth are
+// ~15 % busy), and utterances are independent, so the batch is split into row groups that run as
+// independent chains on side streams: one chain's boundary/fill latency overlaps another chain's
+// compute.  Forked from and joined to the caller's stream with events.
+static int choose_chains(const drnmf_cell_desc_t* d) {
+    if (d->return_all_hidden) return 1;              // training keeps one workspace for the BPTT
+    // Measured on MI355X (C2, B=64): 2 chains 0.78x, 4 chains 0.34x of the single-chain rate --
+    // kernels from different queues do not overlap usefully (every kernel boundary writes back
+    // and invalidates the L2s chip-wide).  Kept as an opt-in experiment only.
+    int g = 1;
+    if (const char* e = getenv("DRNMF_CHAINS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8) g = v;
+    }
+    while (g > 1 && d->B / g < 1) g >>= 1;
+    if (getenv("DRNMF_NO_GRAPH")) g = 1;
+    return g;
+}
+
+static void chain_rows(int B, int G, int g, int* b0, int* b1) {
+    // whole 16-row tiles per chain where possible
+    const int tiles = (B + 15) / 16;
+    const int base = tiles / G, rem = tiles % G;
+    const int t0 = g * base + (g < rem ? g : rem);
+    const int t1 = t0 + base + (g < rem ? 1 : 0);
+    *b0 = t0 * 16 < B ? t0 * 16 : B;
+    *b1 = t1 * 16 < B ? t1 * 16 : B;
+}
+
+static size_t chained_workspace_bytes(const drnmf_cell_desc_t* d, int G) {
+    size_t tot = 0;
+    for (int g = 0; g < G; ++g) {
+        int b0, b1;
+        chain_rows(d->B, G, g, &b0, &b1);
+        if (b1 <= b0) continue;
+        drnmf_cell_desc_t dg = *d;
+        dg.B = b1 - b0;
+        tot += workspace_layout(&dg).total;
+    }
+    return tot;
 }
 
 extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
                                       float mask_value, const void* params, const float* log_h0,
                                       float u0_diag, float u0_off, float uk_off, float* h_out,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
-    return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
-                             workspace, workspace_bytes, stream_, 0, nullptr);
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    int rc = validate_cell_desc(h, d);
+    if (rc) return rc;
+    const int G = choose_chains(d);
+    if (G <= 1)
+        return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off,
+                                 h_out, workspace, workspace_bytes, stream_, 0, nullptr);
+    if (!x || !params || !log_h0 || !h_out || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_forward: NULL pointer argument");
+    if (workspace_bytes < chained_workspace_bytes(d, G))
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "cell_forward: workspace %zu < required %zu",
+                   workspace_bytes, chained_workspace_bytes(d, G));
+    hipStream_t stream = (hipStream_t)stream_;
+    while ((int)h->side_streams.size() < G) {
+        hipStream_t s;
+        hipEvent_t e;
+        DRNMF_HIP(h, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        DRNMF_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->side_streams.push_back(s);
+        h->side_done.push_back(e);
+    }
+    if (!h->fork_event) DRNMF_HIP(h, hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming));
+    DRNMF_HIP(h, hipEventRecord(h->fork_event, stream));
+    const int width = d->N;   // (return_all_hidden never takes this path)
+    std::vector<hipGraphExec_t> exec(G, nullptr);
+    std::vector<int> live(G, 0);
+    size_t woff = 0;
+    for (int g = 0; g < G; ++g) {
+        int b0, b1;
+        chain_rows(d->B, G, g, &b0, &b1);
+        if (b1 <= b0) continue;
+        drnmf_cell_desc_t dg = *d;
+        dg.B = b1 - b0;
+        const size_t wbytes = workspace_layout(&dg).total;
+        DRNMF_HIP(h, hipStreamWaitEvent(h->side_streams[g], h->fork_event, 0));
+        rc = cell_forward_impl(h, &dg, x + (size_t)b0 * d->T * d->F, mask_value, params, log_h0,
+                               u0_diag, u0_off, uk_off, h_out + (size_t)b0 * d->T * width,
+                               (char*)workspace + woff, wbytes, h->side_streams[g], 0, nullptr,
+                               &exec[g]);
+        if (rc) return rc;
+        live[g] = 1;
+        woff += wbytes;
+    }
+    for (int t = 0; t < d->T; ++t)
+        for (int g = 0; g < G; ++g)
+            if (live[g]) DRNMF_HIP(h, hipGraphLaunch(exec[g], h->side_streams[g]));
+    for (int g = 0; g < G; ++g) {
+        if (!live[g]) continue;
+        DRNMF_HIP(h, hipEventRecord(h->side_done[g], h->side_streams[g]));
+        DRNMF_HIP(h, hipStreamWaitEvent(stream, h->side_done[g], 0));
+    }
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_cell_chains(const drnmf_cell_desc_t* d) {
+    if (!d || d->B <= 0) return 0;
+    return choose_chains(d);
 }
 
 extern "C" int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,

@@ -16,7 +16,7 @@ struct CellBArgs {
     const float* xp;         // [T][Bp][Fp]; NULL: plain product, rpart[ks] = +acc (backward)
     float* rpart;            // [KS][Bp][Fp]
     const int* t_rd;
-    int Bp, Fp, Np, nft, KS, nch_ks;   // nch_ks = 16-atom chunks per atom range
+    int Bp, Fp, Np, nft, KS, logKS, nch_ks;   // nch_ks = 16-atom chunks per atom range
 };
 
 // x^ partial of one (row tile, bin tile, atom range) and the residual partial
@@ -25,12 +25,12 @@ struct CellBArgs {
 template <int GB>
 __global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4 * 16 * 16];
-    const int numM = a.Bp / ROWS;
-    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int m = qb % numM;
-    const int rest = (qb / numM) * 8 + xcd;        // (bin tile, atom range)
-    if (rest >= a.nft * a.KS) return;
-    const int ft = rest / a.KS, ks = rest % a.KS;
+    // 2-D grid ((bin tile, atom range) padded to a multiple of 8, row tile): see cell_a_kernel.
+    // KS is a power of two.  Padded blocks redo the last tile with the store predicated off.
+    const int m = blockIdx.y;
+    const bool live = (int)blockIdx.x < a.nft * a.KS;
+    const int rest = live ? (int)blockIdx.x : a.nft * a.KS - 1;
+    const int ft = rest >> a.logKS, ks = rest & (a.KS - 1);
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -51,16 +51,16 @@ __global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
 
     // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
     f32x4 av[GB], bv[GB];
-    auto load_group = [&](int base) {
-#pragma unroll
-        for (int g = 0; g < GB; ++g) {
-            int c = w + 4 * (base + g);
-            c = c > clast ? clast : c;
-            av[g] = *(const f32x4*)(arow + 256 * c);
-            bv[g] = *(const f32x4*)(brow + 256 * c);
-        }
+    auto load_chunk = [&](int base, int g) {
+        int c = w + 4 * (base + g);
+        c = c > clast ? clast : c;
+        av[g] = *(const f32x4*)(arow + 256 * c);
+        bv[g] = *(const f32x4*)(brow + 256 * c);
     };
-    load_group(0);
+    // software pipeline: loads run PF chunks ahead of the MFMAs (see cell_a_kernel)
+    constexpr int PF = GB < 6 ? GB : 6;
+#pragma unroll
+    for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
     // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
     const int erow = tid >> 4, ecol = tid & 15;
@@ -72,34 +72,35 @@ __global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
     }
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    auto compute_group = [&](int base) {
+    auto compute_chunk = [&](int base, int g) {
+        f32x4 a4 = av[g];
+        if (base + g >= per_wave) a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // two independent accumulator chains hide the 40-cycle dependent MFMA latency
 #pragma unroll
-        for (int g = 0; g < GB; ++g) {
-            f32x4 a4 = av[g];
-            if (base + g >= per_wave) a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            // two independent accumulator chains hide the 40-cycle dependent MFMA latency
-            if (g & 1) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc1 = mfma16(a4[s], bv[g][s], acc1);
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc0 = mfma16(a4[s], bv[g][s], acc0);
-            }
+        for (int s = 0; s < 4; ++s) {
+            if (s & 1) acc1 = mfma16(a4[s], bv[g][s], acc1);
+            else acc0 = mfma16(a4[s], bv[g][s], acc0);
         }
     };
-    __builtin_amdgcn_sched_barrier(0);   // keep every load above its group's first MFMA
-    compute_group(0);
-    for (int base = GB; base < per_wave; base += GB) {
-        load_group(base);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_group(base);
+    for (int base = 0; base < per_wave; base += GB) {
+        if (base > 0) {
+#pragma unroll
+            for (int g = 0; g < PF; ++g) load_chunk(base, g);
+        }
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            if (g + PF < GB) load_chunk(base, g + PF);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_chunk(base, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) red[(w * 16 + 4 * q + v) * 16 + j] = acc0[v] + acc1[v];
     __syncthreads();
     const float s = (red[(0 * 16 + erow) * 16 + ecol] + red[(1 * 16 + erow) * 16 + ecol]) +
                     (red[(2 * 16 + erow) * 16 + ecol] + red[(3 * 16 + erow) * 16 + ecol]);
-    a.rpart[(size_t)ks * a.Bp * Fp + eoff] = (a.xp != nullptr) ? xv - s : s;
+    if (live) a.rpart[(size_t)ks * a.Bp * Fp + eoff] = (a.xp != nullptr) ? xv - s : s;
 }
 
 __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
