@@ -608,7 +608,7 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, &ea));
         for (int k = K - 1; k >= 1; --k) {
             CellBArgs b = make_b(k);
-            DRNMF_HIP(h, add(pick_b_func(W.nch_ks), grid_b, 256, &b));
+            DRNMF_HIP(h, add(pick_b_func(W.nch_ks), grid_b, 64 * NW_B, &b));
             BwdAArgs a = make_a(k);
             DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, &a));
         }

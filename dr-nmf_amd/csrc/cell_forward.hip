@@ -60,9 +60,9 @@ struct CellAArgs {
 // G = 16-bin chunks handled per wave per group (all of a group's operand loads are issued before
 // its first MFMA so that one memory round trip covers the group).
 template <int G, int KS, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN>
-__global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
+__global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     constexpr bool WRITE_OUT = IS_LAST || ALL_HIDDEN;
-    __shared__ __attribute__((aligned(16))) float red[4 * ROWS * ATOMS];   // [4][16][32]
+    __shared__ __attribute__((aligned(16))) float red[NW_A * ROWS * ATOMS];   // [NW][16][32]
 
     // 2-D grid (atom block [padded to a multiple of 8], row tile): workgroups are dealt
     // round-robin to the 8 XCDs by linear id = x + y * gridDim.x, gridDim.x % 8 == 0, so the row
@@ -98,14 +98,14 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
     // operand zeroed) so that the compiler can retire them with counted vmcnt waits and the
     // MFMAs start as soon as the first chunk lands.
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int per_wave = (a.nchunks - w + 3) >> 2;   // chunks owned by this wave (>= 0)
+    const int per_wave = (a.nchunks - w + NW_A - 1) / NW_A;   // chunks owned by this wave (>= 0)
     const int clast = a.nchunks - 1;
     constexpr int NP = IS_FIRST ? 1 : KS;
 
     f32x4 av[G][NP];
     f32x2 bv[G][4];
     auto load_chunk = [&](int base, int g) {
-        int c = w + 4 * (base + g);
+        int c = w + NW_A * (base + g);
         c = c > clast ? clast : c;
 #pragma unroll
         for (int ks = 0; ks < NP; ++ks)
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
     // ---- epilogue operands (tiny, needed last; issued behind the GEMM operands) --------------
-    const int erow = tid >> 4, ec = (tid & 15) * 2;
+    const int erow = (tid & 255) >> 4, ec = (tid & 15) * 2;   // waves 4.. mirror waves 0..3
     const int rg = row0 + erow, n = n0 + ec;
     const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
     const f32x2 hp = *(const f32x2*)(a.h_in + hoff);
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
         s += __shfl_xor(s, 2, 16);
         s += __shfl_xor(s, 1, 16);
         ps = s;
-        if (blockIdx.x == 0 && (tid & 15) == 0) {
+        if (blockIdx.x == 0 && tid < 256 && (tid & 15) == 0) {
             a.psum[rg] = ps;
             a.psum_all[(size_t)t * a.Bp + rg] = ps;
         }
@@ -190,9 +190,10 @@ __global__ void __launch_bounds__(256) cell_a_kernel(const CellAArgs a) {
         *(f32x2*)(red + (w * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
     }
     __syncthreads();
+    if (tid >= 256) return;   // the elementwise epilogue is 256 threads wide
     f32x2 gsum = *(const f32x2*)(red + (0 * ROWS + erow) * ATOMS + ec);
 #pragma unroll
-    for (int ww = 1; ww < 4; ++ww) {
+    for (int ww = 1; ww < NW_A; ++ww) {
         const f32x2 p2 = *(const f32x2*)(red + (ww * ROWS + erow) * ATOMS + ec);
         gsum[0] += p2[0];
         gsum[1] += p2[1];
@@ -324,7 +325,7 @@ void* a_func(bool first, bool last) {
 
 template <int KS, bool AH>
 void* a_func_g(int per_wave, bool first, bool last) {
-    // keep operand registers (G * (4*KS + 8)) within budget: large KS only pairs with small G
+    // G chunks per wave per group; operand registers G * (4*KS + 8): large KS pairs with small G
     if (per_wave <= 3) return a_func<3, KS, AH>(first, last);
     if (per_wave <= 5 || KS >= 4) return a_func<5, KS, AH>(first, last);
     return a_func<9, KS, AH>(first, last);
@@ -341,7 +342,7 @@ void* pick_a_func_ah(int per_wave, int KS, bool first, bool last) {
 }
 
 void* pick_a_func(int nchunks, int KS, bool first, bool last, bool all_hidden) {
-    const int per_wave = (nchunks + 3) / 4;
+    const int per_wave = (nchunks + NW_A - 1) / NW_A;
     return all_hidden ? pick_a_func_ah<true>(per_wave, KS, first, last)
                       : pick_a_func_ah<false>(per_wave, KS, first, last);
 }
@@ -494,12 +495,12 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
                 DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, k == 0, k == K - 1,
                                                          d->return_all_hidden != 0),
-                                             grid_a, dim3(256), kp, 0, stream));
+                                             grid_a, dim3(64 * NW_A), kp, 0, stream));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     void* kb[1] = {&b};
                     DRNMF_HIP(h, mark(1));
-                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks), grid_b, dim3(256), kb, 0,
+                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks), grid_b, dim3(64 * NW_B), kb, 0,
                                                  stream));
                 }
             }
@@ -564,10 +565,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         };
         for (int k = 0; k < K; ++k) {
             CellAArgs a = make_a(k);
-            DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 256, &a));
+            DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 64 * NW_A, &a));
             if (k < K - 1) {
                 CellBArgs b = make_b(k);
-                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks), grid_b, 256, &b));
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks), grid_b, 64 * NW_B, &b));
             }
         }
         if (K == 1) {

@@ -9,6 +9,8 @@ namespace {
 constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
 constexpr int ATOMS = 32;   // atoms per cell_a workgroup
 constexpr int MAX_KS = 8;
+constexpr int NW_B = 8;    // waves per cell_b workgroup (more requests in flight per CU)
+constexpr int NW_A = 4;    // waves per cell_a workgroup (8 measured slower: 224k vs 232k frames/s)
 
 struct CellBArgs {
     const float* Dn_next;    // [Fp][Np]  next layer's dictionary
@@ -22,9 +24,9 @@ struct CellBArgs {
 // x^ partial of one (row tile, bin tile, atom range) and the residual partial
 //   rpart[ks] = (ks == 0 ? x_t : 0) - h[16 x range] . Dn_next[16 bins x range]^T.
 // GB = 16-atom chunks per wave per group.
-template <int GB>
-__global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 16];
+template <int GB, int NW = 8>
+__global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[NW * 16 * 16];
     // 2-D grid ((bin tile, atom range) padded to a multiple of 8, row tile): see cell_a_kernel.
     // KS is a power of two.  Padded blocks redo the last tile with the store predicated off.
     const int m = blockIdx.y;
@@ -40,7 +42,7 @@ __global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
     int nch = a.Np / 16 - cbase;                           // chunks left in the matrix
     if (nch > a.nch_ks) nch = a.nch_ks;
     if (nch < 1) nch = 1;                                  // (never: KS*nch_ks covers Np/16)
-    int per_wave = (nch - w + 3) >> 2;
+    int per_wave = (nch - w + NW - 1) / NW;
     const int clast = nch - 1;
 
     const int NAC = Np / 16;
@@ -52,7 +54,7 @@ __global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
     // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
     f32x4 av[GB], bv[GB];
     auto load_chunk = [&](int base, int g) {
-        int c = w + 4 * (base + g);
+        int c = w + NW * (base + g);
         c = c > clast ? clast : c;
         av[g] = *(const f32x4*)(arow + 256 * c);
         bv[g] = *(const f32x4*)(brow + 256 * c);
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
     // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
-    const int erow = tid >> 4, ecol = tid & 15;
+    const int erow = (tid & 255) >> 4, ecol = tid & 15;
     const size_t eoff = ((size_t)m * a.nft + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
     float xv = 0.f;
     if (a.xp != nullptr && ks == 0) {
@@ -98,9 +100,12 @@ __global__ void __launch_bounds__(256) cell_b_kernel(const CellBArgs a) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) red[(w * 16 + 4 * q + v) * 16 + j] = acc0[v] + acc1[v];
     __syncthreads();
-    const float s = (red[(0 * 16 + erow) * 16 + ecol] + red[(1 * 16 + erow) * 16 + ecol]) +
-                    (red[(2 * 16 + erow) * 16 + ecol] + red[(3 * 16 + erow) * 16 + ecol]);
-    if (live) a.rpart[(size_t)ks * a.Bp * Fp + eoff] = (a.xp != nullptr) ? xv - s : s;
+    float s = 0.f;
+    if (tid < 256) {
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += red[(ww * 16 + erow) * 16 + ecol];
+    }
+    if (live && tid < 256) a.rpart[(size_t)ks * a.Bp * Fp + eoff] = (a.xp != nullptr) ? xv - s : s;
 }
 
 __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
@@ -142,10 +147,10 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
 }
 
 void* pick_b_func(int nch_ks) {
-    const int per_wave = (nch_ks + 3) / 4;
+    const int per_wave = (nch_ks + 7) / 8;
+    if (per_wave <= 2) return (void*)&cell_b_kernel<2>;
     if (per_wave <= 4) return (void*)&cell_b_kernel<4>;
-    if (per_wave <= 8) return (void*)&cell_b_kernel<8>;
-    return (void*)&cell_b_kernel<16>;
+    return (void*)&cell_b_kernel<8>;
 }
 
 }  // namespace
