@@ -290,8 +290,9 @@ struct EpiResid {   // R = X - H Dn^T
     const float* X;
     float* R;
     int F, ldr;
-    __device__ void operator()(int64_t row, int col, float xh) const {
-        R[row * ldr + col] = X[row * F + col] - xh;
+    __device__ f32x2 pre(int64_t row, int col) const { return f32x2{X[row * F + col], 0.f}; }
+    __device__ void operator()(int64_t row, int col, float xh, f32x2 pv) const {
+        R[row * ldr + col] = pv[0] - xh;
     }
 };
 struct EpiP1 {      // partial[split] = acc * ia[n]
@@ -299,16 +300,20 @@ struct EpiP1 {      // partial[split] = acc * ia[n]
     const float* ia;
     int Np;
     size_t stride;
-    __device__ void operator()(int split, int m, int n, float acc) const {
-        P[split * stride + (size_t)m * Np + n] = acc * ia[n];
+    __device__ float pre(int, int, int n) const { return ia[n]; }
+    __device__ void operator()(int split, int m, int n, float acc, float pv) const {
+        P[split * stride + (size_t)m * Np + n] = acc * pv;
     }
 };
 struct EpiP2 {      // partial[split] -= acc
     float* P;
     int Np;
     size_t stride;
-    __device__ void operator()(int split, int m, int n, float acc) const {
-        P[split * stride + (size_t)m * Np + n] -= acc;
+    __device__ float pre(int split, int m, int n) const {
+        return P[split * stride + (size_t)m * Np + n];
+    }
+    __device__ void operator()(int split, int m, int n, float acc, float pv) const {
+        P[split * stride + (size_t)m * Np + n] = pv - acc;
     }
 };
 
@@ -643,11 +648,12 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
             DRNMF_HIP(h, gemm::launch(g1, EpiResid{x, Rk, F, W.Fp}, stream));
             Aop = Rk;
         }
-        gemm_tn::Operands t1{Aop, dz_all + (size_t)k * N, BT, F, N, W.Fp, KN};
+        // M = Fp: the padded bins of R / X / dR are zero, and whole 4-column groups keep the loads vectorised
+        gemm_tn::Operands t1{Aop, dz_all + (size_t)k * N, BT, W.Fp, N, W.Fp, KN};
         DRNMF_HIP(h, gemm_tn::launch(t1, EpiP1{P, ia_of(k), W.Np, pstr}, TN_SPLITS, stream));
         if (k >= 1) {
-            gemm_tn::Operands t2{dR_all + (size_t)k * BT * W.Fp, hall + (size_t)(k - 1) * N, BT, F,
-                                 N, W.Fp, KN};
+            gemm_tn::Operands t2{dR_all + (size_t)k * BT * W.Fp, hall + (size_t)(k - 1) * N, BT,
+                                 W.Fp, N, W.Fp, KN};
             DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, TN_SPLITS, stream));
         }
         const int kd = d->n_D == 1 ? 0 : k;

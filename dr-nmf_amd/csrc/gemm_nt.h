@@ -26,26 +26,34 @@ struct Operands {
     int64_t lda, ldb;
 };
 
-// VEC: lda, ldb multiples of 4, base pointers 16-byte aligned -> float4 global loads.
+// VEC: lda, ldb, K multiples of 4, base pointers 16-byte aligned -> one branch-free float4 load
+// (out-of-range rows / k are clamped to a valid address and the result zeroed by a select).
 template <bool VEC>
 __device__ __forceinline__ f32x4 load4(const float* base, int64_t row, int64_t nrows, int64_t ld,
                                        int k, int K) {
+    if (VEC) {
+        const bool ok = row < nrows && k < K;
+        const int64_t rr = row < nrows ? row : nrows - 1;
+        const int kc = k < K ? k : 0;
+        f32x4 v = *(const f32x4*)(base + rr * ld + kc);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        return v;
+    }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (row < nrows) {
         const float* p = base + row * ld + k;
-        if (VEC && k + 3 < K) {
-            v = *(const f32x4*)p;
-        } else {
-            if (k + 0 < K) v[0] = p[0];
-            if (k + 1 < K) v[1] = p[1];
-            if (k + 2 < K) v[2] = p[2];
-            if (k + 3 < K) v[3] = p[3];
-        }
+        if (k + 0 < K) v[0] = p[0];
+        if (k + 1 < K) v[1] = p[1];
+        if (k + 2 < K) v[2] = p[2];
+        if (k + 3 < K) v[3] = p[3];
     }
     return v;
 }
 
-// Epi: struct with  __device__ void operator()(int64_t row, int col, float acc) const
+// Epi: struct with   f32x2 pre(int64_t row, int col) const        -- values the update needs from memory
+//                    void operator()(int64_t row, int col, float acc, f32x2 pre) const
+// The epilogue first issues all 16 `pre` loads of a 32x32 tile, then applies: one memory round trip
+// per tile instead of one per element.
 template <class Epi, bool VEC>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDS_LD];
@@ -124,18 +132,25 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Ep
         for (int b = 0; b < 2; ++b) {
             const int col = n0 + wn * 64 + b * 32 + li;
             if (col >= g.N) continue;
+            f32x2 pv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                int64_t row = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+                row = row < g.M ? row : g.M - 1;
+                pv[v] = epi.pre(row, col);
+            }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int64_t row = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                if (row < g.M) epi(row, col, acc[a][b][v]);
+                if (row < g.M) epi(row, col, acc[a][b][v], pv[v]);
             }
         }
 }
 
 template <class Epi>
 inline hipError_t launch(const Operands& g, const Epi& epi, hipStream_t stream) {
-    const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
-                     (((uintptr_t)g.Bt & 15) == 0);
+    const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) &&
+                     (((uintptr_t)g.A & 15) == 0) && (((uintptr_t)g.Bt & 15) == 0);
     const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (tiles <= 0 || tiles > 0x7fffffff) return hipErrorInvalidValue;
     if (vec)

@@ -23,25 +23,30 @@ struct Operands {
     int64_t lda, ldb;
 };
 
+// VEC: lda, ldb, M, N multiples of 4 and 16-byte aligned bases -> branch-free float4 loads
 template <bool VEC>
 __device__ __forceinline__ f32x4 load4(const float* base, int64_t k, int64_t Kend, int64_t ld,
                                        int c, int C) {
+    if (VEC) {
+        const bool ok = k < Kend && c < C;
+        const int64_t kr = k < Kend ? k : Kend - 1;
+        const int cc = c < C ? c : 0;
+        f32x4 v = *(const f32x4*)(base + kr * ld + cc);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        return v;
+    }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k < Kend) {
         const float* p = base + k * ld + c;
-        if (VEC && c + 3 < C) {
-            v = *(const f32x4*)p;
-        } else {
-            if (c + 0 < C) v[0] = p[0];
-            if (c + 1 < C) v[1] = p[1];
-            if (c + 2 < C) v[2] = p[2];
-            if (c + 3 < C) v[3] = p[3];
-        }
+        if (c + 0 < C) v[0] = p[0];
+        if (c + 1 < C) v[1] = p[1];
+        if (c + 2 < C) v[2] = p[2];
+        if (c + 3 < C) v[3] = p[3];
     }
     return v;
 }
 
-// Epi: __device__ void operator()(int split, int m, int n, float acc) const
+// Epi: float pre(int split, int m, int n) const;  void operator()(int split, int m, int n, float acc, float pre) const
 template <class Epi, bool VEC>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * BM];
@@ -115,18 +120,26 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
         for (int b = 0; b < 2; ++b) {
             const int n = n0 + wn * 64 + b * 32 + li;
             if (n >= g.N) continue;
+            float pv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                int m = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+                m = m < g.M ? m : g.M - 1;
+                pv[v] = epi.pre(split, m, n);
+            }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int m = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                if (m < g.M) epi(split, m, n, acc[a][b][v]);
+                if (m < g.M) epi(split, m, n, acc[a][b][v], pv[v]);
             }
         }
 }
 
 template <class Epi>
 inline hipError_t launch(const Operands& g, const Epi& epi, int splits, hipStream_t stream) {
-    const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
-                     (((uintptr_t)g.B & 15) == 0);
+    // the 4-wide column groups must not straddle M / N: pad the operand or take the scalar path
+    const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.M % 4 == 0) && (g.N % 4 == 0) &&
+                     (((uintptr_t)g.A & 15) == 0) && (((uintptr_t)g.B & 15) == 0);
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid((unsigned)tiles, (unsigned)splits);
     if (vec)

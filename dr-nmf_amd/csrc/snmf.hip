@@ -34,16 +34,18 @@ __global__ void __launch_bounds__(256) fill_kernel(float* p, size_t n, float v) 
 }
 
 // ---------------- ISTA epilogues ----------------------------------------------------------------
+template <int DIV>   // compile-time divergence: the ED epilogue must not carry the powf paths
 struct EpiResidual {   // R = g(X, X^): enhance.py:412 / 431 / 450
     const float* X;
     float* R;
-    int F, ldr, div;
+    int F, ldr;
     float beta;
-    __device__ void operator()(int64_t row, int col, float xh) const {
-        const float x = X[row * F + col];
+    __device__ f32x2 pre(int64_t row, int col) const { return f32x2{X[row * F + col], 0.f}; }
+    __device__ void operator()(int64_t row, int col, float xh, f32x2 pv) const {
+        const float x = pv[0];
         float r;
-        if (div == DRNMF_DIV_ED) r = x - xh;
-        else if (div == DRNMF_DIV_KL) r = x / xh - 1.f;
+        if (DIV == DRNMF_DIV_ED) r = x - xh;
+        else if (DIV == DRNMF_DIV_KL) r = x / xh - 1.f;
         else r = x * powf(xh, beta - 2.f) - powf(xh, beta - 1.f);
         R[row * ldr + col] = r;
     }
@@ -53,9 +55,9 @@ struct EpiIstaUpdate {   // H <- max(0, -lam1/alph + H + (1/alph) G): enhance.py
     float* H;
     int N;
     float neg_lam_over_alph, inv_alph;
-    __device__ void operator()(int64_t row, int col, float gacc) const {
-        float* p = H + row * N + col;
-        *p = fmaxf(0.f, neg_lam_over_alph + *p + inv_alph * gacc);
+    __device__ f32x2 pre(int64_t row, int col) const { return f32x2{H[row * N + col], 0.f}; }
+    __device__ void operator()(int64_t row, int col, float gacc, f32x2 pv) const {
+        H[row * N + col] = fmaxf(0.f, neg_lam_over_alph + pv[0] + inv_alph * gacc);
     }
 };
 
@@ -63,42 +65,47 @@ struct EpiIstaUpdate {   // H <- max(0, -lam1/alph + H + (1/alph) G): enhance.py
 struct EpiStore {
     float* C;
     int ldc;
-    __device__ void operator()(int64_t row, int col, float v) const { C[row * ldc + col] = v; }
+    __device__ f32x2 pre(int64_t, int) const { return f32x2{0.f, 0.f}; }
+    __device__ void operator()(int64_t row, int col, float v, f32x2) const { C[row * ldc + col] = v; }
 };
 
+template <int BC>   // beta class: 2 -> beta == 2, 1 -> beta == 1, 0 -> general
 struct EpiLambda {   // lambda = max(W H, flr) and its beta-dependent derivatives
     const float* V;
     float* P1;   // beta==2: lambda;  beta==1: V/lambda;  else: lambda^(beta-1)
     float* P2;   // general beta only: V * lambda^(beta-2)
     int F, ld;
     float beta, flr;
-    __device__ void operator()(int64_t row, int col, float acc) const {
+    __device__ f32x2 pre(int64_t row, int col) const {
+        return f32x2{BC == 2 ? 0.f : V[row * F + col], 0.f};
+    }
+    __device__ void operator()(int64_t row, int col, float acc, f32x2 pv) const {
         const float lam = fmaxf(acc, flr);
         const size_t o = row * ld + col;
-        if (beta == 2.f) {
+        if (BC == 2) {
             P1[o] = lam;
-        } else if (beta == 1.f) {
-            P1[o] = V[row * F + col] / lam;
+        } else if (BC == 1) {
+            P1[o] = pv[0] / lam;
         } else {
             P1[o] = powf(lam, beta - 1.f);
-            P2[o] = V[row * F + col] * powf(lam, beta - 2.f);
+            P2[o] = pv[0] * powf(lam, beta - 2.f);
         }
     }
 };
 
+template <int BC>
 struct EpiMuUpdate {   // H <- H * dmh / max(dph + sparsity, flr): sparse_nmf_gpu.m:217-227
     float* H;
     const float* DMH;      // [n][N] (beta != 1)
     const float* colsum;   // [N]    (beta == 1: dph = sum_f w + sparsity, dmh = acc)
     int N;
-    float sparsity, flr, beta;
-    __device__ void operator()(int64_t row, int col, float acc) const {
-        float* p = H + row * N + col;
-        if (beta == 1.f) {
-            *p = *p * acc / fmaxf(colsum[col] + sparsity, flr);
-        } else {
-            *p = *p * DMH[row * N + col] / fmaxf(acc + sparsity, flr);
-        }
+    float sparsity, flr;
+    __device__ f32x2 pre(int64_t row, int col) const {
+        return f32x2{H[row * N + col], BC == 1 ? colsum[col] : DMH[row * N + col]};
+    }
+    __device__ void operator()(int64_t row, int col, float acc, f32x2 pv) const {
+        if (BC == 1) H[row * N + col] = pv[0] * acc / fmaxf(pv[1] + sparsity, flr);
+        else H[row * N + col] = pv[0] * pv[1] / fmaxf(acc + sparsity, flr);
     }
 };
 
@@ -224,10 +231,14 @@ extern "C" int32_t drnmf_ista_forward(drnmf_handle_t h, int64_t n, int32_t F, in
     if (Fp4 != F) DRNMF_HIP(h, hipMemsetAsync(R, 0, (size_t)n * Fp4 * 4, stream));
     gemm::Operands g1{H, W, n, F, N, N, N};          // X^ = H . W^T   (contract atoms)
     gemm::Operands g2{R, Wt, n, N, Fp4, Fp4, Fp4};   // G  = R . W     (contract bins)
-    EpiResidual e1{X, R, F, Fp4, divergence, beta};
     EpiIstaUpdate e2{H, N, -lam1 / alph, 1.f / alph};
     for (int k = 0; k < K; ++k) {
-        DRNMF_HIP(h, gemm::launch(g1, e1, stream));
+        if (divergence == DRNMF_DIV_ED)
+            DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_ED>{X, R, F, Fp4, beta}, stream));
+        else if (divergence == DRNMF_DIV_KL)
+            DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_KL>{X, R, F, Fp4, beta}, stream));
+        else
+            DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_BETA>{X, R, F, Fp4, beta}, stream));
         DRNMF_HIP(h, gemm::launch(g2, e2, stream));
     }
     return DRNMF_OK;
@@ -291,7 +302,11 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
         DRNMF_HIP(h, hipMemsetAsync(P2, 0, (size_t)n * Fp4 * 4, stream));
     }
     gemm::Operands gl{H, Wn, n, F, N, N, N};            // W H  (row layout: H . Wn^T)
-    EpiLambda el{Vuse, P1, P2, F, Fp4, beta, flr};
+    auto launch_lambda = [&]() -> hipError_t {
+        if (beta == 2.f) return gemm::launch(gl, EpiLambda<2>{Vuse, P1, P2, F, Fp4, beta, flr}, stream);
+        if (beta == 1.f) return gemm::launch(gl, EpiLambda<1>{Vuse, P1, P2, F, Fp4, beta, flr}, stream);
+        return gemm::launch(gl, EpiLambda<0>{Vuse, P1, P2, F, Fp4, beta, flr}, stream);
+    };
     if (beta == 2.f) {
         // dmh = W^T V is loop invariant: one GEMM V . W up front (V copied to a padded buffer so
         // the contraction over bins can use 16-byte loads)
@@ -300,15 +315,18 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
         gemm::Operands gd{P2, Wt, n, N, Fp4, Fp4, Fp4};
         DRNMF_HIP(h, gemm::launch(gd, EpiStore{DMH, N}, stream));
     }
-    DRNMF_HIP(h, gemm::launch(gl, el, stream));         // lambda before the loop (:173)
+    DRNMF_HIP(h, launch_lambda());                      // lambda before the loop (:173)
     for (int it = 0; it < n_iter; ++it) {
         if (beta != 2.f && beta != 1.f) {
             gemm::Operands gd{P2, Wt, n, N, Fp4, Fp4, Fp4};
             DRNMF_HIP(h, gemm::launch(gd, EpiStore{DMH, N}, stream));
         }
         gemm::Operands gu{P1, Wt, n, N, Fp4, Fp4, Fp4};
-        DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate{H, DMH, colsum, N, sparsity, flr, beta}, stream));
-        DRNMF_HIP(h, gemm::launch(gl, el, stream));     // lambda = max(w*h, flr)  (:228)
+        if (beta == 1.f)
+            DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<1>{H, DMH, colsum, N, sparsity, flr}, stream));
+        else
+            DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<2>{H, DMH, colsum, N, sparsity, flr}, stream));
+        DRNMF_HIP(h, launch_lambda());                  // lambda = max(w*h, flr)  (:228)
     }
     if (irm) {
         int rc = head_irm_forward(h, n, F, N / 2, H, N, Wn, irm, ecat, stream);

@@ -98,7 +98,8 @@ struct EpiStoreOff {
     float* C;
     int64_t ldc;
     int coloff;
-    __device__ void operator()(int64_t row, int col, float v) const {
+    __device__ f32x2 pre(int64_t, int) const { return f32x2{0.f, 0.f}; }
+    __device__ void operator()(int64_t row, int col, float v, f32x2) const {
         C[row * ldc + coloff + col] = v;
     }
 };
@@ -106,7 +107,8 @@ struct EpiPart {
     float* P;
     int ld;
     size_t stride;
-    __device__ void operator()(int split, int m, int n, float acc) const {
+    __device__ float pre(int, int, int) const { return 0.f; }
+    __device__ void operator()(int split, int m, int n, float acc, float) const {
         P[split * stride + (size_t)m * ld + n] = acc;
     }
 };
@@ -223,7 +225,7 @@ extern "C" int32_t drnmf_loss_head_backward(drnmf_handle_t h, int64_t rows, int3
         gemm::Operands g1{dX, Es, rows, r, Fp4, Fp4, Fp4};
         DRNMF_HIP(h, gemm::launch(g1, EpiStoreOff{d_hidden, N2, seg * r}, stream));
         // dE[n][f] = sum_rows hidden[row][seg*r + n] dX[row][f];  dK = dE * E
-        gemm_tn::Operands t1{hidden + h_off + (size_t)seg * r, dX, rows, r, F, ld_h, Fp4};
+        gemm_tn::Operands t1{hidden + h_off + (size_t)seg * r, dX, rows, r, Fp4, ld_h, Fp4};
         const size_t pstr = (size_t)r * Fp4;
         DRNMF_HIP(h, gemm_tn::launch(t1, EpiPart{P, Fp4, pstr}, HB_SPLITS, stream));
         const size_t tot = (size_t)r * F;
