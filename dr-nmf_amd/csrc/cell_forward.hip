@@ -53,7 +53,12 @@ struct CellAArgs {
     int* t_wr;               // counter to publish (or null)
     int t_wr_add;
     float u0d, u0o, uko;
-    int B, T, N, Bp, Fp, Np, numA, nchunks, KS;
+    const float* Dn_next;    // packed dictionary of layer k+1 (tail rows for the next x^ tail)
+    const float* q_in;       // [numA][MAX_TAIL][Bp] tail-bin x^ partials of the previous layer
+    float* q_out;            // same, produced for the next layer
+    float* xtail;            // [MAX_TAIL][Bp] tail bins of x_t (published by the first layer)
+    float* xcur;             // [Bp][Fp] packed x_t, republished by the first layer for cell_b
+    int B, T, N, Bp, Fp, Np, numA, nchunks, KS, ntail;
     int out_width, out_off, write_out;
 };
 
@@ -154,12 +159,45 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     }
     bool vld = true;
     if (WRITE_OUT) vld = a.valid[(size_t)t * a.Bp + rg] != 0;
+    // tail bins (F = 16*nchunks + ntail): residual r_tail = x_tail - sum over atom blocks of the
+    // partial dot products left by the previous layer; dictionary tail rows of this layer
+    float rt[MAX_TAIL] = {0.f, 0.f};
+    f32x2 dt[MAX_TAIL] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < MAX_TAIL; ++i) {
+        if (i >= a.ntail) continue;
+        const size_t toff = ((size_t)a.nchunks * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
+        dt[i] = *(const f32x2*)(a.Dn + toff);
+        float xt;
+        if (IS_FIRST) {
+            // packed input: bin 16*nchunks + i sits at tile nchunks, position perm(i) = 4*i
+            xt = rsrc[((size_t)m * nft + a.nchunks) * 256 + erow * 16 + 4 * i];
+            if (blockIdx.x == 0 && tid < 256 && (tid & 15) == 0) a.xtail[(size_t)i * a.Bp + rg] = xt;
+            rt[i] = xt;
+        } else {
+            xt = a.xtail[(size_t)i * a.Bp + rg];
+            const float* qp = a.q_in + (size_t)i * a.Bp + rg;
+            float sq = 0.f;
+            for (int b2 = (tid & 15); b2 < a.numA; b2 += 16) sq += qp[(size_t)b2 * MAX_TAIL * a.Bp];
+            sq += __shfl_xor(sq, 8, 16);
+            sq += __shfl_xor(sq, 4, 16);
+            sq += __shfl_xor(sq, 2, 16);
+            sq += __shfl_xor(sq, 1, 16);
+            rt[i] = xt - sq;
+        }
+    }
 
     // ---- GEMM:  g[16 x 32] = r[16 x F] . Dn[F x 32] -------------------------------------------
     auto compute_chunk = [&](int base, int g) {
         f32x4 r4 = av[g][0];
 #pragma unroll
         for (int ks = 1; ks < NP; ++ks) r4 += av[g][ks];
+        if (IS_FIRST && blockIdx.x == 0 && base + g < per_wave) {
+            // republish this row tile's x_t chunk at a frame-independent address (cell_b reads
+            // it without a dependent frame-index load)
+            const int c = w + NW_A * (base + g);
+            *(f32x4*)(a.xcur + (size_t)m * nft * 256 + 256 * c + j * 16 + q * 4) = r4;
+        }
         if (base + g >= per_wave) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -197,6 +235,12 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
         const f32x2 p2 = *(const f32x2*)(red + (ww * ROWS + erow) * ATOMS + ec);
         gsum[0] += p2[0];
         gsum[1] += p2[1];
+    }
+
+#pragma unroll
+    for (int i = 0; i < MAX_TAIL; ++i) {   // rank-1 update per tail bin (rt, dt are 0 beyond ntail)
+        gsum[0] = fmaf(rt[i], dt[i][0], gsum[0]);
+        gsum[1] = fmaf(rt[i], dt[i][1], gsum[1]);
     }
 
     // ---- fused update: soft-threshold / non-negativity projection --------------------------
@@ -239,6 +283,19 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
             a.rs_part[((size_t)((t + 1) & 1) * a.numA + ab) * a.Bp + rg] = s;
     } else {
         *(f32x2*)(a.h_out + hoff) = hn;
+        // tail bins of the next layer's x^: partial dot product over this block's 32 atoms
+#pragma unroll
+        for (int i = 0; i < MAX_TAIL; ++i) {
+            if (i >= a.ntail) continue;
+            const size_t toff = ((size_t)a.nchunks * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
+            const f32x2 dn = *(const f32x2*)(a.Dn_next + toff);
+            float sq = hn[0] * dn[0] + hn[1] * dn[1];
+            sq += __shfl_xor(sq, 8, 16);
+            sq += __shfl_xor(sq, 4, 16);
+            sq += __shfl_xor(sq, 2, 16);
+            sq += __shfl_xor(sq, 1, 16);
+            if ((tid & 15) == 0) a.q_out[((size_t)ab * MAX_TAIL + i) * a.Bp + rg] = sq;
+        }
     }
 }
 
@@ -423,7 +480,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     const bool use_graph = (getenv("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0) ||
                            out_exec != nullptr;
 
-    const int numM = W.Bp / ROWS, nft = W.Fp / 16;
+    const int numM = W.Bp / ROWS, nft = W.nft_main;   // MFMA bin tiles (tail bins handled apart)
     const dim3 grid_a((unsigned)round_up(W.numA, 8), (unsigned)numM);
     const dim3 grid_b((unsigned)round_up(nft * W.KS, 8), (unsigned)numM);
     const float* Dn_base = (const float*)(pb + L.off_dn);
@@ -453,7 +510,14 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         else { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
         a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
         a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
-        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS;
+        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS; a.ntail = W.ntail;
+        a.Dn_next = Dn_of(k + 1 < K ? k + 1 : k);
+        float* qp = (float*)(ws + W.off_qpart);
+        const size_t qstride = (size_t)W.numA * MAX_TAIL * W.Bp;
+        a.q_in = qp + (size_t)((k + 1) & 1) * qstride;    // written by layer k-1
+        a.q_out = qp + (size_t)(k & 1) * qstride;
+        a.xtail = (float*)(ws + W.off_xtail);
+        a.xcur = (float*)(ws + W.off_xcur);
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
         a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
@@ -463,7 +527,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         CellBArgs b;
         b.Dn_next = Dn_of(k + 1);
         b.h = hb[k & 1];
-        b.xp = xp;
+        b.xp = (const float*)(ws + W.off_xcur);
         b.rpart = rpart;
         b.t_rd = tA;
         b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS;

@@ -9,13 +9,15 @@ namespace {
 constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
 constexpr int ATOMS = 32;   // atoms per cell_a workgroup
 constexpr int MAX_KS = 8;
+constexpr int MAX_TAIL = 2;   // STFT sizes are 2^k + 1: the odd bin(s) must not cost a whole 16-bin tile
 constexpr int NW_B = 8;    // waves per cell_b workgroup (more requests in flight per CU)
 constexpr int NW_A = 4;    // waves per cell_a workgroup (8 measured slower: 224k vs 232k frames/s)
 
 struct CellBArgs {
     const float* Dn_next;    // [Fp][Np]  next layer's dictionary
     const float* h;          // [Bp][Np]  this layer's h
-    const float* xp;         // [T][Bp][Fp]; NULL: plain product, rpart[ks] = +acc (backward)
+    const float* xp;         // [Bp][Fp] packed x of the CURRENT frame (republished by layer 0's cell_a,
+                             // so this kernel needs no frame index); NULL: rpart[ks] = +acc (backward)
     float* rpart;            // [KS][Bp][Fp]
     const int* t_rd;
     int Bp, Fp, Np, nft, KS, logKS, nch_ks;   // nch_ks = 16-atom chunks per atom range
@@ -66,12 +68,10 @@ __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
 
     // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
     const int erow = (tid & 255) >> 4, ecol = tid & 15;
-    const size_t eoff = ((size_t)m * a.nft + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
+    // (buffers keep Fp/16 tiles per row tile even when only a.nft of them are MFMA tiles)
+    const size_t eoff = ((size_t)m * (Fp / 16) + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
     float xv = 0.f;
-    if (a.xp != nullptr && ks == 0) {
-        const int t = *a.t_rd;
-        xv = a.xp[(size_t)t * a.Bp * Fp + eoff];
-    }
+    if (a.xp != nullptr && ks == 0) xv = a.xp[eoff];
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     auto compute_chunk = [&](int base, int g) {
@@ -114,6 +114,8 @@ struct Workspace {
     size_t off_xp, off_valid, off_seen, off_psum_all, off_rpart, off_h0, off_h1, off_state, off_rs,
         off_psum, off_t, total;
     int Bp, Fp, Np, numA, KS, nch_ks;
+    int nft_main, ntail;   // forward: bins 16*nft_main .. F-1 (at most MAX_TAIL) are handled outside the MFMA tiles
+    size_t off_qpart, off_xtail, off_xcur;
 };
 
 Workspace workspace_layout(const drnmf_cell_desc_t* d) {
@@ -123,7 +125,9 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.Np = pad_n(d->N);
     W.numA = W.Np / ATOMS;
     // atom ranges per (row tile, bin tile) in cell_b: enough workgroups to cover the 256 CUs
-    const int tiles = (W.Bp / ROWS) * (W.Fp / 16);
+    W.ntail = (d->F % 16 != 0 && d->F % 16 <= MAX_TAIL && d->F > 16) ? d->F % 16 : 0;
+    W.nft_main = W.ntail ? d->F / 16 : W.Fp / 16;
+    const int tiles = (W.Bp / ROWS) * W.nft_main;
     const int nchN = W.Np / 16;
     int KS = 1;
     while (KS < MAX_KS && tiles * KS < 224 && nchN / (KS * 2) >= 4) KS *= 2;
@@ -141,6 +145,9 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_state = take((size_t)W.Bp * W.Np * 4);
     W.off_rs = take((size_t)2 * W.numA * W.Bp * 4);
     W.off_psum = take((size_t)W.Bp * 4);
+    W.off_qpart = take((size_t)2 * W.numA * MAX_TAIL * W.Bp * 4);
+    W.off_xtail = take((size_t)MAX_TAIL * W.Bp * 4);
+    W.off_xcur = take((size_t)W.Bp * W.Fp * 4);
     W.off_t = take(256);
     W.total = o;
     return W;
