@@ -54,6 +54,10 @@ SIGNATURES = {
     "drnmf_mu_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "drnmf_mu_forward": (_i32, [_vp, _i64, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _sz, _vp]),
+    "drnmf_snmf_train_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "drnmf_snmf_train_init": (_i32, [_vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "drnmf_snmf_train_step": (_i32, [_vp, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _i32, _vp,
+                                     _vp, _sz, _vp]),
     "drnmf_stft_frames": (_i32, [_i64, _i32, _i32]),
     "drnmf_stft_mag": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
 }

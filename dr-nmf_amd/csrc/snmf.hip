@@ -6,6 +6,7 @@
 //     G  = R W        -> H <- max(0, H + (G - lam1)/alph)   or    H <- H * DMH / max(G + sp, flr)
 // Row layout: frames are rows (X, V: [n][F]; H: [n][N]); W is [F][N] as in the reference.
 #include "gemm_nt.h"
+#include "gemm_tn.h"
 
 namespace {
 
@@ -74,6 +75,7 @@ struct EpiLambda {   // lambda = max(W H, flr) and its beta-dependent derivative
     const float* V;
     float* P1;   // beta==2: lambda;  beta==1: V/lambda;  else: lambda^(beta-1)
     float* P2;   // general beta only: V * lambda^(beta-2)
+    float* LAM;  // optional: lambda itself (dictionary training: objective)
     int F, ld;
     float beta, flr;
     __device__ f32x2 pre(int64_t row, int col) const {
@@ -82,6 +84,7 @@ struct EpiLambda {   // lambda = max(W H, flr) and its beta-dependent derivative
     __device__ void operator()(int64_t row, int col, float acc, f32x2 pv) const {
         const float lam = fmaxf(acc, flr);
         const size_t o = row * ld + col;
+        if (LAM) LAM[o] = lam;
         if (BC == 2) {
             P1[o] = lam;
         } else if (BC == 1) {
@@ -303,9 +306,9 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
     }
     gemm::Operands gl{H, Wn, n, F, N, N, N};            // W H  (row layout: H . Wn^T)
     auto launch_lambda = [&]() -> hipError_t {
-        if (beta == 2.f) return gemm::launch(gl, EpiLambda<2>{Vuse, P1, P2, F, Fp4, beta, flr}, stream);
-        if (beta == 1.f) return gemm::launch(gl, EpiLambda<1>{Vuse, P1, P2, F, Fp4, beta, flr}, stream);
-        return gemm::launch(gl, EpiLambda<0>{Vuse, P1, P2, F, Fp4, beta, flr}, stream);
+        if (beta == 2.f) return gemm::launch(gl, EpiLambda<2>{Vuse, P1, P2, nullptr, F, Fp4, beta, flr}, stream);
+        if (beta == 1.f) return gemm::launch(gl, EpiLambda<1>{Vuse, P1, P2, nullptr, F, Fp4, beta, flr}, stream);
+        return gemm::launch(gl, EpiLambda<0>{Vuse, P1, P2, nullptr, F, Fp4, beta, flr}, stream);
     };
     if (beta == 2.f) {
         // dmh = W^T V is loop invariant: one GEMM V . W up front (V copied to a padded buffer so
@@ -332,5 +335,308 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
         int rc = head_irm_forward(h, n, F, N / 2, H, N, Wn, irm, ecat, stream);
         if (rc) return rc;
     }
+    return DRNMF_OK;
+}
+
+
+// =====================================================================================================
+// Dictionary training: multiplicative W and H updates in the column-normalised basis
+// (sparseNMF/sparse_nmf_gpu.m:156-298; driven by snmf.py:9-113 and enhance.py:81-135).
+// One iteration = H update, lambda, W update (masked columns) + renormalisation, lambda, objective.
+// Frame contractions (V^T H, lambda^T H) are split-K TN GEMMs; everything elementwise rides in
+// GEMM epilogues or thread-per-column kernels.  Row layout as above (frames are rows).
+// =====================================================================================================
+namespace {
+
+constexpr int TR_SPLITS = 8;
+
+struct EpiPartTN {
+    float* P;
+    int ld;
+    size_t stride;
+    __device__ float pre(int, int, int) const { return 0.f; }
+    __device__ void operator()(int split, int m, int n, float acc, float) const {
+        P[split * stride + (size_t)m * ld + n] = acc;
+    }
+};
+
+// column sums over frames of H: hs[n] (beta == 1 W update)
+__global__ void __launch_bounds__(256)
+colsum_rows_kernel(const float* __restrict__ H, float* __restrict__ part, int64_t n, int N,
+                   int splits) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    const int64_t per = (n + splits - 1) / splits;
+    const int64_t r0 = blockIdx.y * per;
+    int64_t r1 = r0 + per;
+    if (r1 > n) r1 = n;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += H[r * N + col];
+    part[(size_t)blockIdx.y * N + col] = s;
+}
+
+// W update of one column (sparse_nmf_gpu.m:232-262) + L2 renormalisation of every column:
+//   dpw = DEN + W * sum_f(NUM * W);  dmw = NUM + W * sum_f(DEN * W);  W <- W * dmw / max(dpw, flr)
+// NUM/DEN are sums of TR_SPLITS partial [Fp4][N] buffers; for beta == 1, DEN[f][n] = hs[n].
+__global__ void __launch_bounds__(256)
+w_update_kernel(float* __restrict__ W, const float* __restrict__ PN, const float* __restrict__ PD,
+                const float* __restrict__ hs_part, const unsigned char* __restrict__ upd, int F,
+                int N, size_t stride, int hs_splits, int beta_is_one, float flr) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const bool do_upd = upd ? upd[n] != 0 : true;
+    if (do_upd) {
+        float hs = 0.f;
+        if (beta_is_one)
+            for (int s = 0; s < hs_splits; ++s) hs += hs_part[(size_t)s * N + n];
+        float sn = 0.f, sd = 0.f;
+        for (int f = 0; f < F; ++f) {
+            float num = 0.f, den = hs;
+            for (int s = 0; s < TR_SPLITS; ++s) num += PN[s * stride + (size_t)f * N + n];
+            if (!beta_is_one) {
+                den = 0.f;
+                for (int s = 0; s < TR_SPLITS; ++s) den += PD[s * stride + (size_t)f * N + n];
+            }
+            const float w = W[(size_t)f * N + n];
+            sn = fmaf(num, w, sn);
+            sd = fmaf(den, w, sd);
+        }
+        for (int f = 0; f < F; ++f) {
+            float num = 0.f, den = hs;
+            for (int s = 0; s < TR_SPLITS; ++s) num += PN[s * stride + (size_t)f * N + n];
+            if (!beta_is_one) {
+                den = 0.f;
+                for (int s = 0; s < TR_SPLITS; ++s) den += PD[s * stride + (size_t)f * N + n];
+            }
+            const float w = W[(size_t)f * N + n];
+            const float dpw = fmaxf(den + w * sn, flr);
+            const float dmw = num + w * sd;
+            W[(size_t)f * N + n] = w * dmw / dpw;
+        }
+    }
+    float s2 = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float w = W[(size_t)f * N + n];
+        s2 = fmaf(w, w, s2);
+    }
+    const float inv = 1.f / sqrtf(s2);
+    for (int f = 0; f < F; ++f) W[(size_t)f * N + n] *= inv;
+}
+
+// objective partials: div (beta-divergence between V and lambda) and sum(H)
+__global__ void __launch_bounds__(256)
+objective_kernel(const float* __restrict__ Vp, const float* __restrict__ LAM,
+                 const float* __restrict__ H, int64_t n, int F, int Fp4, int N, float beta,
+                 float* __restrict__ part) {
+    __shared__ double sd[256], sh[256];
+    double d = 0.0, hsum = 0.0;
+    const int64_t totV = n * (int64_t)Fp4, totH = n * (int64_t)N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < totV; i += (int64_t)gridDim.x * 256) {
+        if ((int)(i % Fp4) >= F) continue;
+        const float v = Vp[i], l = LAM[i];
+        float e;
+        if (beta == 2.f) e = (v - l) * (v - l);
+        else if (beta == 1.f) e = v * logf(v / l) - v + l;
+        else if (beta == 0.f) e = v / l - logf(v / l) - 1.f;
+        else e = (powf(v, beta) + (beta - 1.f) * powf(l, beta) - beta * v * powf(l, beta - 1.f)) /
+                 (beta * (beta - 1.f));
+        d += (double)e;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < totH; i += (int64_t)gridDim.x * 256)
+        hsum += (double)H[i];
+    sd[threadIdx.x] = d;
+    sh[threadIdx.x] = hsum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sd[threadIdx.x] += sd[threadIdx.x + o];
+            sh[threadIdx.x] += sh[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (float)sd[0];
+        part[2 * blockIdx.x + 1] = (float)sh[0];
+    }
+}
+__global__ void __launch_bounds__(256)
+objective_final_kernel(const float* __restrict__ part, int nblocks, float sparsity,
+                       float* __restrict__ obj) {
+    __shared__ double sd[256], sh[256];
+    double d = 0.0, hs = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        d += (double)part[2 * i];
+        hs += (double)part[2 * i + 1];
+    }
+    sd[threadIdx.x] = d;
+    sh[threadIdx.x] = hs;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sd[threadIdx.x] += sd[threadIdx.x + o];
+            sh[threadIdx.x] += sh[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        obj[0] = (float)sd[0];
+        obj[1] = (float)(sd[0] + (double)sparsity * sh[0]);
+    }
+}
+
+constexpr int OBJ_BLOCKS = 1024, HS_SPLITS = 64;
+
+struct TrWs {
+    size_t off_P1, off_P2, off_LAM, off_Vp, off_Wt, off_DMH, off_norm, off_colsum, off_PN, off_PD,
+        off_hs, off_obj, off_min, total;
+    int Fp4;
+};
+TrWs tr_ws(int64_t n, int F, int N) {
+    TrWs w;
+    w.Fp4 = pad4(F);
+    size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += round_up_sz(b, 256); return at; };
+    const size_t nf = (size_t)n * w.Fp4 * 4;
+    w.off_P1 = take(nf); w.off_P2 = take(nf); w.off_LAM = take(nf); w.off_Vp = take(nf);
+    w.off_Wt = take((size_t)N * w.Fp4 * 4);
+    w.off_DMH = take((size_t)n * N * 4);
+    w.off_norm = take((size_t)N * 4);
+    w.off_colsum = take((size_t)N * 4);
+    w.off_PN = take((size_t)TR_SPLITS * w.Fp4 * N * 4);
+    w.off_PD = take((size_t)TR_SPLITS * w.Fp4 * N * 4);
+    w.off_hs = take((size_t)HS_SPLITS * N * 4);
+    w.off_obj = take((size_t)OBJ_BLOCKS * 2 * 4);
+    w.off_min = take(256);
+    w.total = o;
+    return w;
+}
+
+template <int BC>
+hipError_t launch_lambda_train(const gemm::Operands& gl, const float* Vp, float* P1, float* P2,
+                               float* LAM, int Fp4, float beta, float flr, hipStream_t stream) {
+    // V is read from the padded copy (ld = Fp4)
+    return gemm::launch(gl, EpiLambda<BC>{Vp, P1, P2, LAM, Fp4, Fp4, beta, flr}, stream);
+}
+hipError_t lambda_train(const gemm::Operands& gl, const float* Vp, float* P1, float* P2, float* LAM,
+                        int Fp4, float beta, float flr, hipStream_t stream) {
+    if (beta == 2.f) return launch_lambda_train<2>(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream);
+    if (beta == 1.f) return launch_lambda_train<1>(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream);
+    return launch_lambda_train<0>(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream);
+}
+
+}  // namespace
+
+extern "C" size_t drnmf_snmf_train_workspace_bytes(int64_t n, int32_t F, int32_t N) {
+    if (n <= 0 || F <= 0 || N <= 0) return 0;
+    return tr_ws(n, F, N).total;
+}
+
+extern "C" int32_t drnmf_snmf_train_init(drnmf_handle_t h, int64_t n, int32_t F, int32_t N, float beta,
+                                         const float* V, float* W, float* H, void* workspace,
+                                         size_t workspace_bytes, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n <= 0 || F <= 0 || N <= 0 || !V || !W || !H || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "snmf_train_init: bad argument");
+    const TrWs L = tr_ws(n, F, N);
+    if (workspace_bytes < L.total)
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "snmf_train_init: workspace %zu < required %zu",
+                   workspace_bytes, L.total);
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float* P1 = (float*)(ws + L.off_P1); float* P2 = (float*)(ws + L.off_P2);
+    float* LAM = (float*)(ws + L.off_LAM); float* Vp = (float*)(ws + L.off_Vp);
+    float* Wt = (float*)(ws + L.off_Wt);
+    float* norm = (float*)(ws + L.off_norm); float* colsum = (float*)(ws + L.off_colsum);
+    unsigned* minb = (unsigned*)(ws + L.off_min);
+    const int Fp4 = L.Fp4;
+    const float flr = 1e-9f;
+    const int64_t nH = n * (int64_t)N, nV = n * (int64_t)F;
+    DRNMF_HIP(h, hipMemsetAsync(ws, 0, L.off_Wt, stream));   // P1, P2, LAM, Vp (zero padding)
+    const float* Vsrc = V;
+    if (beta != 2.f) {   // zeros of V are raised to its smallest positive entry (:201-205)
+        DRNMF_HIP(h, hipMemsetAsync(minb, 0x7f, 4, stream));
+        hipLaunchKernelGGL(min_positive_kernel, dim3(1024), dim3(256), 0, stream, V, nV, minb);
+        hipLaunchKernelGGL(floor_zeros_kernel, dim3((unsigned)((nV + 255) / 256)), dim3(256), 0,
+                           stream, V, P1, nV, minb);   // P1 as scratch [n][F]
+        Vsrc = P1;
+    }
+    DRNMF_HIP(h, hipMemcpy2DAsync(Vp, (size_t)Fp4 * 4, Vsrc, (size_t)F * 4, (size_t)F * 4, (size_t)n,
+                                  hipMemcpyDeviceToDevice, stream));
+    if (beta != 2.f) DRNMF_HIP(h, hipMemsetAsync(P1, 0, (size_t)n * Fp4 * 4, stream));
+    // normalise W in place, rescale H (:163-166)
+    hipLaunchKernelGGL(mu_colnorm_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, W, W, norm,
+                       colsum, F, N);
+    hipLaunchKernelGGL(mu_scale_h_kernel, dim3((unsigned)((nH + 255) / 256)), dim3(256), 0, stream,
+                       H, norm, nH, N);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Fp4 + 31) / 32, (N + 31) / 32), dim3(256), 0,
+                       stream, W, Wt, F, N, Fp4);
+    gemm::Operands gl{H, W, n, F, N, N, N};
+    DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream));   // (:173)
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F, int32_t N, float beta,
+                                         float sparsity, float* W, float* H,
+                                         const unsigned char* w_update_mask, int32_t update_w,
+                                         float* obj, void* workspace, size_t workspace_bytes,
+                                         void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n <= 0 || F <= 0 || N <= 0 || !W || !H || !obj || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "snmf_train_step: bad argument");
+    const TrWs L = tr_ws(n, F, N);
+    if (workspace_bytes < L.total)
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "snmf_train_step: workspace %zu < required %zu",
+                   workspace_bytes, L.total);
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float* P1 = (float*)(ws + L.off_P1); float* P2 = (float*)(ws + L.off_P2);
+    float* LAM = (float*)(ws + L.off_LAM); float* Vp = (float*)(ws + L.off_Vp);
+    float* Wt = (float*)(ws + L.off_Wt); float* DMH = (float*)(ws + L.off_DMH);
+    float* colsum = (float*)(ws + L.off_colsum);
+    float* PN = (float*)(ws + L.off_PN); float* PD = (float*)(ws + L.off_PD);
+    float* hs = (float*)(ws + L.off_hs); float* objp = (float*)(ws + L.off_obj);
+    const int Fp4 = L.Fp4;
+    const float flr = 1e-9f;
+    gemm::Operands gl{H, W, n, F, N, N, N};
+    // ---- H update (:210-229) -------------------------------------------------------------------
+    if (beta == 1.f) {
+        // dph = sum_f w + sparsity needs the column sums of the CURRENT W
+        hipLaunchKernelGGL(colsum_rows_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, stream, W,
+                           colsum, (int64_t)F, N, 1);
+        gemm::Operands gu{P1, Wt, n, N, Fp4, Fp4, Fp4};
+        DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<1>{H, DMH, colsum, N, sparsity, flr}, stream));
+    } else {
+        gemm::Operands gd{beta == 2.f ? Vp : P2, Wt, n, N, Fp4, Fp4, Fp4};
+        DRNMF_HIP(h, gemm::launch(gd, EpiStore{DMH, N}, stream));
+        gemm::Operands gu{P1, Wt, n, N, Fp4, Fp4, Fp4};
+        DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<2>{H, DMH, colsum, N, sparsity, flr}, stream));
+    }
+    DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream));   // (:228)
+    // ---- W update (:232-264) -------------------------------------------------------------------
+    if (update_w) {
+        const size_t pstr = (size_t)Fp4 * N;
+        const float* num_src = beta == 2.f ? Vp : (beta == 1.f ? P1 : P2);
+        gemm_tn::Operands tn{num_src, H, n, Fp4, N, Fp4, N};
+        DRNMF_HIP(h, gemm_tn::launch(tn, EpiPartTN{PN, N, pstr}, TR_SPLITS, stream));
+        if (beta == 1.f) {
+            hipLaunchKernelGGL(colsum_rows_kernel, dim3((N + 255) / 256, HS_SPLITS), dim3(256), 0,
+                               stream, H, hs, n, N, HS_SPLITS);
+        } else {
+            gemm_tn::Operands td{P1, H, n, Fp4, N, Fp4, N};
+            DRNMF_HIP(h, gemm_tn::launch(td, EpiPartTN{PD, N, pstr}, TR_SPLITS, stream));
+        }
+        hipLaunchKernelGGL(w_update_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, W, PN, PD, hs,
+                           w_update_mask, F, N, pstr, HS_SPLITS, beta == 1.f ? 1 : 0, flr);
+        hipLaunchKernelGGL(transpose_pad_kernel, dim3((Fp4 + 31) / 32, (N + 31) / 32), dim3(256), 0,
+                           stream, W, Wt, F, N, Fp4);
+        DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream));   // (:263)
+    }
+    // ---- objective (:267-281) ------------------------------------------------------------------
+    hipLaunchKernelGGL(objective_kernel, dim3(OBJ_BLOCKS), dim3(256), 0, stream, Vp, LAM, H, n, F,
+                       Fp4, N, beta, objp);
+    hipLaunchKernelGGL(objective_final_kernel, dim3(1), dim3(256), 0, stream, objp, OBJ_BLOCKS,
+                       sparsity, obj);
+    DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }

@@ -308,3 +308,40 @@ def stft_mag(pcm, N=1024, hop=None):
                           _capi.ptr(pcm), _capi.ptr(mag), _stream())
     _capi.check(rc, h, "drnmf_stft_mag")
     return mag
+
+
+class SnmfTrainer(object):
+    """Device state of one sparse-NMF training problem (one chunk of frames): V [n,F] rows,
+    W [F,N], H [n,N].  `step()` runs one iteration of sparse_nmf_gpu.m:210-281 and returns a device
+    tensor obj = [div, cost]."""
+
+    def __init__(self, V, W, H, beta=2.0):
+        self.L = _capi.lib()
+        self.h = _capi.handle(_dev_index(V))
+        self.V, self.W, self.H = _f32c(V, "V"), _f32c(W, "W").clone(), _f32c(H, "H").clone()
+        self.n, self.F = self.V.shape
+        self.N = self.W.shape[1]
+        if self.W.shape[0] != self.F or tuple(self.H.shape) != (self.n, self.N):
+            raise ValueError("shape mismatch: V %s W %s H %s" % (tuple(V.shape), tuple(W.shape),
+                                                                  tuple(H.shape)))
+        self.beta = float(beta)
+        self.nbytes = self.L.drnmf_snmf_train_workspace_bytes(self.n, self.F, self.N)
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=V.device)
+        rc = self.L.drnmf_snmf_train_init(self.h, self.n, self.F, self.N, self.beta,
+                                          _capi.ptr(self.V), _capi.ptr(self.W), _capi.ptr(self.H),
+                                          _capi.ptr(self.ws), self.nbytes, _stream())
+        _capi.check(rc, self.h, "drnmf_snmf_train_init")
+
+    def step(self, sparsity, w_update_mask=None, update_w=True):
+        obj = torch.empty(2, dtype=torch.float32, device=self.V.device)
+        m = None
+        if w_update_mask is not None:
+            m = w_update_mask.to(device=self.V.device, dtype=torch.uint8).contiguous()
+            if m.numel() != self.N:
+                raise ValueError("w_update_mask must have N entries")
+        rc = self.L.drnmf_snmf_train_step(self.h, self.n, self.F, self.N, self.beta,
+                                          float(sparsity), _capi.ptr(self.W), _capi.ptr(self.H),
+                                          _capi.ptr(m), int(bool(update_w)), _capi.ptr(obj),
+                                          _capi.ptr(self.ws), self.nbytes, _stream())
+        _capi.check(rc, self.h, "drnmf_snmf_train_step")
+        return obj

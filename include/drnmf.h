@@ -180,6 +180,22 @@ int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int32_t N, int3
                          float* H, float* irm, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* ---- sparse-NMF dictionary training: replaces the Matlab process behind sparse_nmf_matlab for
+ * the training calls (snmf.py:9-113; enhance.py:81-135): sparse_nmf_gpu.m:156-298 -- H update,
+ * W update of the columns flagged in w_update_mask (NULL = all) with L2 renormalisation, objective.
+ * Row layout: V [n][F], W [F][N] (in/out), H [n][N] (in/out; the caller supplies the random inits).
+ * `init` normalises W / rescales H and computes lambda; each `step` is ONE iteration and writes
+ * obj[0] = divergence, obj[1] = cost (device); the convergence test (sparse_nmf_gpu.m:287-296) is
+ * the host's.  The workspace carries state between init and the steps. */
+size_t drnmf_snmf_train_workspace_bytes(int64_t n, int32_t F, int32_t N);
+int32_t drnmf_snmf_train_init(drnmf_handle_t h, int64_t n, int32_t F, int32_t N, float beta,
+                              const float* V, float* W, float* H, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F, int32_t N, float beta,
+                              float sparsity, float* W, float* H,
+                              const unsigned char* w_update_mask, int32_t update_w, float* obj,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- STFT magnitude front end: replaces wavread scaling (util.py:29-35), stft_mc
  * (util.py:171-201, librosa stft(center=False)), the sqrt-Hann window
  * (audio_dataset.py:194) and the 'mag' transform (audio_dataset.py:22-23).

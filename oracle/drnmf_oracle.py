@@ -493,3 +493,78 @@ def synth_problem(B, T, F, r, seed=7654, ragged=False, mask_value=-1.0, density=
             Y[b, lengths[b]:] = mask_value
     log_h0 = rng.uniform(-0.05, 0.05, N).astype(np.float32)
     return dict(W=W, X=X, Y=Y, lengths=lengths, log_h0=log_h0)
+
+
+# --------------------------------------------------------------------------------------------
+# sparse-NMF dictionary training: sparseNMF/sparse_nmf_gpu.m:156-298 (W and H updates, column
+# renormalisation, objective, convergence test); two-stage clean -> noisy training enhance.py:81-135
+# --------------------------------------------------------------------------------------------
+def sparse_nmf_train(V, W0, H0, sparsity, max_iter, conv_eps=0.0, beta=2.0, w_update_ind=None,
+                     flr=1e-9):
+    """V:(F,n), W0:(F,r), H0:(r,n) (explicit inits: Matlab's rand('seed') is not reproducible).
+    Returns W, H, dict(div=[...], cost=[...]) exactly as the Matlab loop orders its updates."""
+    V = np.array(V, copy=True)
+    W = np.array(W0, dtype=V.dtype, copy=True)
+    H = np.array(H0, dtype=V.dtype, copy=True)
+    r = W.shape[1]
+    w_ind = np.ones(r, bool) if w_update_ind is None else np.asarray(w_update_ind, bool)
+    wn = np.sqrt(np.sum(W * W, axis=0))
+    W = W / wn
+    H = H * wn[:, None]                                                   # :163-166
+    lam = np.maximum(W @ H, flr)
+    if beta != 2:
+        V[V == 0] = V[V > 0].min()                                         # :201-205
+    last_cost = np.inf
+    divs, costs = [], []
+    for it in range(int(max_iter)):
+        # H update (:210-229)
+        if beta == 1:
+            dph = np.maximum(W.sum(0)[:, None] + sparsity, flr)
+            dmh = W.T @ (V / lam)
+        elif beta == 2:
+            dph = np.maximum(W.T @ lam + sparsity, flr)
+            dmh = W.T @ V
+        else:
+            dph = np.maximum(W.T @ lam ** (beta - 1) + sparsity, flr)
+            dmh = W.T @ (V * lam ** (beta - 2))
+        H = H * dmh / dph
+        lam = np.maximum(W @ H, flr)
+        # W update (:232-264)
+        if w_ind.any():
+            Hw, Ww = H[w_ind], W[:, w_ind]
+            if beta == 1:
+                num = (V / lam) @ Hw.T
+                hs = Hw.sum(1)[None, :]
+                dpw = hs + np.sum(num * Ww, 0, keepdims=True) * Ww
+                dmw = num + np.sum(hs * Ww, 0, keepdims=True) * Ww
+            elif beta == 2:
+                num, den = V @ Hw.T, lam @ Hw.T
+                dpw = den + np.sum(num * Ww, 0, keepdims=True) * Ww
+                dmw = num + np.sum(den * Ww, 0, keepdims=True) * Ww
+            else:
+                num = (V * lam ** (beta - 2)) @ Hw.T
+                den = lam ** (beta - 1) @ Hw.T
+                dpw = den + np.sum(num * Ww, 0, keepdims=True) * Ww
+                dmw = num + np.sum(den * Ww, 0, keepdims=True) * Ww
+            dpw = np.maximum(dpw, flr)
+            W[:, w_ind] = Ww * dmw / dpw
+            W = W / np.sqrt(np.sum(W * W, axis=0))                         # :262
+            lam = np.maximum(W @ H, flr)
+        # objective (:267-281)
+        if beta == 1:
+            div = np.sum(V * np.log(V / lam) - V + lam)
+        elif beta == 2:
+            div = np.sum((V - lam) ** 2)
+        elif beta == 0:
+            div = np.sum(V / lam - np.log(V / lam) - 1)
+        else:
+            div = np.sum(V ** beta + (beta - 1) * lam ** beta - beta * V * lam ** (beta - 1)) \
+                / (beta * (beta - 1))
+        cost = div + np.sum(sparsity * H)
+        divs.append(div)
+        costs.append(cost)
+        if it > 0 and conv_eps > 0:                                         # :287-296
+            if abs(cost - last_cost) / last_cost < conv_eps:
+                break
+        last_cost = cost
+    return W, H, dict(div=np.array(divs), cost=np.array(costs))

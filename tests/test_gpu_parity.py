@@ -314,3 +314,59 @@ def test_stft_mag_vs_oracle(dev, N, hop, nsampl, int16):
         err = np.max(np.abs(got[s] - ref)) / np.max(np.abs(ref))
         assert err <= 2e-5, "N=%d rel err %.3e" % (N, err)
     assert np.all(got[:, 0, :] == 0)                   # the all-zero leading frame
+
+
+# ------------------------------------------------------------------ sparse-NMF dictionary training
+@pytest.mark.parametrize("beta,cf", [(2.0, "ed"), (1.0, "kl"), (1.5, None)])
+def test_snmf_training_matches_oracle(dev, beta, cf):
+    """W/H multiplicative updates + renormalisation + objective vs the numpy restatement of
+    sparse_nmf_gpu.m (same explicit inits), incl. a frozen half of the dictionary."""
+    from drnmf_amd import ops
+    rng = np.random.default_rng(8)
+    F, r, n, iters = 65, 12, 300, 25
+    Wt = rng.random((F, r))
+    V = (Wt @ (rng.random((r, n)) * (rng.random((r, n)) < 0.4)) + 1e-3).astype(np.float32)
+    if beta != 2.0:
+        V[rng.random(V.shape) < 0.01] = 0.0
+    W0 = rng.random((F, r)).astype(np.float32) * 2
+    H0 = rng.random((r, n)).astype(np.float32)
+    w_ind = np.array([False] * 5 + [True] * 7)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    tr = ops.SnmfTrainer(t(V.T), t(W0), t(H0.T), beta=beta)
+    mask = torch.from_numpy(w_ind.astype(np.uint8)).to(dev)
+    objs = [tr.step(0.1, mask, True).cpu().numpy() for _ in range(iters)]
+    Wr, Hr, oref = O.sparse_nmf_train(V.astype(np.float64), W0.astype(np.float64),
+                                      H0.astype(np.float64), 0.1, iters, 0.0, beta, w_ind)
+    W, H = tr.W.cpu().numpy(), tr.H.cpu().numpy().T
+    assert np.max(np.abs(W - Wr)) / np.max(np.abs(Wr)) <= 5e-4
+    assert np.max(np.abs(H - Hr)) / np.max(np.abs(Hr)) <= 5e-4
+    np.testing.assert_allclose(np.array(objs)[:, 1], oref["cost"], rtol=2e-4)
+    np.testing.assert_allclose(np.array(objs)[:, 0], oref["div"], rtol=2e-4)
+    np.testing.assert_allclose((W * W).sum(0), 1.0, rtol=1e-5)
+    # frozen columns only get renormalised (they were unit-norm after init): unchanged direction
+    W0n = W0 / np.sqrt((W0 * W0).sum(0))
+    np.testing.assert_allclose(W[:, :5], W0n[:, :5], rtol=1e-5)
+    assert np.all(np.diff(np.array(objs)[:, 1]) <= 1e-4 * np.array(objs)[:-1, 1])
+
+
+def test_sparse_nmf_host_api_chunks_and_two_stage(dev):
+    """sparse_nmf / train_snmf mirror snmf.sparse_nmf_matlab / enhance.train_snmf: chunking,
+    convergence stop, two-stage training with the speech half frozen."""
+    from drnmf_amd import snmf
+    rng = np.random.default_rng(9)
+    F, r, n = 33, 6, 500
+    clean = (rng.random((F, r)) @ (rng.random((r, n)) * (rng.random((r, n)) < 0.3)) + 1e-3).astype(np.float32)
+    noise = (rng.random((F, r)) @ (rng.random((r, n)) * (rng.random((r, n)) < 0.3))).astype(np.float32)
+    noisy = clean + noise
+    params = dict(r=r, cf="ed", sparsity=0.1, max_iter=40, conv_eps=1e-4, random_seed=2016)
+    W, H, obj = snmf.sparse_nmf(clean, params)
+    assert W.shape == (F, r) and H.shape == (r, n)
+    assert len(obj["cost"]) <= 40 and np.all(np.diff(obj["cost"]) <= 1e-4 * obj["cost"][:-1])
+    # chunked run (3 chunks): objective bookkeeping of snmf.py:66-83
+    W3, H3, obj3 = snmf.sparse_nmf(clean, params, max_frame_batch_size=6)   # 6*200/6 = 200 frames
+    assert len(obj3["obj_snmf_per_chunk"]) == 3 and len(obj3["cost"]) == 2 and H3.shape == (r, n)
+    Wn, Hn, objn = snmf.train_snmf(clean, noisy, dict(params, max_iter=15, conv_eps=0.0))
+    assert Wn.shape == (F, 2 * r) and Hn.shape == (2 * r, n)
+    Wc, _, _ = snmf.sparse_nmf(clean, dict(params, max_iter=15, conv_eps=0.0))
+    np.testing.assert_allclose(Wn[:, :r], Wc, rtol=1e-4, atol=1e-6)      # speech half frozen
+    np.testing.assert_allclose((Wn * Wn).sum(0), 1.0, rtol=1e-5)
