@@ -60,6 +60,11 @@ SIGNATURES = {
                                      _vp, _sz, _vp]),
     "drnmf_stft_frames": (_i32, [_i64, _i32, _i32]),
     "drnmf_stft_mag": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "drnmf_stft": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "drnmf_istft_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "drnmf_istft_masked": (_i32, [_vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz,
+                                  _vp]),
+    "drnmf_snr": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

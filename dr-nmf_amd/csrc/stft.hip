@@ -14,9 +14,34 @@
 
 namespace {
 
+// in-place radix-2 DIT FFT of N complex points in LDS (input already bit-reversed); tw[k] =
+// e^{-2 pi i k / N}, k < N/2
+__device__ __forceinline__ void fft_lds(float2* buf, const float2* tw, int N, int logN, int tid) {
+    for (int s = 1; s <= logN; ++s) {
+        const int half = 1 << (s - 1);
+        const int tstride = N >> s;
+        for (int b = tid; b < N / 2; b += 256) {
+            const int pos = b & (half - 1);
+            const int i0 = ((b >> (s - 1)) << s) + pos, i1 = i0 + half;
+            const float2 w = tw[pos * tstride];
+            const float2 u = buf[i0], v = buf[i1];
+            const float2 t = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            buf[i0] = make_float2(u.x + t.x, u.y + t.y);
+            buf[i1] = make_float2(u.x - t.x, u.y - t.y);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float sqrt_hann(int i, int N) {
+    // sqrt(hann(N, sym=False)) with the Hann value rounded to float32 first (audio_dataset.py:194)
+    const float hann = (float)(0.5 - 0.5 * cospi(2.0 * (double)i / (double)N));
+    return sqrtf(hann);
+}
+
 __global__ void __launch_bounds__(256)
-stft_mag_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int N, int logN, int hop,
-                int nf, float* __restrict__ mag) {
+stft_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int N, int logN, int hop,
+            int nf, float* __restrict__ mag, float* __restrict__ re, float* __restrict__ im) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float2* buf = (float2*)smem;            // N complex points
     float2* tw = buf + N;                   // N/2 twiddles e^{-2 pi i k / N}
@@ -36,32 +61,101 @@ stft_mag_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int 
             v = is_int16 ? (float)((const short*)pcm)[(size_t)sig * nsampl + idx] / 32768.0f
                          : ((const float*)pcm)[(size_t)sig * nsampl + idx];
         }
-        // sqrt(hann(N, sym=False)) with the Hann value rounded to float32 first
-        const float hann = (float)(0.5 - 0.5 * cospi(2.0 * (double)i / (double)N));
-        v *= sqrtf(hann);
+        v *= sqrt_hann(i, N);
         const unsigned rev = __brev((unsigned)i) >> (32 - logN);
         buf[rev] = make_float2(v, 0.f);
     }
     __syncthreads();
-    for (int s = 1; s <= logN; ++s) {
-        const int half = 1 << (s - 1);
-        const int tstride = N >> s;
-        for (int b = tid; b < N / 2; b += 256) {
-            const int pos = b & (half - 1);
-            const int i0 = ((b >> (s - 1)) << s) + pos, i1 = i0 + half;
-            const float2 w = tw[pos * tstride];
-            const float2 u = buf[i0], v = buf[i1];
-            const float2 t = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-            buf[i0] = make_float2(u.x + t.x, u.y + t.y);
-            buf[i1] = make_float2(u.x - t.x, u.y - t.y);
+    fft_lds(buf, tw, N, logN, tid);
+    const size_t o = ((size_t)sig * nf + frame) * (N / 2 + 1);
+    for (int k = tid; k <= N / 2; k += 256) {
+        const float2 z = buf[k];
+        if (mag) mag[o + k] = sqrtf(z.x * z.x + z.y * z.y);
+        if (re) re[o + k] = z.x;
+        if (im) im[o + k] = -z.y;    // librosa 0.5.1 conjugates the spectrum (util.py:195 via stft)
+    }
+}
+
+// one workgroup per (signal, frame): masked spectrum -> Hermitian extension -> inverse FFT -> real
+// part * window * 2/(N/hop)  (util.py:48-169 istft_noDiv with center=False)
+__global__ void __launch_bounds__(256)
+istft_frames_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                    const float* __restrict__ mask, int N, int logN, int hop, int nf,
+                    float* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* buf = (float2*)smem;
+    float2* tw = buf + N;
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x, sig = blockIdx.y;
+    const int F = N / 2 + 1;
+    for (int k = tid; k < N / 2; k += 256) {
+        float s, c;
+        sincospif(-2.0f * (float)k / (float)N, &s, &c);
+        tw[k] = make_float2(c, s);
+    }
+    // ifft(z) = conj(fft(conj(z)))/N.  With S the stored (conjugated) spectrum the reference
+    // builds z = [conj(S_0..S_{N/2}), S_{N/2-1}..S_1], so conj(z) = [S_k ; conj(S_{N-k})].
+    const size_t o = ((size_t)sig * nf + frame) * F;
+    for (int k = tid; k < N; k += 256) {
+        const int kk = k <= N / 2 ? k : N - k;
+        const float m = mask ? mask[o + kk] : 1.f;
+        float2 z = make_float2(m * re[o + kk], m * im[o + kk]);
+        if (k > N / 2) z.y = -z.y;
+        const unsigned rev = __brev((unsigned)k) >> (32 - logN);
+        buf[rev] = z;
+    }
+    __syncthreads();
+    fft_lds(buf, tw, N, logN, tid);
+    const float scale = (2.0f / ((float)N / (float)hop)) / (float)N;
+    float* out = frames + ((size_t)sig * nf + frame) * N;
+    for (int i = tid; i < N; i += 256) out[i] = buf[i].x * scale * sqrt_hann(i, N);
+}
+
+// overlap-add by gathering (deterministic), with istft_mc's trimming of the N padding samples on
+// both sides and the crop to nsampl (util.py:203-226)
+__global__ void __launch_bounds__(256)
+overlap_add_kernel(const float* __restrict__ frames, int N, int hop, int nf, int64_t nsampl,
+                   float* __restrict__ y) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int sig = blockIdx.y;
+    if (s >= nsampl) return;
+    const int64_t p = s + N;                                  // index in the untrimmed signal
+    const int64_t total = (int64_t)N + (int64_t)hop * (nf - 1);
+    float acc = 0.f;
+    if (p < total - N) {
+        int64_t j0 = (p - N + hop) / hop;                     // ceil((p - N + 1) / hop)
+        if (j0 < 0) j0 = 0;
+        int64_t j1 = p / hop;
+        if (j1 > nf - 1) j1 = nf - 1;
+        for (int64_t j = j0; j <= j1; ++j)
+            acc += frames[((size_t)sig * nf + j) * N + (p - j * hop)];
+    }
+    y[(size_t)sig * nsampl + s] = acc;
+}
+
+// SNR = 10 log10(sum ref^2 / sum (ref - est)^2)  (score_audio.m:209), one workgroup per signal
+__global__ void __launch_bounds__(256)
+snr_kernel(const float* __restrict__ est, const float* __restrict__ ref, int64_t nsampl,
+           float* __restrict__ out_db) {
+    __shared__ double s0[256], s1[256];
+    const int sig = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < nsampl; i += 256) {
+        const double r = ref[(size_t)sig * nsampl + i], e = est[(size_t)sig * nsampl + i];
+        a += r * r;
+        b += (r - e) * (r - e);
+    }
+    s0[threadIdx.x] = a;
+    s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            s0[threadIdx.x] += s0[threadIdx.x + o];
+            s1[threadIdx.x] += s1[threadIdx.x + o];
         }
         __syncthreads();
     }
-    float* out = mag + ((size_t)sig * nf + frame) * (N / 2 + 1);
-    for (int k = tid; k <= N / 2; k += 256) {
-        const float2 z = buf[k];
-        out[k] = sqrtf(z.x * z.x + z.y * z.y);
-    }
+    if (threadIdx.x == 0) out_db[sig] = (float)(10.0 * log10(s0[0] / s1[0]));
 }
 
 }  // namespace
@@ -87,8 +181,73 @@ extern "C" int32_t drnmf_stft_mag(drnmf_handle_t h, int32_t n_sig, int64_t nsamp
     while ((1 << logN) < N) ++logN;
     const int nf = drnmf_stft_frames(nsampl, N, hop);
     const size_t shmem = (size_t)(N + N / 2) * sizeof(float2);
-    hipLaunchKernelGGL(stft_mag_kernel, dim3((unsigned)nf, (unsigned)n_sig), dim3(256), shmem,
-                       (hipStream_t)stream_, pcm, is_int16, nsampl, N, logN, hop, nf, mag);
+    hipLaunchKernelGGL(stft_kernel, dim3((unsigned)nf, (unsigned)n_sig), dim3(256), shmem,
+                       (hipStream_t)stream_, pcm, is_int16, nsampl, N, logN, hop, nf, mag,
+                       (float*)nullptr, (float*)nullptr);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+static int check_fft_size(drnmf_handle_t h, int N, const char* who) {
+    if (N < 64 || N > 4096 || (N & (N - 1)))
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "%s: N=%d must be a power of two in [64,4096]", who, N);
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_stft(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32_t N,
+                              int32_t hop, int32_t is_int16, const void* pcm, float* re, float* im,
+                              float* mag, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n_sig <= 0 || nsampl <= 0 || hop <= 0 || !pcm || !re || !im)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "stft: bad argument");
+    int rc = check_fft_size(h, N, "stft");
+    if (rc) return rc;
+    int logN = 0;
+    while ((1 << logN) < N) ++logN;
+    const int nf = drnmf_stft_frames(nsampl, N, hop);
+    const size_t shmem = (size_t)(N + N / 2) * sizeof(float2);
+    hipLaunchKernelGGL(stft_kernel, dim3((unsigned)nf, (unsigned)n_sig), dim3(256), shmem,
+                       (hipStream_t)stream_, pcm, is_int16, nsampl, N, logN, hop, nf, mag, re, im);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+extern "C" size_t drnmf_istft_workspace_bytes(int32_t n_sig, int32_t n_frames, int32_t N) {
+    if (n_sig <= 0 || n_frames <= 0 || N <= 0) return 0;
+    return round_up_sz((size_t)n_sig * n_frames * N * sizeof(float), 256);
+}
+
+extern "C" int32_t drnmf_istft_masked(drnmf_handle_t h, int32_t n_sig, int32_t n_frames,
+                                      int64_t nsampl, int32_t N, int32_t hop, const float* re,
+                                      const float* im, const float* mask, float* y,
+                                      void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n_sig <= 0 || n_frames <= 0 || nsampl <= 0 || hop <= 0 || !re || !im || !y || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "istft_masked: bad argument");
+    int rc = check_fft_size(h, N, "istft_masked");
+    if (rc) return rc;
+    if (workspace_bytes < drnmf_istft_workspace_bytes(n_sig, n_frames, N))
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "istft_masked: workspace too small");
+    int logN = 0;
+    while ((1 << logN) < N) ++logN;
+    hipStream_t stream = (hipStream_t)stream_;
+    float* frames = (float*)workspace;
+    const size_t shmem = (size_t)(N + N / 2) * sizeof(float2);
+    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)n_frames, (unsigned)n_sig), dim3(256),
+                       shmem, stream, re, im, mask, N, logN, hop, n_frames, frames);
+    hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((nsampl + 255) / 256), (unsigned)n_sig),
+                       dim3(256), 0, stream, frames, N, hop, n_frames, nsampl, y);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_snr(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, const float* est,
+                             const float* ref, float* out_db, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n_sig <= 0 || nsampl <= 0 || !est || !ref || !out_db)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "snr: bad argument");
+    hipLaunchKernelGGL(snr_kernel, dim3((unsigned)n_sig), dim3(256), 0, (hipStream_t)stream_, est,
+                       ref, nsampl, out_db);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }

@@ -345,3 +345,74 @@ class SnmfTrainer(object):
                                           _capi.ptr(self.ws), self.nbytes, _stream())
         _capi.check(rc, self.h, "drnmf_snmf_train_step")
         return obj
+
+
+def stft(pcm, N=1024, hop=None, want_mag=False):
+    """Complex STFT (reference stack convention: conjugated spectrum, util.py:195,351).
+    Returns (re, im[, mag]) each [n_sig, n_frames, N/2+1]."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(pcm))
+    if hop is None:
+        hop = N // 2
+    if pcm.dim() == 1:
+        pcm = pcm[None]
+    if pcm.dtype not in (torch.int16, torch.float32):
+        raise ValueError("pcm must be int16 or float32")
+    pcm = pcm.contiguous()
+    n_sig, nsampl = pcm.shape
+    nf = stft_frames(nsampl, N, hop)
+    shape = (n_sig, nf, N // 2 + 1)
+    re = torch.empty(shape, dtype=torch.float32, device=pcm.device)
+    im = torch.empty(shape, dtype=torch.float32, device=pcm.device)
+    mag = torch.empty(shape, dtype=torch.float32, device=pcm.device) if want_mag else None
+    rc = L.drnmf_stft(h, n_sig, nsampl, int(N), int(hop), int(pcm.dtype == torch.int16),
+                      _capi.ptr(pcm), _capi.ptr(re), _capi.ptr(im), _capi.ptr(mag), _stream())
+    _capi.check(rc, h, "drnmf_stft")
+    return (re, im, mag) if want_mag else (re, im)
+
+
+def istft_masked(re, im, mask, nsampl, N, hop):
+    """y [n_sig, nsampl] = istft_noDiv(mask * (re + i im)) with the sqrt-Hann synthesis window
+    (audio_dataset.py:267-278; util.py:48-169, 203-226).  mask may be None."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(re))
+    re, im = _f32c(re, "re"), _f32c(im, "im")
+    n_sig, nf, F = re.shape
+    if F != N // 2 + 1:
+        raise ValueError("re/im have %d bins, N=%d needs %d" % (F, N, N // 2 + 1))
+    if mask is not None:
+        mask = _f32c(mask, "mask")
+        if tuple(mask.shape) != tuple(re.shape):
+            raise ValueError("mask shape %s != spectrum shape %s" % (tuple(mask.shape),
+                                                                     tuple(re.shape)))
+    y = torch.empty((n_sig, int(nsampl)), dtype=torch.float32, device=re.device)
+    nbytes = L.drnmf_istft_workspace_bytes(n_sig, nf, int(N))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=re.device)
+    rc = L.drnmf_istft_masked(h, n_sig, nf, int(nsampl), int(N), int(hop), _capi.ptr(re),
+                              _capi.ptr(im), _capi.ptr(mask), _capi.ptr(y), _capi.ptr(ws), nbytes,
+                              _stream())
+    _capi.check(rc, h, "drnmf_istft_masked")
+    return y
+
+
+def snr_db(est, ref):
+    """Raw SNR per signal (score_audio.m:209)."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(est))
+    est, ref = _f32c(est, "est"), _f32c(ref, "ref")
+    if est.dim() == 1:
+        est, ref = est[None], ref[None]
+    n_sig, nsampl = est.shape
+    out = torch.empty(n_sig, dtype=torch.float32, device=est.device)
+    rc = L.drnmf_snr(h, n_sig, nsampl, _capi.ptr(est), _capi.ptr(ref), _capi.ptr(out), _stream())
+    _capi.check(rc, h, "drnmf_snr")
+    return out
+
+
+def to_int16_wav(x):
+    """util.wavwrite's float32 -> int16 conversion (util.py:37-45): divide by max|x| if it exceeds
+    1, scale by 32767, truncate toward zero (numpy int16 cast)."""
+    m = x.abs().max()
+    if float(m) > 1.0:
+        x = x / m
+    return (x * 32767.0).to(torch.int16)

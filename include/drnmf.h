@@ -206,6 +206,27 @@ int32_t drnmf_stft_frames(int64_t nsampl, int32_t N, int32_t hop);
 int32_t drnmf_stft_mag(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32_t N, int32_t hop,
                        int32_t is_int16, const void* pcm, float* mag, void* stream);
 
+/* ---- complex STFT (same framing / window as drnmf_stft_mag): re, im [n_sig][n_frames][N/2+1] in
+ * librosa 0.5.1's CONJUGATED convention, i.e. what compute_STFTs stacks as [real; imag]
+ * (util.py:195, 351); mag optional (NULL to skip). */
+int32_t drnmf_stft(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32_t N, int32_t hop,
+                   int32_t is_int16, const void* pcm, float* re, float* im, float* mag,
+                   void* stream);
+
+/* ---- masked reconstruction: replaces AudioDataset.reconstruct_x (audio_dataset.py:267-278:
+ * mask tiled over the re/im halves) + istft_mc(flag_noDiv=1, sqrt-Hann) (util.py:48-169, 203-226).
+ *   y [n_sig][nsampl] = istft_noDiv(mask * (re + i im)), the N padding samples trimmed on both
+ *   sides, cropped to nsampl.  mask [n_sig][n_frames][N/2+1] or NULL. */
+size_t drnmf_istft_workspace_bytes(int32_t n_sig, int32_t n_frames, int32_t N);
+int32_t drnmf_istft_masked(drnmf_handle_t h, int32_t n_sig, int32_t n_frames, int64_t nsampl,
+                           int32_t N, int32_t hop, const float* re, const float* im,
+                           const float* mask, float* y, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* ---- raw SNR in dB per signal: 10 log10(sum ref^2 / sum (ref-est)^2)  (score_audio.m:209). */
+int32_t drnmf_snr(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, const float* est,
+                  const float* ref, float* out_db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -568,3 +568,36 @@ def sparse_nmf_train(V, W0, H0, sparsity, max_iter, conv_eps=0.0, beta=2.0, w_up
                 break
         last_cost = cost
     return W, H, dict(div=np.array(divs), cost=np.array(costs))
+
+
+# --------------------------------------------------------------------------------------------
+# reconstruction: util.py:48-169 (istft_noDiv, librosa 0.5.1 istft minus the window-sum division),
+# util.py:203-226 (istft_mc trimming), audio_dataset.py:267-278 (mask tiled over re/im), SNR
+# score_audio.m:209
+# --------------------------------------------------------------------------------------------
+def istft_noDiv(S, hop, window, dtype=np.float64):
+    """S: (N/2+1, n_frames) complex in the reference's CONJUGATED convention; center=False."""
+    F, nf = S.shape
+    N = 2 * (F - 1)
+    w = np.asarray(window, dtype=dtype) * (2.0 / (N / hop))                     # util.py:143-146
+    y = np.zeros(N + hop * (nf - 1), dtype=dtype)
+    for i in range(nf):
+        spec = S[:, i]
+        spec = np.concatenate((spec.conj(), spec[-2:0:-1]), 0)                  # util.py:155
+        y[i * hop:i * hop + N] += w * np.fft.ifft(spec).real
+    return y
+
+
+def reconstruct(re, im, mask, hop, window, nsampl=None, dtype=np.float64):
+    """audio_dataset.reconstruct_x + util.istft_mc(flag_noDiv=1): re/im/mask (F, n_frames)."""
+    S = (mask * re if mask is not None else re).astype(dtype) + \
+        1j * (mask * im if mask is not None else im).astype(dtype)
+    N = 2 * (S.shape[0] - 1)
+    xr = istft_noDiv(S, hop, window, dtype)
+    xr = xr[:len(xr) - N][N:]                                                   # util.py:221-224
+    return xr if nsampl is None else xr[:nsampl]
+
+
+def snr_db(est, ref):
+    """score_audio.m:209."""
+    return 10.0 * np.log10(np.sum(ref ** 2) / np.sum((ref - est) ** 2))

@@ -370,3 +370,39 @@ def test_sparse_nmf_host_api_chunks_and_two_stage(dev):
     Wc, _, _ = snmf.sparse_nmf(clean, dict(params, max_iter=15, conv_eps=0.0))
     np.testing.assert_allclose(Wn[:, :r], Wc, rtol=1e-4, atol=1e-6)      # speech half frozen
     np.testing.assert_allclose((Wn * Wn).sum(0), 1.0, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ STFT -> mask -> iSTFT -> SNR
+@pytest.mark.parametrize("N,hop,nsampl", [(512, 128, 16000), (1024, 256, 9999), (64, 16, 700)])
+def test_stft_istft_reconstruction_and_snr(dev, N, hop, nsampl):
+    from drnmf_amd import ops
+    rng = np.random.default_rng(N)
+    n_sig = 2
+    x = (0.3 * rng.standard_normal((n_sig, nsampl))).astype(np.float32)
+    tx = torch.from_numpy(x).to(dev)
+    re, im, mag = ops.stft(tx, N=N, hop=hop, want_mag=True)
+    w = O.sqrt_hann(N)
+    nf = O.stft_frames(nsampl, N, hop)
+    for s in range(n_sig):
+        S = O.stft_mc(x[s], N, hop, w)                      # conjugated convention
+        scale = np.max(np.abs(S))
+        assert np.max(np.abs(re[s].cpu().numpy().T - S.real)) <= 2e-5 * scale
+        assert np.max(np.abs(im[s].cpu().numpy().T - S.imag)) <= 2e-5 * scale
+    # unmasked round trip: sqrt-Hann analysis + synthesis, hop = N/4 -> perfect reconstruction
+    y = ops.istft_masked(re, im, None, nsampl, N, hop)
+    torch.cuda.synchronize()
+    err = np.max(np.abs(y.cpu().numpy() - x)) / np.max(np.abs(x))
+    assert err <= 1e-4, err
+    # masked reconstruction vs the oracle's reconstruct_x/istft_mc
+    mask = rng.random((n_sig, nf, N // 2 + 1)).astype(np.float32)
+    ym = ops.istft_masked(re, im, torch.from_numpy(mask).to(dev), nsampl, N, hop).cpu().numpy()
+    for s in range(n_sig):
+        S = O.stft_mc(x[s], N, hop, w)
+        ref = O.reconstruct(S.real, S.imag, mask[s].T.astype(np.float64), hop, w, nsampl)
+        assert np.max(np.abs(ym[s] - ref)) <= 1e-4 * np.max(np.abs(ref))
+    snr = ops.snr_db(torch.from_numpy(ym).to(dev), tx).cpu().numpy()
+    for s in range(n_sig):
+        np.testing.assert_allclose(snr[s], O.snr_db(ym[s].astype(np.float64), x[s].astype(np.float64)),
+                                   rtol=1e-4)
+    q = ops.to_int16_wav(y[0])
+    assert q.dtype == torch.int16 and int(q.abs().max()) <= 32767
