@@ -301,6 +301,36 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
 
 __global__ void noop_kernel() {}
 
+// stateful mode (custom_layers.py:296-318; Keras Recurrent stateful=True): the state entering frame
+// 0 is supplied by the caller.  One wave per row: pack the row into Hp and leave its sum in atom
+// block 0 of parity 0 (sum(p) adds the blocks).
+__global__ void __launch_bounds__(256)
+load_state_kernel(const float* __restrict__ init, float* __restrict__ state,
+                  float* __restrict__ rs_part, int* tptr, int B, int N, int Np, int Bp, int numA) {
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wv;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { tptr[0] = 0; tptr[16] = 0; }
+    if (b >= Bp) return;
+    float s = 0.f;
+    for (int n = l; n < Np; n += 64) {
+        const float v = (b < B && n < N) ? init[(size_t)b * N + n] : 0.f;
+        s += v;
+        state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + (b & 15) * 16 + (n & 15)] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (l == 0) {
+        for (int a = 0; a < 2 * numA; ++a) rs_part[(size_t)a * Bp + b] = (a == 0) ? s : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+store_state_kernel(const float* __restrict__ state, float* __restrict__ out, int B, int N, int Np) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    const int b = (int)(i / N), n = (int)(i % N);
+    out[i] = state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + (b & 15) * 16 + (n & 15)];
+}
+
 // Masking + relayout: x [B][T][F] -> xp [T][Bp][Fp] (masked frames and all padding zero) and
 // valid [T][Bp].  One wave per (t, row).  [K2.0.4-memory: keras.layers.Masking]
 __global__ void __launch_bounds__(256)
@@ -423,7 +453,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                                  float u0_diag, float u0_off, float uk_off, float* h_out,
                                  void* workspace, size_t workspace_bytes, void* stream_,
                                  int profile_frames, float* out_us,
-                                 hipGraphExec_t* out_exec = nullptr) {
+                                 hipGraphExec_t* out_exec = nullptr,
+                                 const float* initial_state = nullptr) {
     // out_exec != NULL: enqueue the prologue and build/find the frame graph, but leave the T
     // replays to the caller (who interleaves them with other chains)
     if (!h) return DRNMF_ERR_INVALID_ARG;
@@ -459,8 +490,12 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                            stream, x, xp, valid, mask_value, d->B, d->T, d->F, W.Bp, W.Fp);
         hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 255) / 256), dim3(256), 0, stream, valid,
                            (unsigned char*)(ws + W.off_seen), d->T, W.Bp);
-        hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
-                           rs_part, tA, d->N, W.Np, W.Bp, W.numA);
+        if (initial_state)
+            hipLaunchKernelGGL(load_state_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream,
+                               initial_state, state, rs_part, tA, d->B, d->N, W.Np, W.Bp, W.numA);
+        else
+            hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
+                               rs_part, tA, d->N, W.Np, W.Bp, W.numA);
         DRNMF_HIP(h, hipGetLastError());
     }
 
@@ -749,6 +784,25 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
         DRNMF_HIP(h, hipEventRecord(h->side_done[g], h->side_streams[g]));
         DRNMF_HIP(h, hipStreamWaitEvent(stream, h->side_done[g], 0));
     }
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d,
+                                               const float* x, float mask_value, const void* params,
+                                               const float* log_h0, float u0_diag, float u0_off,
+                                               float uk_off, const float* initial_state,
+                                               float* final_state, float* h_out, void* workspace,
+                                               size_t workspace_bytes, void* stream_) {
+    int rc = cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
+                               workspace, workspace_bytes, stream_, 0, nullptr, nullptr,
+                               initial_state);
+    if (rc || !final_state) return rc;
+    const Workspace W = workspace_layout(d);
+    const size_t tot = (size_t)d->B * d->N;
+    hipLaunchKernelGGL(store_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream_, (const float*)((char*)workspace + W.off_state),
+                       final_state, d->B, d->N, W.Np);
+    DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }
 

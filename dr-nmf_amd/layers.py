@@ -275,6 +275,7 @@ class SimpleDeepRNN(_Layer):
         self.input_shape = input_shape
         self.stateful = stateful
         self.consume_less = 'gpu'
+        self.states = [None]
         self.device = torch.device(device if device is not None else 'cuda')
         self._params_block = None
         self._ws = {}
@@ -292,8 +293,6 @@ class SimpleDeepRNN(_Layer):
             problems.append('dropout is never enabled by the reference and is not implemented')
         if W_regularizer or U_regularizer or b_regularizer:
             problems.append('regularizers are not implemented')
-        if stateful:
-            problems.append('stateful=True is not implemented')
         if problems:
             raise NotImplementedError('SimpleDeepRNN (HIP path): ' + '; '.join(problems))
 
@@ -361,7 +360,12 @@ class SimpleDeepRNN(_Layer):
                 'flag_connect_input_to_layers': self.flag_connect_input_to_layers}
 
     def reset_states(self):                                               # custom_layers.py:296-318
+        """Stateful mode: zero the carried state (the reference sets np.zeros, not h0)."""
         assert self.stateful, 'Layer must be stateful.'
+        if getattr(self, 'states', None) is None or self.states[0] is None:
+            raise ValueError('If a RNN is stateful, it needs to know its batch size: call the layer '
+                             'once (or pass batch_input_shape) before reset_states().')
+        self.states[0].zero_()
 
     # -- forward ---------------------------------------------------------------------------
     def _stacked(self, name):
@@ -407,8 +411,18 @@ class SimpleDeepRNN(_Layer):
         if key not in self._ws:
             self._ws.clear()
             self._ws[key] = ops.cell_workspace(desc, x.device)
+        init = fin = None
+        if self.stateful:
+            # Keras stateful RNN: the state left by the previous batch enters this one; the first
+            # batch starts from zeros (Recurrent.reset_states / custom_layers.py:315-318)
+            if getattr(self, 'states', None) is None or self.states[0] is None or \
+                    tuple(self.states[0].shape) != (B, self.output_dim):
+                self.states = [torch.zeros((B, self.output_dim), dtype=torch.float32,
+                                           device=x.device)]
+            init = fin = self.states[0]
         h = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
-                             out=out, workspace=self._ws[key])
+                             out=out, workspace=self._ws[key], initial_state=init,
+                             final_state=fin)
         return h if self.return_sequences else h[:, -1]
 
     __call__ = call

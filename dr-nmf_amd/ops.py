@@ -75,9 +75,10 @@ def cell_workspace(desc, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
-def cell_forward(x, mask_value, params, desc, log_h0, u, out=None, workspace=None):
+def cell_forward(x, mask_value, params, desc, log_h0, u, out=None, workspace=None,
+                 initial_state=None, final_state=None):
     """x [B,T,F] -> h [B,T,N] (or [B,T,K*N]).  mask_value None = no masking.
-    u = (u0_diag, u0_off, uk_off)."""
+    u = (u0_diag, u0_off, uk_off).  initial_state / final_state [B,N]: stateful mode."""
     L = _capi.lib()
     dev = _dev_index(x)
     h = _capi.handle(dev)
@@ -96,6 +97,18 @@ def cell_forward(x, mask_value, params, desc, log_h0, u, out=None, workspace=Non
     if workspace is None:
         workspace = cell_workspace(desc, x.device)
     mv = float("nan") if mask_value is None else float(mask_value)
+    if initial_state is not None or final_state is not None:
+        for st in (initial_state, final_state):
+            if st is not None and (tuple(st.shape) != (desc.B, desc.N) or st.dtype != torch.float32
+                                   or not st.is_contiguous()):
+                raise ValueError("states must be contiguous float32 (B,N) tensors")
+        rc = L.drnmf_cell_forward_stateful(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
+                                           _capi.ptr(log_h0), float(u[0]), float(u[1]),
+                                           float(u[2]), _capi.ptr(initial_state),
+                                           _capi.ptr(final_state), _capi.ptr(out),
+                                           _capi.ptr(workspace), workspace.numel(), _stream())
+        _capi.check(rc, h, "drnmf_cell_forward_stateful")
+        return out
     rc = L.drnmf_cell_forward(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
                               _capi.ptr(log_h0), float(u[0]), float(u[1]), float(u[2]),
                               _capi.ptr(out), _capi.ptr(workspace), workspace.numel(), _stream())

@@ -89,6 +89,16 @@ int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const f
                            float u0_diag, float u0_off, float uk_off, float* h_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Stateful variant (Keras Recurrent stateful=True + SimpleDeepRNN.reset_states,
+ * custom_layers.py:296-318): the state entering frame 0 is initial_state [B][N] (NULL = the
+ * softplus(log_h0) default) and the state after the last frame is written to final_state [B][N]
+ * (NULL to skip). */
+int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                    float mask_value, const void* params, const float* log_h0,
+                                    float u0_diag, float u0_off, float uk_off,
+                                    const float* initial_state, float* final_state, float* h_out,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* Number of independent utterance chains drnmf_cell_forward will run concurrently for this
  * descriptor (row groups on internal side streams, forked from / joined to the caller's stream). */
 int32_t drnmf_cell_chains(const drnmf_cell_desc_t* d);

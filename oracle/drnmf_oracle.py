@@ -168,7 +168,7 @@ def cell_forward_dense(x, Wk, Uk, bk, Sk, log_h0, mask_value=-1.0, return_all_hi
 
 
 def cell_forward_factored(x, layers, u, log_h0, mask_value=-1.0, return_all_hidden=False,
-                          dtype=np.float64):
+                          dtype=np.float64, initial_state=None, return_state=False):
     """Same recurrence in the factored ISTA form (never materialises S_k or U_k):
         layer 0 : relu(u0d*p + u0o*(sum(p)-p) + (x Dn_0)*ia_0 + b_0)
         layer k : relu(h + ((x - h Dn_k^T) Dn_k)*ia_k + b_k + uko*sum(p))
@@ -182,6 +182,8 @@ def cell_forward_factored(x, layers, u, log_h0, mask_value=-1.0, return_all_hidd
     h0 = softplus(np.asarray(log_h0, dtype=dtype))
     width = K * N if return_all_hidden else N
     state = np.tile((np.tile(h0, K) if return_all_hidden else h0)[None, :], (B, 1))
+    if initial_state is not None:       # stateful mode (custom_layers.py:296-318)
+        state = np.array(initial_state, dtype=dtype, copy=True)
     out_prev = np.zeros((B, width), dtype=dtype)
     hs = np.empty((B, T, width), dtype=dtype)
     for t in range(T):
@@ -202,7 +204,7 @@ def cell_forward_factored(x, layers, u, log_h0, mask_value=-1.0, return_all_hidd
         out_prev = np.where(v, out, out_prev)
         state = np.where(v, out, state)
         hs[:, t] = out_prev
-    return hs
+    return (hs, state) if return_state else hs
 
 
 # --------------------------------------------------------------------------------------------

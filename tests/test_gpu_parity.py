@@ -406,3 +406,33 @@ def test_stft_istft_reconstruction_and_snr(dev, N, hop, nsampl):
                                    rtol=1e-4)
     q = ops.to_int16_wav(y[0])
     assert q.dtype == torch.int16 and int(q.abs().max()) <= 32767
+
+
+def test_stateful_cell_carries_state_across_batches(dev):
+    """stateful=True (custom_layers.py:296-318): two consecutive half-length calls equal one
+    full-length run started from the zero state; reset_states() zeroes it again."""
+    from drnmf_amd import layers
+    K = 3
+    P, alt, labels, N = _problem(3, 8, 21, 6, K, ragged=False)
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(N / 4.0), lam1=np.float32(0.3))
+    alt_l, maps = layers.build_alt(N, K, params, params_untied=["log_D", "log_alph"])
+    for k in alt_l:
+        alt_l[k] = alt[k]
+    cell = layers.SimpleDeepRNN(N, activation="relu", K_layers=K, alt_params=alt_l,
+                                maps_from_alt=maps, flag_connect_input_to_layers=True,
+                                flag_nonnegative=True, return_sequences=True, stateful=True)
+    cell.build((3, 4, 21))
+    cell.log_h0.copy_(torch.from_numpy(P["log_h0"]))
+    x = torch.from_numpy(P["X"]).to(dev)
+    h1 = cell(x[:, :4].contiguous()).cpu().numpy()
+    h2 = cell(x[:, 4:].contiguous()).cpu().numpy()
+    lay, u = O.maps_factored(alt, labels, K), O.u_scalars(alt)
+    ref, st = O.cell_forward_factored(P["X"], lay, u, P["log_h0"], mask_value=np.nan,
+                                      initial_state=np.zeros((3, N)), return_state=True)
+    _check_h(np.concatenate([h1, h2], 1), ref)
+    np.testing.assert_allclose(cell.states[0].cpu().numpy(), st, atol=1e-4 * np.max(np.abs(st)))
+    cell.reset_states()
+    assert float(cell.states[0].abs().max()) == 0.0
+    h1b = cell(x[:, :4].contiguous()).cpu().numpy()
+    np.testing.assert_array_equal(h1, h1b)

@@ -96,9 +96,12 @@ def test_simple_deep_rnn_rejects_uncovered_configs():
     cell.return_sequences = False
     assert cell.compute_output_shape((7, 11, 21)) == (7, K * N)
     assert cell.get_config()["K_layers"] == K
+    st = layers.SimpleDeepRNN(N, **dict(ok, stateful=True))      # stateful mode is supported
+    with pytest.raises(ValueError):
+        st.reset_states()                                        # batch size not known yet
     for bad in (dict(activation="tanh"), dict(flag_nonnegative=False),
                 dict(flag_connect_input_to_layers=False), dict(dropout_W=0.5),
-                dict(stateful=True), dict(maps_from_alt={"W": lambda a: a})):
+                dict(maps_from_alt={"W": lambda a: a})):
         kw = dict(ok)
         kw.update(bad)
         with pytest.raises(NotImplementedError):
