@@ -160,30 +160,28 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     bool vld = true;
     if (WRITE_OUT) vld = a.valid[(size_t)t * a.Bp + rg] != 0;
     // tail bins (F = 16*nchunks + ntail): residual r_tail = x_tail - sum over atom blocks of the
-    // partial dot products left by the previous layer; dictionary tail rows of this layer
-    float rt[MAX_TAIL] = {0.f, 0.f};
+    // partial dot products left by the previous layer.  Only the LOADS are issued here; they are
+    // reduced after the MFMA loop (consuming them now would force an in-order vmcnt wait on every
+    // operand load issued so far).
+    float xt[MAX_TAIL] = {0.f, 0.f};
+    float qv[MAX_TAIL][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x2 dt[MAX_TAIL] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < MAX_TAIL; ++i) {
         if (i >= a.ntail) continue;
         const size_t toff = ((size_t)a.nchunks * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
         dt[i] = *(const f32x2*)(a.Dn + toff);
-        float xt;
         if (IS_FIRST) {
             // packed input: bin 16*nchunks + i sits at tile nchunks, position perm(i) = 4*i
-            xt = rsrc[((size_t)m * nft + a.nchunks) * 256 + erow * 16 + 4 * i];
-            if (blockIdx.x == 0 && tid < 256 && (tid & 15) == 0) a.xtail[(size_t)i * a.Bp + rg] = xt;
-            rt[i] = xt;
+            xt[i] = rsrc[((size_t)m * nft + a.nchunks) * 256 + erow * 16 + 4 * i];
         } else {
-            xt = a.xtail[(size_t)i * a.Bp + rg];
+            xt[i] = a.xtail[(size_t)i * a.Bp + rg];
             const float* qp = a.q_in + (size_t)i * a.Bp + rg;
-            float sq = 0.f;
-            for (int b2 = (tid & 15); b2 < a.numA; b2 += 16) sq += qp[(size_t)b2 * MAX_TAIL * a.Bp];
-            sq += __shfl_xor(sq, 8, 16);
-            sq += __shfl_xor(sq, 4, 16);
-            sq += __shfl_xor(sq, 2, 16);
-            sq += __shfl_xor(sq, 1, 16);
-            rt[i] = xt - sq;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // atom blocks (tid&15) + 16u: covers numA <= 64 here
+                const int b2 = (tid & 15) + 16 * u;
+                if (b2 < a.numA) qv[i][u] = qp[(size_t)b2 * MAX_TAIL * a.Bp];
+            }
         }
     }
 
@@ -238,9 +236,24 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     }
 
 #pragma unroll
-    for (int i = 0; i < MAX_TAIL; ++i) {   // rank-1 update per tail bin (rt, dt are 0 beyond ntail)
-        gsum[0] = fmaf(rt[i], dt[i][0], gsum[0]);
-        gsum[1] = fmaf(rt[i], dt[i][1], gsum[1]);
+    for (int i = 0; i < MAX_TAIL; ++i) {   // rank-1 update per tail bin
+        if (i >= a.ntail) continue;
+        float rt = xt[i];
+        if (IS_FIRST) {
+            if (blockIdx.x == 0 && (tid & 15) == 0) a.xtail[(size_t)i * a.Bp + rg] = xt[i];
+        } else {
+            float sq = (qv[i][0] + qv[i][1]) + (qv[i][2] + qv[i][3]);
+            const float* qp = a.q_in + (size_t)i * a.Bp + rg;
+            for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16)      // numA > 64 only
+                sq += qp[(size_t)b2 * MAX_TAIL * a.Bp];
+            sq += __shfl_xor(sq, 8, 16);
+            sq += __shfl_xor(sq, 4, 16);
+            sq += __shfl_xor(sq, 2, 16);
+            sq += __shfl_xor(sq, 1, 16);
+            rt -= sq;
+        }
+        gsum[0] = fmaf(rt, dt[i][0], gsum[0]);
+        gsum[1] = fmaf(rt, dt[i][1], gsum[1]);
     }
 
     // ---- fused update: soft-threshold / non-negativity projection --------------------------
