@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // issuing one chunk's operand loads for all waves takes about as long as one wave's MFMAs on
     // that chunk.  Loads run PF chunks ahead of the MFMAs (enough to cover the L2/fabric latency)
     // and the two streams overlap instead of adding up.
-    constexpr int PF = G < 4 ? G : 4;
+    constexpr int PF = G < 3 ? G : 3;   // measured: 2..4 equivalent (250k frames/s), 6 slower (241k)
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
