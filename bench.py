@@ -39,15 +39,18 @@ def parse():
     ap.add_argument("--tied", action="store_true", help="tie log_D/log_alph across layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ista", action="store_true", help="skip the frame-parallel ISTA line")
-    ap.add_argument("--no-train", action="store_true", help="skip the training-step line")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step lines")
+    ap.add_argument("--no-train-c2", action="store_true",
+                    help="skip the training step at the headline shape (needs ~70 GB of HBM)")
     ap.add_argument("--cpu-frames", type=int, default=0,
                     help="frame-steps of the CPU baseline sample (0 = auto, ~15-25 s)")
     return ap.parse_args()
 
 
-def synth_on_device(torch, dev, B, T, F, r, seed):
+def synth_on_device(torch, dev, B, T, F, r, seed, want_clean=False):
     """SURVEY.md section 8d generator; the dictionary comes from numpy PCG64(7654), the
-    activations/noise from torch's generator on the device (256M draws)."""
+    activations/noise from torch's generator on the device (256M draws).  want_clean also
+    returns the clean target Y = Htrue[:, :r] W[:, :r]^T."""
     N = 2 * r
     rng = np.random.Generator(np.random.PCG64(7654))
     W = rng.random((F, N)) ** 4
@@ -57,10 +60,15 @@ def synth_on_device(torch, dev, B, T, F, r, seed):
     g.manual_seed(seed)
     Wt = torch.from_numpy(W).to(dev)
     X = torch.empty((B, T, F), dtype=torch.float32, device=dev)
+    Y = torch.empty((B, T, F), dtype=torch.float32, device=dev) if want_clean else None
     for b in range(B):
         Ht = (torch.rand((T, N), generator=g, device=dev) < 0.02) * \
             torch.rand((T, N), generator=g, device=dev) * 5.0
         X[b] = Ht @ Wt.t() + 0.01 * torch.rand((T, F), generator=g, device=dev)
+        if want_clean:
+            Y[b] = Ht[:, :r] @ Wt[:, :r].t()
+    if want_clean:
+        return W, log_h0, X, Y
     return W, log_h0, X
 
 
@@ -89,23 +97,28 @@ def ista_bench(torch, dev, F, N, K, W, n=32768):
             "gemm_launch_us": sec / (2 * K) * 1e6}
 
 
-def train_bench(torch, dev, steps=3):
-    """BASELINE configs[2]: the shipped training configuration (downsample1: F=257, maxlen=500,
-    batch 32, K=5, r=1000, untied log_D/log_alph) -- forward + BPTT + Adam per step, synthetic
-    ragged batch.  Algorithmic flops fwd+bwd = 12*F*N*K - 2*F*N per frame."""
+def train_bench(torch, dev, steps=3, shape=(32, 500, 257, 1000, 5), ragged=True):
+    """Forward + BPTT + Adam per step on a synthetic batch.  Default shape = BASELINE configs[2],
+    the shipped training configuration (downsample1: F=257, maxlen=500, batch 32, K=5, r=1000,
+    untied log_D/log_alph, ragged lengths); bench also runs it at the headline shape (F=513,
+    T=2000, K=25, B=64) for the metric's "fwd+bwd" reading.  Algorithmic flops fwd+bwd =
+    12*F*N*K - 2*F*N per frame."""
     from drnmf_amd import layers
-    from oracle import drnmf_oracle as O
-    B, T, F, r, K = 32, 500, 257, 1000, 5
+    B, T, F, r, K = shape
     N = 2 * r
-    P = O.synth_problem(B, T, F, r, seed=7654, ragged=True)
+    W, _, x, y = synth_on_device(torch, dev, B, T, F, r, seed=7654, want_clean=True)
+    w = torch.ones((B, T), dtype=torch.float32, device=dev)
+    if ragged:      # lengths in [0.4 T, T], -1 padding after the valid prefix (audio_dataset.py:144)
+        lens = np.random.Generator(np.random.PCG64(7654)).integers(int(0.4 * T), T + 1, size=B)
+        keep = torch.arange(T, device=dev)[None, :] < torch.from_numpy(lens).to(dev)[:, None]
+        w = keep.to(torch.float32)
+        x = torch.where(keep[..., None], x, torch.full_like(x, -1.0))
+        y = torch.where(keep[..., None], y, torch.full_like(y, -1.0))
     p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
-             W=P["W"], alph=400.0, lam1=1.0, params_untied=["log_D", "log_alph"],
-             params_trainable=["log_D", "log_alph"])
+             W=W, alph=400.0 if r >= 1000 else 50.0, lam1=1.0,
+             params_untied=["log_D", "log_alph"], params_trainable=["log_D", "log_alph"])
     model = layers.build_unfolded_snmf(p, device=dev)
     model.compile(lr=1e-3)
-    x = torch.from_numpy(P["X"]).to(dev)
-    y = torch.from_numpy(P["Y"]).to(dev)
-    w = torch.from_numpy((P["X"] != -1.0).any(-1).astype(np.float32)).to(dev)
     losses = [model.train_on_batch(x, y, w)]          # warm-up (graph build)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -115,8 +128,11 @@ def train_bench(torch, dev, steps=3):
     sec = (time.perf_counter() - t0) / steps
     valid = float(w.sum().item())
     flops = (12.0 * F * N * K - 2.0 * F * N) * B * T
-    return {"config": "F=%d N=%d K=%d B=%d T=%d untied, ragged (%.0f%% valid)" %
-                      (F, N, K, B, T, 100.0 * valid / (B * T)),
+    del model, x, y, w
+    torch.cuda.empty_cache()
+    return {"config": "F=%d N=%d K=%d B=%d T=%d untied, %s (%.0f%% valid)" %
+                      (F, N, K, B, T, "ragged" if ragged else "full length",
+                       100.0 * valid / (B * T)),
             "ms_per_step": sec * 1e3, "frames_per_s": B * T / sec,
             "valid_frames_per_s": valid / sec, "tflops": flops / sec / 1e12,
             "loss_first": losses[0], "loss_last": losses[-1]}
@@ -274,8 +290,12 @@ def main():
             del X
             torch.cuda.empty_cache()
             extra["train_step_configs2"] = train_bench(torch, dev)
+            if not a.no_train_c2:
+                extra["train_step_headline_shape"] = train_bench(
+                    torch, dev, steps=2, shape=(B, T, F, r, K), ragged=False)
     out = {
-        "metric": "STFT frames/sec (K=%d unrolled DR-NMF forward, %d-bin x %d-frame)" % (K, F, T),
+        "metric": "STFT frames/sec (fwd; fwd+bwd in extra.train_step_headline_shape), %d-bin x "
+                  "%d-frame, K=%d unrolls" % (F, T, K),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
