@@ -138,6 +138,26 @@ def train_bench(torch, dev, steps=3, shape=(32, 500, 257, 1000, 5), ragged=True)
             "loss_first": losses[0], "loss_last": losses[-1]}
 
 
+def pmc_traffic():
+    """HBM-side bytes per cell launch from the newest committed PMC summary (separate rocprofv3
+    --pmc passes over this same command, profiles/collect.sh; FETCH_SIZE KB x 1024 x 2 -- the
+    gfx950 under-report of wide coalesced reads, MI355X_MICROARCH.md -- plus WRITE_SIZE KB x
+    1024).  PMC counters cannot be read from inside the process, so this is the profiled figure
+    of the same kernels, or None when no summary is present."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_summary.json")))
+    for f in reversed(files):
+        try:
+            v = json.load(open(f)).get("_cell_launch_mean_traffic_bytes")
+        except (OSError, ValueError):
+            v = None
+        if v:
+            return float(v), "bytes per cell launch, HBM side (PMC passes: profiles/%s)" % \
+                os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(F, r, K, B, frames, tied):
     """The reference's op graph (dense p.U_k, materialised Gram h.S_k, x.Wk_k, bias+relu, K layers
     per frame inside a loop over time; custom_layers.py:361-369 + enhance.py:161-204) restated in
@@ -274,8 +294,9 @@ def main():
     flops_per_launch = 2.0 * (B / chains) * F * N
     launch_us = (sum(cell_ms) / len(cell_ms)) * 1e3 / n_launch
     ach = flops_per_launch / (launch_us * 1e-6) / 1e12
+    traffic, traffic_src = pmc_traffic()
     roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": traffic_src,
             "kernel": "cell_a_kernel / cell_b_kernel (mean over the 2K-1 launches of a frame)",
             "launch_us": launch_us, "flops_per_launch": flops_per_launch,
             "concurrent_chains": chains}

@@ -163,20 +163,21 @@ __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
     const int clast = a.nchunks - 1;
     f32x4 av[G][KS];
     f32x2 bv[G][4];
-    auto load_group = [&](int base) {
+    auto load_chunk = [&](int base, int g) {
+        int c = w + 4 * (base + g);
+        c = c > clast ? clast : c;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            int c = w + 4 * (base + g);
-            c = c > clast ? clast : c;
+        for (int ks = 0; ks < KS; ++ks)
+            av[g][ks] = *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                av[g][ks] = *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
-        }
+        for (int s = 0; s < 4; ++s)
+            bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
     };
-    load_group(0);
+    // same software pipeline as the forward's cell_a_kernel: operand loads run PF chunks ahead
+    // of the MFMAs
+    constexpr int PF = G < 3 ? G : 3;
+#pragma unroll
+    for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
     const int cnt = *a.c_rd;
     if (a.c_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.c_wr = cnt + 1;
@@ -193,34 +194,41 @@ __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
         if (rg < a.B && n + e < a.N)
             hprev[e] = a.hall[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n + e];
 
-    auto compute_group = [&](int base) {
+    // The summed d r_k of this row tile goes out row-major for the weight gradients.  Every
+    // workgroup of the row tile holds all of it; chunk c is stored by atom block c mod numA so
+    // that no single workgroup carries the whole copy (it used to be block 0: the launch then
+    // waited for that one straggler).
+    float* const dr_row = a.dR + ((size_t)(row0 + j) * a.T + t) * Fp + q;
+    const bool dr_lane = row0 + j < a.B;
+    auto compute_chunk = [&](int base, int g) {
+        f32x4 r4 = av[g][0];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            f32x4 r4 = av[g][0];
+        for (int ks = 1; ks < KS; ++ks) r4 += av[g][ks];
+        const bool ok = base + g < per_wave;
+        if (!ok) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = w + 4 * (base + g);
+        if (live && ok && (c % a.numA) == ab && dr_lane) {
 #pragma unroll
-            for (int ks = 1; ks < KS; ++ks) r4 += av[g][ks];
-            const bool ok = base + g < per_wave;
-            if (!ok) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (blockIdx.x == 0 && ok && row0 + j < a.B) {
-                // the summed d r_k of this row tile goes out row-major for the weight gradients
-                const int c = w + 4 * (base + g);
-                float* dr = a.dR + ((size_t)(row0 + j) * a.T + t) * Fp + 16 * c + q;
+            for (int s = 0; s < 4; ++s) dr_row[16 * c + 4 * s] = r4[s];
+        }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) dr[4 * s] = r4[s];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc0 = mfma16(r4[s], bv[g][s][0], acc0);
-                acc1 = mfma16(r4[s], bv[g][s][1], acc1);
-            }
+        for (int s = 0; s < 4; ++s) {
+            acc0 = mfma16(r4[s], bv[g][s][0], acc0);
+            acc1 = mfma16(r4[s], bv[g][s][1], acc1);
         }
     };
-    __builtin_amdgcn_sched_barrier(0);
-    compute_group(0);
-    for (int base = G; base < per_wave; base += G) {
-        load_group(base);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_group(base);
+    for (int base = 0; base < per_wave; base += G) {
+        if (base > 0) {
+#pragma unroll
+            for (int g = 0; g < PF; ++g) load_chunk(base, g);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g + PF < G) load_chunk(base, g + PF);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_chunk(base, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
 #pragma unroll
