@@ -326,18 +326,30 @@ struct EpiP2 {      // partial[split] -= acc
 };
 
 // d log_D (+)= Dn * (dDn - Dn * c),  c[n] = sum_f dDn[f][n] Dn[f][n],  dDn = sum of the partials
+// Workgroup = 32 atoms x 8 bin groups (bins f = fg mod 8); the column sums c are combined through
+// LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256)
 dlogd_kernel(const float* __restrict__ P, const float* __restrict__ Dn, float* __restrict__ dlogD,
              int F, int N, int Np, int splits, size_t stride, int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float cs[8][32];
+    const int ln = threadIdx.x & 31, fg = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + ln;
+    const bool ok = n < N;
     float c = 0.f;
-    for (int f = 0; f < F; ++f) {
-        float g = 0.f;
-        for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)f * Np + n];
-        c = fmaf(g, Dn[(size_t)f * Np + n], c);
+    if (ok) {
+        for (int f = fg; f < F; f += 8) {
+            float g = 0.f;
+            for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)f * Np + n];
+            c = fmaf(g, Dn[(size_t)f * Np + n], c);
+        }
     }
-    for (int f = 0; f < F; ++f) {
+    cs[fg][ln] = c;
+    __syncthreads();
+    if (!ok) return;
+    c = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c += cs[i][ln];
+    for (int f = fg; f < F; f += 8) {
         float g = 0.f;
         for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)f * Np + n];
         const float dn = Dn[(size_t)f * Np + n];
@@ -376,10 +388,11 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const ColRedArgs a) {
         h0v = (z > 20.f) ? z : log1pf(expf(z));
     }
     float sb = 0.f, sg = 0.f;
+    int b = (int)(r0 / a.T), t = (int)(r0 % a.T) - 1;
     for (int64_t bt = r0; bt < r1; ++bt) {
+        if (++t == a.T) { t = 0; ++b; }
         const float dz = a.dz_all[bt * KN + (size_t)a.k * a.N + n];
         if (dz == 0.f) continue;
-        const int b = (int)(bt / a.T), t = (int)(bt % a.T);
         const float ps = a.psum_all[(size_t)t * a.Bp + b];
         const float hk = a.hall[bt * KN + (size_t)a.k * a.N + n];
         float base;
@@ -665,7 +678,7 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
             DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, TN_SPLITS, stream));
         }
         const int kd = d->n_D == 1 ? 0 : k;
-        hipLaunchKernelGGL(dlogd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, P, Dn_rm,
+        hipLaunchKernelGGL(dlogd_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, P, Dn_rm,
                            d_log_D + (size_t)kd * F * N, F, N, W.Np, TN_SPLITS, pstr,
                            (d->n_D == 1 && k > 0) ? 1 : 0);
         ColRedArgs ca;

@@ -98,6 +98,9 @@ def test_prepare_params_matches_oracle(dev):
     dict(B=1, T=12, F=513, r=100, K=10, untied=()),                  # BASELINE config 1 shape
     dict(B=2, T=3, F=1025, r=24, K=2),                               # F > one operand group
     dict(B=3, T=4, F=21, r=6, K=3, untied=("log_D", "log_alph", "log_lam1")),
+    dict(B=2, T=2, F=1025, r=4000, K=3, alph=1600.0),                # BASELINE config 5 width
+    dict(B=33, T=2, F=514, r=17, K=2),                               # two tail bins, odd r, 3 row tiles
+    dict(B=2, T=3, F=16, r=1, K=2),                                  # N = 2: a single atom pair
 ])
 def test_cell_forward_matches_oracle(dev, cfg):
     cfg = dict(cfg)
