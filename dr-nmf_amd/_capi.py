@@ -67,6 +67,9 @@ SIGNATURES = {
     "drnmf_istft_masked": (_i32, [_vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz,
                                   _vp]),
     "drnmf_snr": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "drnmf_sdr_workspace_bytes": (_sz, [_i32, _i64, _i32]),
+    "drnmf_sdr_corr": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "drnmf_sdr_project": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -2,6 +2,8 @@
 enqueues hand-written HIP kernels on torch's current stream through libdrnmf.so."""
 import ctypes as C
 
+import numpy as np
+
 import torch
 
 from . import _capi
@@ -420,6 +422,45 @@ def snr_db(est, ref):
     rc = L.drnmf_snr(h, n_sig, nsampl, _capi.ptr(est), _capi.ptr(ref), _capi.ptr(out), _stream())
     _capi.check(rc, h, "drnmf_snr")
     return out
+
+
+def sdr_db(est, ref, flen=512, return_parts=False):
+    """SDR per signal as `bss_eval_sources(xest', xref')` computes it for one source
+    (score_audio.m:206; BSS Eval 3.0, 512-tap time-invariant filters).  Correlations, the
+    projection and the energies run on the device in fp64; the flen x flen Toeplitz normal
+    equations are solved on the host (numpy fp64), one system per signal."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(est))
+    est, ref = _f32c(est, "est"), _f32c(ref, "ref")
+    if est.dim() == 1:
+        est, ref = est[None], ref[None]
+    if est.shape != ref.shape:
+        raise ValueError("est and ref must have the same shape")
+    n_sig, nsampl = est.shape
+    dev = est.device
+    f64 = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+    r, d, coef, en = f64(n_sig, flen), f64(n_sig, flen), f64(n_sig, flen), f64(n_sig, 2)
+    out = torch.empty(n_sig, dtype=torch.float32, device=dev)
+    nbytes = L.drnmf_sdr_workspace_bytes(n_sig, nsampl, flen)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    rc = L.drnmf_sdr_corr(h, n_sig, nsampl, flen, _capi.ptr(est), _capi.ptr(ref), _capi.ptr(r),
+                          _capi.ptr(d), _capi.ptr(ws), ws.numel(), _stream())
+    _capi.check(rc, h, "drnmf_sdr_corr")
+    rh, dh = r.cpu().numpy(), d.cpu().numpy()
+    idx = np.abs(np.arange(flen)[:, None] - np.arange(flen)[None, :])
+    ch = np.empty_like(dh)
+    for i in range(n_sig):
+        G = rh[i][idx]
+        try:
+            ch[i] = np.linalg.solve(G, dh[i])
+        except np.linalg.LinAlgError:          # silent reference: any solution of G c = d
+            ch[i] = np.linalg.lstsq(G, dh[i], rcond=None)[0]
+    coef.copy_(torch.from_numpy(ch))
+    rc = L.drnmf_sdr_project(h, n_sig, nsampl, flen, _capi.ptr(est), _capi.ptr(ref),
+                             _capi.ptr(coef), _capi.ptr(en), _capi.ptr(out), _capi.ptr(ws),
+                             ws.numel(), _stream())
+    _capi.check(rc, h, "drnmf_sdr_project")
+    return (out, coef, en) if return_parts else out
 
 
 def to_int16_wav(x):

@@ -237,6 +237,27 @@ int32_t drnmf_istft_masked(drnmf_handle_t h, int32_t n_sig, int32_t n_frames, in
 int32_t drnmf_snr(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, const float* est,
                   const float* ref, float* out_db, void* stream);
 
+/* ---- SDR per signal: replaces `SDR=bss_eval_sources(xest',xref')` with one source
+ * (score_audio.m:206).  BSS Eval 3.0 is a third-party toolbox fetched by download_toolboxes.sh and
+ * absent from the reference tree (parity pinned to the published definition only): the estimate,
+ * zero-padded by flen-1 samples (toolbox: flen = 512), is projected onto the span of the reference
+ * delayed by 0..flen-1 samples.  Two device stages around a host solve of the flen x flen Toeplitz
+ * normal equations (fp64):
+ *   drnmf_sdr_corr     r[sig][a] = sum_n ref[n] ref[n-a],  d[sig][a] = sum_n est[n] ref[n-a]
+ *   (host)             coef[sig] = Toeplitz(r[sig])^-1 d[sig]
+ *   drnmf_sdr_project  s = coef * ref;  energies[sig] = {sum s^2, sum (est - s)^2};
+ *                      out_db[sig] = 10 log10(energies[0] / energies[1])
+ * est, ref [n_sig][nsampl] float32 (trailing zero padding of ragged batches is exact);
+ * r, d, coef [n_sig][flen] and energies [n_sig][2] are float64 device buffers; flen <= 2048. */
+size_t drnmf_sdr_workspace_bytes(int32_t n_sig, int64_t nsampl, int32_t flen);
+int32_t drnmf_sdr_corr(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32_t flen,
+                       const float* est, const float* ref, double* r_out, double* d_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int32_t drnmf_sdr_project(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32_t flen,
+                          const float* est, const float* ref, const double* coef,
+                          double* energies, float* out_db, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -603,3 +603,44 @@ def reconstruct(re, im, mask, hop, window, nsampl=None, dtype=np.float64):
 def snr_db(est, ref):
     """score_audio.m:209."""
     return 10.0 * np.log10(np.sum(ref ** 2) / np.sum((ref - est) ** 2))
+
+
+def sdr_corr(est, ref, flen=512):
+    """Lagged correlations the SDR projection needs (fp64): r[a] = sum_n ref[n] ref[n-a],
+    d[a] = sum_n est[n] ref[n-a], a = 0..flen-1, via zero-padded FFTs as BSS Eval does."""
+    est = np.asarray(est, np.float64)
+    ref = np.asarray(ref, np.float64)
+    n = est.shape[0]
+    nfft = 1 << int(np.ceil(np.log2(n + flen - 1)))
+    sf = np.fft.rfft(ref, nfft)
+    ef = np.fft.rfft(est, nfft)
+    r = np.fft.irfft(sf * np.conj(sf), nfft)[:flen]
+    d = np.fft.irfft(ef * np.conj(sf), nfft)[:flen]
+    return r, d
+
+
+def sdr_db(est, ref, flen=512, return_parts=False):
+    """SDR of `bss_eval_sources(xest', xref')` with ONE source (score_audio.m:206).  BSS Eval 3.0
+    is a third-party Matlab toolbox fetched by download_toolboxes.sh and absent from the reference
+    tree: PARITY UNPINNED.  Restated from the published definition (Vincent, Gribonval, Fevotte,
+    IEEE TASLP 14(4), 2006; toolbox v3.0 uses time-invariant filters of 512 taps): the estimate is
+    zero-padded by flen-1 samples and projected onto the span of the reference delayed by
+    0..flen-1 samples,
+        s_target = sum_a C[a] ref[n-a],   C = G^-1 d,  G[a,b] = r[|a-b|]   (Toeplitz normal eqs)
+        SDR = 10 log10( |s_target|^2 / |est - s_target|^2 )
+    (with a single source the interference term is identically zero)."""
+    est = np.asarray(est, np.float64)
+    ref = np.asarray(ref, np.float64)
+    n = est.shape[0]
+    r, d = sdr_corr(est, ref, flen)
+    idx = np.abs(np.arange(flen)[:, None] - np.arange(flen)[None, :])
+    G = r[idx]
+    try:
+        C = np.linalg.solve(G, d)
+    except np.linalg.LinAlgError:
+        C = np.linalg.lstsq(G, d, rcond=None)[0]
+    sp = np.convolve(ref, C)[:n + flen - 1]
+    e = np.concatenate([est, np.zeros(flen - 1)]) - sp
+    num, den = float(np.sum(sp * sp)), float(np.sum(e * e))
+    out = 10.0 * np.log10(num / den)
+    return (out, C, num, den) if return_parts else out

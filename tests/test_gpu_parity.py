@@ -439,3 +439,36 @@ def test_stateful_cell_carries_state_across_batches(dev):
     assert float(cell.states[0].abs().max()) == 0.0
     h1b = cell(x[:, :4].contiguous()).cpu().numpy()
     np.testing.assert_array_equal(h1, h1b)
+
+
+@pytest.mark.parametrize("nsampl,flen", [(3000, 64), (16000, 512), (777, 512)])
+def test_sdr_vs_oracle(dev, nsampl, flen):
+    """SDR of bss_eval_sources with one source (score_audio.m:206; BSS Eval 3.0 absent from the
+    reference tree -> pinned to the published definition, oracle.sdr_db)."""
+    from drnmf_amd import ops
+    rng = np.random.default_rng(nsampl)
+    n_sig = 3
+    # speech-like coloured references (AR(2)), estimates = filtered reference + noise
+    ref = np.zeros((n_sig, nsampl), np.float32)
+    est = np.zeros((n_sig, nsampl), np.float32)
+    for s in range(n_sig):
+        w = rng.standard_normal(nsampl)
+        x = np.zeros(nsampl)
+        for i in range(nsampl):
+            x[i] = w[i] + (1.3 * x[i - 1] if i > 0 else 0.0) - (0.6 * x[i - 2] if i > 1 else 0.0)
+        ref[s] = (0.1 * x).astype(np.float32)
+        est[s] = (np.convolve(ref[s], [0.8, 0.1, -0.05])[:nsampl] +
+                  0.02 * (s + 1) * rng.standard_normal(nsampl)).astype(np.float32)
+    ref[2, nsampl - 100:] = 0.0          # a zero-padded (shorter) signal in the batch
+    est[2, nsampl - 100:] = 0.0
+    out, coef, en = ops.sdr_db(torch.from_numpy(est).to(dev), torch.from_numpy(ref).to(dev),
+                               flen=flen, return_parts=True)
+    torch.cuda.synchronize()
+    out, en = out.cpu().numpy(), en.cpu().numpy()
+    for s in range(n_sig):
+        want, C, num, den = O.sdr_db(est[s], ref[s], flen, return_parts=True)
+        assert abs(out[s] - want) <= 1e-3, (s, out[s], want)          # dB
+        np.testing.assert_allclose(en[s], [num, den], rtol=1e-6)
+    # correlations alone (no solve): exact to fp64 rounding of different summation orders
+    want2 = O.sdr_db(est[2, :nsampl - 100], ref[2, :nsampl - 100], flen)
+    assert abs(out[2] - want2) <= 1e-3                                # padding changes nothing

@@ -219,3 +219,24 @@ def test_torch_autograd_restatement_matches_numpy_oracle():
     np.testing.assert_allclose(float(loss), O.loss_mse_of_masked(P["X"].astype(np.float64), mref,
                                                                  P["Y"].astype(np.float64), w),
                                rtol=1e-12)
+
+
+def test_sdr_oracle_is_the_least_squares_projection():
+    """The FFT/Toeplitz restatement of the BSS Eval criterion equals the textbook definition:
+    least-squares projection of the zero-padded estimate on the delayed references."""
+    rng = np.random.default_rng(0)
+    n, flen = 400, 16
+    ref = rng.standard_normal(n)
+    est = np.convolve(ref, rng.standard_normal(5))[:n] * 0.7 + 0.3 * rng.standard_normal(n)
+    A = np.zeros((n + flen - 1, flen))
+    for a in range(flen):
+        A[a:a + n, a] = ref
+    y = np.concatenate([est, np.zeros(flen - 1)])
+    sp = A @ np.linalg.lstsq(A, y, rcond=None)[0]
+    want = 10 * np.log10(np.sum(sp ** 2) / np.sum((y - sp) ** 2))
+    assert abs(O.sdr_db(est, ref, flen) - want) < 1e-9
+    # invariances of the criterion: gain and a short delay/filter of the estimate cost nothing
+    assert abs(O.sdr_db(3.0 * est, ref, flen) - want) < 1e-9
+    clean = np.convolve(ref, [0.0, 0.0, 0.5, 0.25])[:n]
+    assert O.sdr_db(clean, ref, flen) > 25.0          # only the truncated tail counts as error
+    assert O.sdr_db(est, ref, flen) >= O.snr_db(est, ref) - 1e-9
