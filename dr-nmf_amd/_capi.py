@@ -42,6 +42,9 @@ SIGNATURES = {
     "drnmf_head_forward": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp,
                                   _vp, _vp, _vp, _vp]),
     "drnmf_loss_head_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "drnmf_snmf_cost_head_backward": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp,
+                                             _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz,
+                                             _vp]),
     "drnmf_loss_head_backward": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                         _vp]),

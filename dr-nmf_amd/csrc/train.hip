@@ -73,6 +73,63 @@ loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ mask,
     }
 }
 
+// SNMF-cost pretraining loss (enhance.py:1023-1035): outputs [x_recon = A + Bn, h], targets [x, x],
+// losses ['mse', mean|h|] with weights [0.5, lam1*N/F]  ==  (0.5 |x - x_recon|^2 + lam1 |h|_1) / F
+// per frame.  dA = dBn = w (x_recon - x) / F; the |h|_1 part of d hidden is added by l1_add_kernel.
+__global__ void __launch_bounds__(256)
+snmf_cost_grad_kernel(const float* __restrict__ x, const float* __restrict__ A,
+                      const float* __restrict__ Bn, const float* __restrict__ hidden,
+                      int64_t ld_h, const float* __restrict__ w, float* __restrict__ dA,
+                      float* __restrict__ dBn, float* __restrict__ part, int64_t rows, int F,
+                      int Fp4, int N2, float l1_weight) {
+    __shared__ float ssum[4], scnt[4];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    float acc = 0.f, cnt = 0.f;
+    if (row < rows) {
+        const float wt = w[row];
+        const float invF = 1.f / (float)F;
+        for (int f = l; f < Fp4; f += 64) {
+            float d = 0.f;
+            if (f < F) {
+                const size_t o = (size_t)row * F + f;
+                const float err = A[o] + Bn[o] - x[o];
+                acc += 0.5f * wt * err * err * invF;
+                d = wt * err * invF;
+            }
+            dA[(size_t)row * Fp4 + f] = d;
+            dBn[(size_t)row * Fp4 + f] = d;
+        }
+        float hs = 0.f;
+        for (int n = l; n < N2; n += 64) hs += fabsf(hidden[(size_t)row * ld_h + n]);
+        acc += wt * l1_weight * hs / (float)N2;
+        cnt = (l == 0 && wt != 0.f) ? 1.f : 0.f;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    if (l == 0) { ssum[wv] = acc; scnt[wv] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * (size_t)blockIdx.x + 0] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        part[2 * (size_t)blockIdx.x + 1] = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
+    }
+}
+
+// d hidden[row][n] += w[row] * coef * sign(h)   (h >= 0 in this model; sign(0) = 0 as Theano's abs)
+__global__ void __launch_bounds__(256)
+l1_add_kernel(float* __restrict__ d_hidden, const float* __restrict__ hidden, int64_t ld_h,
+              const float* __restrict__ w, int64_t rows, int N2, float coef) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * N2) return;
+    const int64_t row = i / N2;
+    const int n = (int)(i - row * N2);
+    const float hv = hidden[(size_t)row * ld_h + n];
+    const float sg = hv > 0.f ? 1.f : (hv < 0.f ? -1.f : 0.f);
+    d_hidden[i] += w[row] * coef * sg;
+}
+
 __global__ void __launch_bounds__(256)
 final_sums_kernel(const float* __restrict__ part, int64_t nblocks, float* __restrict__ sums) {
     __shared__ double s0[256], s1[256];
@@ -174,6 +231,30 @@ LhWs lh_layout(int64_t rows, int F, int r) {
     return L;
 }
 
+// d hidden = [dA E_c^T | dBn E_n^T],  d kernel = (hidden^T dX) * E  for the two reconstruction layers
+int32_t head_backward_gemms(drnmf_handle_t h, int64_t rows, int F, int r, const float* hidden,
+                            int64_t ld_h, int h_off, const float* dA, const float* dB,
+                            const float* E, float* P, int Fp4, float* d_hidden,
+                            float* d_kernel_clean, float* d_kernel_noise, hipStream_t stream) {
+    const int N2 = 2 * r;
+    for (int seg = 0; seg < 2; ++seg) {
+        const float* dX = seg ? dB : dA;
+        const float* Es = E + (size_t)seg * r * Fp4;
+        // d hidden[:, seg*r + n] = sum_f dX[row][f] E[n][f]
+        gemm::Operands g1{dX, Es, rows, r, Fp4, Fp4, Fp4};
+        DRNMF_HIP(h, gemm::launch(g1, EpiStoreOff{d_hidden, N2, seg * r}, stream));
+        // dE[n][f] = sum_rows hidden[row][seg*r + n] dX[row][f];  dK = dE * E
+        gemm_tn::Operands t1{hidden + h_off + (size_t)seg * r, dX, rows, r, Fp4, ld_h, Fp4};
+        const size_t pstr = (size_t)r * Fp4;
+        DRNMF_HIP(h, gemm_tn::launch(t1, EpiPart{P, Fp4, pstr}, HB_SPLITS, stream));
+        const size_t tot = (size_t)r * F;
+        hipLaunchKernelGGL(dkernel_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                           P, Es, seg ? d_kernel_noise : d_kernel_clean, r, F, Fp4, HB_SPLITS, pstr);
+    }
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
 }  // namespace
 
 extern "C" size_t drnmf_loss_head_workspace_bytes(int64_t rows, int32_t F, int32_t r) {
@@ -217,21 +298,54 @@ extern "C" int32_t drnmf_loss_head_backward(drnmf_handle_t h, int64_t rows, int3
                        mask, A, Bn, y, w, dA, dB, part, rows, F, Fp4, square);
     hipLaunchKernelGGL(final_sums_kernel, dim3(1), dim3(256), 0, stream, part, L.nblocks, sums);
     DRNMF_HIP(h, hipGetLastError());
-    const int N2 = 2 * r;
-    for (int seg = 0; seg < 2; ++seg) {
-        const float* dX = seg ? dB : dA;
-        const float* Es = E + (size_t)seg * r * Fp4;
-        // d hidden[:, seg*r + n] = sum_f dX[row][f] E[n][f]
-        gemm::Operands g1{dX, Es, rows, r, Fp4, Fp4, Fp4};
-        DRNMF_HIP(h, gemm::launch(g1, EpiStoreOff{d_hidden, N2, seg * r}, stream));
-        // dE[n][f] = sum_rows hidden[row][seg*r + n] dX[row][f];  dK = dE * E
-        gemm_tn::Operands t1{hidden + h_off + (size_t)seg * r, dX, rows, r, Fp4, ld_h, Fp4};
-        const size_t pstr = (size_t)r * Fp4;
-        DRNMF_HIP(h, gemm_tn::launch(t1, EpiPart{P, Fp4, pstr}, HB_SPLITS, stream));
-        const size_t tot = (size_t)r * F;
-        hipLaunchKernelGGL(dkernel_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
-                           P, Es, seg ? d_kernel_noise : d_kernel_clean, r, F, Fp4, HB_SPLITS, pstr);
+    return head_backward_gemms(h, rows, F, r, hidden, ld_h, h_off, dA, dB, E, P, Fp4, d_hidden,
+                               d_kernel_clean, d_kernel_noise, stream);
+}
+
+extern "C" int32_t drnmf_snmf_cost_head_backward(drnmf_handle_t h, int64_t rows, int32_t F,
+                                                 int32_t r, const float* x_raw,
+                                                 const float* hidden, int64_t ld_h, int32_t h_off,
+                                                 const float* kernel_clean,
+                                                 const float* kernel_noise, const float* A,
+                                                 const float* Bn, const float* w, float l1_weight,
+                                                 float* sums, float* d_hidden,
+                                                 float* d_kernel_clean, float* d_kernel_noise,
+                                                 void* workspace, size_t workspace_bytes,
+                                                 void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (rows <= 0 || F <= 0 || r <= 0 || h_off < 0 || ld_h < h_off + 2 * (int64_t)r)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "snmf_cost_head_backward: bad shape");
+    if (!x_raw || !hidden || !kernel_clean || !kernel_noise || !A || !Bn || !w || !sums ||
+        !d_hidden || !d_kernel_clean || !d_kernel_noise || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "snmf_cost_head_backward: NULL pointer argument");
+    const LhWs L = lh_layout(rows, F, r);
+    if (workspace_bytes < L.total)
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "snmf_cost_head_backward: workspace %zu < required %zu",
+                   workspace_bytes, L.total);
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float* E = (float*)(ws + L.off_E);
+    float* dA = (float*)(ws + L.off_dA);
+    float* dB = (float*)(ws + L.off_dB);
+    float* part = (float*)(ws + L.off_part);
+    float* P = (float*)(ws + L.off_P);
+    const int Fp4 = L.Fp4, N2 = 2 * r;
+    {
+        const size_t tot = (size_t)2 * r * Fp4;
+        hipLaunchKernelGGL(exp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                           stream, kernel_clean, kernel_noise, E, r, F, Fp4);
     }
+    hipLaunchKernelGGL(snmf_cost_grad_kernel, dim3((unsigned)L.nblocks), dim3(256), 0, stream,
+                       x_raw, A, Bn, hidden + h_off, ld_h, w, dA, dB, part, rows, F, Fp4, N2,
+                       l1_weight);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(1), dim3(256), 0, stream, part, L.nblocks, sums);
+    DRNMF_HIP(h, hipGetLastError());
+    const int32_t rc = head_backward_gemms(h, rows, F, r, hidden, ld_h, h_off, dA, dB, E, P, Fp4,
+                                           d_hidden, d_kernel_clean, d_kernel_noise, stream);
+    if (rc != DRNMF_OK) return rc;
+    const int64_t tot = rows * N2;
+    hipLaunchKernelGGL(l1_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                       d_hidden, hidden + h_off, ld_h, w, rows, N2, l1_weight / (float)N2);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }

@@ -635,6 +635,109 @@ class UnfoldedSNMFModel(object):
         return hist
 
 
+def l1_of_output(y_true=None, y_pred=None):
+    """Marker for the second pretraining loss, `K.mean(K.abs(y_pred), axis=-1)` (enhance.py:1027)."""
+    raise NotImplementedError("l1_of_output is evaluated on the device inside "
+                              "SNMFCostPretrainModel; pass it to compile(loss=[...]) only")
+
+
+class SNMFCostPretrainModel(UnfoldedSNMFModel):
+    """enhance.py:1023-1035: `model_pretrain = Model(inputs=model.input, outputs=[x_recon,
+    h_estimated])` with x_recon = clean_est + noise_est and h_estimated the cell output, compiled
+    with loss ['mse', l1_of_output] and loss_weights [0.5, lam1*2r/input_dim], fitted on
+    (x, [x, x]) with sample_weight [mask, mask] (enhance.py:1110-1115).  Shares every weight tensor
+    with the model it was made from, so after pretraining `model` already holds the weights
+    (the reference reloads them from the checkpoint, enhance.py:1118-1119)."""
+
+    def __init__(self, model):
+        if model.square:
+            raise NotImplementedError("pretrain_with_snmf_cost is defined by layer indices that "
+                                      "assume no transform_before_irm (enhance.py:1024-1025)")
+        UnfoldedSNMFModel.__init__(self, model.layers, model.cell, model.clean, model.noise,
+                                   model.mask_value, False)
+        self.loss_weights = None
+
+    def compile(self, loss=('mse', l1_of_output), loss_weights=None, **kw):
+        loss = list(loss)
+        if len(loss) != 2 or loss[0] != 'mse' or loss[1] is not l1_of_output:
+            raise NotImplementedError("pretraining loss must be ['mse', l1_of_output]")
+        if loss_weights is None or len(loss_weights) != 2:
+            raise ValueError("loss_weights=[0.5, lam1*2r/input_dim] is required (enhance.py:1035)")
+        if abs(float(loss_weights[0]) - 0.5) > 1e-12:
+            raise NotImplementedError("the reconstruction loss weight is 0.5 (enhance.py:1035)")
+        self.loss_weights = [float(loss_weights[0]), float(loss_weights[1])]
+        return UnfoldedSNMFModel.compile(self, loss='mse', **kw)
+
+    @staticmethod
+    def _first(a):
+        return a[0] if isinstance(a, (list, tuple)) else a
+
+    def forward(self, x, want_hidden=False):
+        """-> [x_recon, h_estimated]"""
+        h = self.cell.call(x, mask_value=self.mask_value)
+        _, A, Bn = ops.head_forward(h, self.clean.kernel, self.noise.kernel, want_ab=True)
+        return [A + Bn, h]
+
+    def predict_on_batch(self, x):
+        xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.cell.device)
+        return [o.cpu().numpy() for o in self.forward(xt)]
+
+    def loss_and_grads(self, x, y, sample_weight):
+        cell = self.cell
+        N, K = cell.output_dim, cell.K_layers
+        hall = cell.forward_train(x, mask_value=self.mask_value)
+        h_off = (K - 1) * N
+        _, A, Bn = ops.head_forward(hall, self.clean.kernel, self.noise.kernel, want_ab=True,
+                                    h_off=h_off)
+        # the targets are the input itself (enhance.py:1110); y is accepted for API symmetry
+        sums, d_hidden, dkc, dkn = ops.snmf_cost_head_backward(
+            self._first(y), hall, self.clean.kernel, self.noise.kernel, A, Bn,
+            self._first(sample_weight), self.loss_weights[1], h_off=h_off)
+        g = cell.backward(x, hall, d_hidden)
+        self._flat.zero_()
+        gv = self._gview
+        gv['log_h0'].copy_(g['d_log_h0'])
+        for wname, gkey, idx in cell.grad_slices():
+            if wname in gv:
+                gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
+        gv['kernel_clean'].copy_(dkc)
+        gv['kernel_noise'].copy_(dkn)
+        self._flat[-2:].copy_(sums)
+        return self._flat
+
+    def train_on_batch(self, x, y=None, sample_weight=None):
+        y = x if y is None else self._first(y)
+        return UnfoldedSNMFModel.train_on_batch(self, x, y, self._first(sample_weight))
+
+    def test_on_batch(self, x, y=None, sample_weight=None):
+        from . import dp
+        dev = self.cell.device
+        tt = lambda a: a if isinstance(a, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        x = tt(x)
+        y = x if y is None else tt(self._first(y))
+        sw = self._first(sample_weight)
+        w = tt(sw) if sw is not None else torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
+        xr, h = self.forward(x)
+        per = 0.5 * ((xr - y) ** 2).mean(-1) + self.loss_weights[1] * h.abs().mean(-1)
+        s = torch.stack([(per * w).sum(), (w != 0).float().sum()])
+        dp.allreduce_sum_(s)
+        return float(s[0]) / max(float(s[1]), 1.0)
+
+    def fit(self, x, y=None, sample_weight=None, validation_data=None, **kw):
+        y = x if y is None else self._first(y)
+        if validation_data is not None:
+            xv, yv, wv = validation_data
+            validation_data = (xv, self._first(yv), self._first(wv))
+        return UnfoldedSNMFModel.fit(self, x, y, sample_weight=self._first(sample_weight),
+                                     validation_data=validation_data, **kw)
+
+
+def make_pretrain_model(model):
+    """The `model_pretrain` of enhance.py:1023-1026 for `model = build_unfolded_snmf(...)`."""
+    return SNMFCostPretrainModel(model)
+
+
 def build_unfolded_snmf(params_unfolded_snmf, device=None):
     """enhance.py:209-317 with the same parameter dictionary keys."""
     p = params_unfolded_snmf

@@ -193,6 +193,36 @@ def loss_head_backward(x_raw, hidden, kernel_clean, kernel_noise, mask, A, Bn, y
     return sums, d_hidden, dkc, dkn
 
 
+def snmf_cost_head_backward(x_raw, hidden, kernel_clean, kernel_noise, A, Bn, w, l1_weight,
+                            h_off=0):
+    """Unnormalised SNMF-cost pretraining loss + head gradients (drnmf_snmf_cost_head_backward):
+    per frame 0.5*mean_f (A+Bn-x)^2 + l1_weight*mean_n |h|.  Same returns as loss_head_backward."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(hidden))
+    x_raw, hidden, A, Bn, w = (_f32c(t, n) for t, n in
+                               ((x_raw, "x_raw"), (hidden, "hidden"), (A, "A"), (Bn, "Bn"),
+                                (w, "w")))
+    kc, kn = _f32c(kernel_clean, "kernel_clean"), _f32c(kernel_noise, "kernel_noise")
+    r, F = kc.shape
+    ld = hidden.shape[-1]
+    rows = hidden.numel() // ld
+    if x_raw.numel() != rows * F or w.numel() != rows or A.numel() != rows * F:
+        raise ValueError("snmf_cost_head_backward: shape mismatch")
+    dev = hidden.device
+    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    d_hidden = torch.empty(tuple(hidden.shape[:-1]) + (2 * r,), dtype=torch.float32, device=dev)
+    dkc, dkn = torch.empty_like(kc), torch.empty_like(kn)
+    nbytes = L.drnmf_loss_head_workspace_bytes(rows, F, r)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rc = L.drnmf_snmf_cost_head_backward(h, rows, F, r, _capi.ptr(x_raw), _capi.ptr(hidden), ld,
+                                         int(h_off), _capi.ptr(kc), _capi.ptr(kn), _capi.ptr(A),
+                                         _capi.ptr(Bn), _capi.ptr(w), float(l1_weight),
+                                         _capi.ptr(sums), _capi.ptr(d_hidden), _capi.ptr(dkc),
+                                         _capi.ptr(dkn), _capi.ptr(ws), nbytes, _stream())
+    _capi.check(rc, h, "drnmf_snmf_cost_head_backward")
+    return sums, d_hidden, dkc, dkn
+
+
 def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=None):
     """BPTT through the cell (forward must have been run with return_all_hidden=True on the same
     workspace).  Returns dict(d_log_D [n_D,F,N], d_log_alph [n_alph,alph_len], d_log_lam1 [n_lam],

@@ -144,6 +144,22 @@ int32_t drnmf_loss_head_backward(drnmf_handle_t h, int64_t rows, int32_t F, int3
                                  float* d_kernel_noise, void* workspace, size_t workspace_bytes,
                                  void* stream);
 
+/* ---- optional pretraining with the SNMF cost (enhance.py:1023-1035, 1089-1119): the reference's
+ * `model_pretrain` has outputs [x_recon = clean_est + noise_est, h_estimated], targets [x, x],
+ * losses ['mse', mean_n |h|] and loss weights [0.5, lam1*N/F], i.e. per frame
+ * (0.5 |x - x_recon|^2 + lam1 |h|_1) / F.  Same conventions as drnmf_loss_head_backward
+ * (unnormalised gradients, sums = {sum_rows w * loss_row, #rows with w != 0});
+ * l1_weight = lam1 * N / F (the second Keras loss weight).  Not defined for
+ * transform_before_irm = 'square' (the reference's layer indices then point elsewhere). */
+int32_t drnmf_snmf_cost_head_backward(drnmf_handle_t h, int64_t rows, int32_t F, int32_t r,
+                                      const float* x_raw, const float* hidden, int64_t ld_h,
+                                      int32_t h_off, const float* kernel_clean,
+                                      const float* kernel_noise, const float* A, const float* Bn,
+                                      const float* w, float l1_weight, float* sums,
+                                      float* d_hidden, float* d_kernel_clean,
+                                      float* d_kernel_noise, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+
 /* ---- training: BPTT through the recurrent cell.  Replaces Theano's autodiff of the scan
  * (enhance.py:1071-1073, 1152).  Requires the forward to have been run with
  * return_all_hidden = 1 on the same x / params / workspace:

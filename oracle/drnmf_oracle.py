@@ -268,6 +268,20 @@ def loss_mse_of_masked(x_raw, mask_pred, y_true, weights, norm='masked_mean'):
     return np.mean(score)
 
 
+def loss_snmf_cost(x_raw, A, Bn, h, weights, lam1):
+    """Pretraining objective of `model_pretrain` (enhance.py:1023-1035, 1110): outputs
+    [x_recon = A + Bn, h], targets [x, x], losses ['mse', mean_n |h|], loss weights
+    [0.5, lam1 * N / F], temporal sample weights = data mask on both outputs; each output
+    normalised like loss_mse_of_masked(norm='masked_mean').  Equals the masked mean over frames of
+    (0.5 |x - x_recon|^2 + lam1 |h|_1) / F."""
+    F, N = x_raw.shape[-1], h.shape[-1]
+    w = np.asarray(weights, dtype=np.float64)
+    nz = max(np.sum(w != 0), 1)
+    mse = np.mean((A + Bn - x_raw) ** 2, axis=-1)
+    l1 = np.mean(np.abs(h), axis=-1)
+    return float(np.sum(w * (0.5 * mse + lam1 * N / F * l1)) / nz)
+
+
 # --------------------------------------------------------------------------------------------
 # frame-parallel ISTA: enhance.py:385-456 (column convention: x (F,n), W (F,N), H (N,n))
 # --------------------------------------------------------------------------------------------

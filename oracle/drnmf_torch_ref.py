@@ -13,7 +13,7 @@ def unit_cols(logD):
 
 
 def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, square=False,
-               normalise=True):
+               normalise=True, snmf_cost_l1_weight=None):
     """x, y: (B,T,F) float64 tensors; w: (B,T) sample weights (= validity mask in the reference).
     alt: dict name -> tensor (requires_grad where wanted).  Returns (loss, mask, h)."""
     B, T, F = x.shape
@@ -52,7 +52,11 @@ def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, s
     if square:
         A, Bn = A * A, Bn * Bn
     mask = torch.exp(torch.log(EPS + A) - torch.log(EPS + A + Bn))
-    mse = ((x * mask - y) ** 2).mean(-1)                # y_pred = x_raw * mask (enhance.py:1042)
+    if snmf_cost_l1_weight is not None:
+        # pretraining (enhance.py:1023-1035): 0.5*mse(x_recon, y) + l1_weight*mean|h|, y = x
+        mse = 0.5 * ((A + Bn - y) ** 2).mean(-1) + snmf_cost_l1_weight * hs.abs().mean(-1)
+    else:
+        mse = ((x * mask - y) ** 2).mean(-1)            # y_pred = x_raw * mask (enhance.py:1042)
     sse = (mse * w).sum()
     cnt = (w != 0).to(x.dtype).sum()
     loss = sse / cnt if normalise else sse

@@ -45,19 +45,19 @@ def _setup(B, T, F, r, K, untied, untie_alph=False, square=False, seed=5, masked
     return model, P, wmask
 
 
-def _autograd(model, P, wmask, K, square):
+def _autograd(model, P, wmask, K, square, snmf_cost_l1_weight=None):
     names = ["log_h0"] + list(model.cell._alt.keys()) + ["kc", "kn"]
     wd = {n: torch.tensor(a, dtype=torch.float64, requires_grad=True)
           for n, a in zip(names, model.get_weights())}
     alt = {k: wd[k] for k in model.cell._alt.keys()}
     x = torch.tensor(P["X"], dtype=torch.float64)
-    y = torch.tensor(P["Y"], dtype=torch.float64)
+    y = torch.tensor(P["X"] if snmf_cost_l1_weight is not None else P["Y"], dtype=torch.float64)
     w = torch.tensor(wmask, dtype=torch.float64)
     loss, mask, hs = TR.model_loss(x, y, w, alt, model.cell.maps_from_alt.labels_per_k, K,
                                    wd["log_h0"], wd["kc"], wd["kn"], square=square,
-                                   normalise=False)
+                                   normalise=False, snmf_cost_l1_weight=snmf_cost_l1_weight)
     loss.backward()
-    return float(loss), {n: (t.grad.numpy() if t.grad is not None else None)
+    return float(loss.detach()), {n: (t.grad.numpy() if t.grad is not None else None)
                          for n, t in wd.items()}, float((w != 0).sum())
 
 
@@ -118,3 +118,48 @@ def test_train_on_batch_matches_reference_adam_step_and_learns(dev):
     losses = [loss0] + [model.train_on_batch(P["X"], P["Y"], wmask) for _ in range(15)]
     assert losses[-1] < 0.9 * losses[0], losses
     assert abs(model.test_on_batch(P["X"], P["Y"], wmask) - losses[-1]) < 0.2 * losses[-1]
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, T=6, F=21, r=6, K=3, untied=("log_D", "log_alph")),
+    dict(B=4, T=5, F=33, r=8, K=1, untied=()),
+    dict(B=3, T=6, F=40, r=10, K=2, untied=("log_D",), masked_head=True,
+         trainable=("log_D", "log_alph", "log_lam1")),
+])
+def test_snmf_cost_pretraining_gradients_and_fit(dev, cfg):
+    """model_pretrain of enhance.py:1023-1035 (outputs [x_recon, h], losses ['mse', l1_of_output],
+    weights [0.5, lam1*2r/F]) vs autograd of the same objective; then a few epochs of fit() on
+    (x, [x, x]) lower the SNMF cost and leave the weights in the shared DR-NMF model."""
+    from drnmf_amd import layers
+    cfg = dict(cfg)
+    K = cfg["K"]
+    model, P, wmask = _setup(**cfg)
+    F, N = P["X"].shape[-1], 2 * cfg["r"]
+    lam1 = 0.3
+    pre = layers.make_pretrain_model(model)
+    pre.compile(loss=['mse', layers.l1_of_output], loss_weights=[0.5, lam1 * N / F], lr=1e-2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    flat = pre.loss_and_grads(t(P["X"]), t(P["X"]), t(wmask)).clone()
+    torch.cuda.synchronize()
+    ref_loss, ref, cnt = _autograd(model, P, wmask, K, False, snmf_cost_l1_weight=lam1 * N / F)
+    assert abs(float(flat[-2]) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-9
+    assert float(flat[-1]) == cnt
+    name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
+    for n, _ in pre._train_items:
+        g = pre._gview[n].cpu().numpy()
+        r_ = ref[name_map.get(n, n)]
+        scale = max(np.max(np.abs(r_)), 1e-12)
+        err = np.max(np.abs(g - r_)) / scale
+        assert err <= G_TOL, "%s: rel err %.3e (max ref %.3e)" % (n, err, scale)
+    # value of the objective vs the numpy oracle on the device outputs
+    xr, h = pre.predict_on_batch(P["X"])
+    want = O.loss_snmf_cost(P["X"], xr, np.zeros_like(xr), h, wmask, lam1)
+    got = pre.test_on_batch(P["X"], [P["X"], P["X"]], [wmask, wmask])
+    assert abs(got - want) <= 1e-5 * abs(want)
+    assert abs(got - ref_loss / cnt) <= 1e-5 * abs(got)
+    hist = pre.fit(P["X"], [P["X"], P["X"]], sample_weight=[wmask, wmask], batch_size=2, epochs=6,
+                   validation_data=(P["X"], [P["X"], P["X"]], [wmask, wmask]))
+    assert hist["val_loss"][-1] < got
+    # the DR-NMF model shares the pretrained weights (enhance.py:1119 reloads them from disk)
+    for a, b in zip(model.get_weights(), pre.get_weights()):
+        np.testing.assert_array_equal(a, b)
