@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--tied", action="store_true", help="tie log_D/log_alph across layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ista", action="store_true", help="skip the frame-parallel ISTA line")
+    ap.add_argument("--no-slab", action="store_true",
+                    help="skip the 250-utterance inference slab line")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step lines")
     ap.add_argument("--no-train-c2", action="store_true",
                     help="skip the training step at the headline shape (needs ~70 GB of HBM)")
@@ -136,6 +138,38 @@ def train_bench(torch, dev, steps=3, shape=(32, 500, 257, 1000, 5), ragged=True)
             "ms_per_step": sec * 1e3, "frames_per_s": B * T / sec,
             "valid_frames_per_s": valid / sec, "tflops": flops / sec / 1e12,
             "loss_first": losses[0], "loss_last": losses[-1]}
+
+
+def slab_bench(torch, dev, F, r, K, T, slab=250):
+    """The reference predicts in slabs of 250 utterances (enhance.py:1189-1193): the same forward
+    (cell + mask head) on one slab, where the row-blocked kernels apply."""
+    from drnmf_amd import layers, ops
+    N = 2 * r
+    W, log_h0, X = synth_on_device(torch, dev, slab, T, F, r, seed=99)
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K, W=W,
+             alph=400.0 if r >= 1000 else 50.0, lam1=1.0, params_trainable=["log_D", "log_alph"],
+             params_untied=["log_D", "log_alph"])
+    model = layers.build_unfolded_snmf(p, device=dev)
+    h_buf = torch.empty((slab, T, N), dtype=torch.float32, device=dev)
+    m_buf = torch.empty((slab, T, F), dtype=torch.float32, device=dev)
+
+    def step():
+        h = model.cell.call(X, mask_value=-1., out=h_buf)
+        ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
+    step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    step()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3
+    tf = slab * T * 4.0 * F * N * K / sec / 1e12
+    out = {"utterances": slab, "frames_per_s": slab * T / sec, "ms_per_slab": sec * 1e3,
+           "tflops": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS}
+    del model, X, h_buf, m_buf
+    torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic():
@@ -284,29 +318,23 @@ def main():
     # of the cell's launches on the launch stream / number of launches (the hipGraph replays run
     # back to back, so this includes the ~1.7 us launch boundary, as rocprofv3's kernel trace of
     # the same command does: it reports zero gaps between consecutive kernels).
-    import ctypes
-    from drnmf_amd import _capi
-    chains = int(_capi.lib().drnmf_cell_chains(ctypes.byref(model.cell._desc(B, T))))
-    # the batch runs as `chains` concurrent row groups, each with its own 2K-1 launches per frame;
-    # launch_us is the mean time the chip spends per launch (cell time / launches): concurrent
-    # launches overlap, so it is a throughput figure, not one kernel's latency
-    n_launch = T * (2 * K - 1) * chains
-    flops_per_launch = 2.0 * (B / chains) * F * N
+    n_launch = T * (2 * K - 1)
     launch_us = (sum(cell_ms) / len(cell_ms)) * 1e3 / n_launch
     ach = flops_per_launch / (launch_us * 1e-6) / 1e12
     traffic, traffic_src = pmc_traffic()
     roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": traffic_src,
             "kernel": "cell_a_kernel / cell_b_kernel (mean over the 2K-1 launches of a frame)",
-            "launch_us": launch_us, "flops_per_launch": flops_per_launch,
-            "concurrent_chains": chains}
+            "launch_us": launch_us, "flops_per_launch": flops_per_launch}
     extra = {}
     if rank == 0:
-        extra = {"frame_us": launch_us * (2 * K - 1) * chains, "cell_ms_per_step": sum(cell_ms) / len(cell_ms),
+        extra = {"frame_us": launch_us * (2 * K - 1), "cell_ms_per_step": sum(cell_ms) / len(cell_ms),
                  "whole_forward_tflops": whole,
                  "whole_forward_frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS}
         if not a.no_ista:
             extra["ista_frame_parallel"] = ista_bench(torch, dev, F, N, K, W)
+        if not a.no_slab and world == 1:
+            extra["inference_slab_250"] = slab_bench(torch, dev, F, r, K, T)
         if not a.no_train and world == 1:
             del X
             torch.cuda.empty_cache()

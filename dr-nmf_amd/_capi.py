@@ -35,7 +35,6 @@ SIGNATURES = {
                                   _vp]),
     "drnmf_cell_forward_stateful": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp,
                                            _vp, _vp, _sz, _vp]),
-    "drnmf_cell_chains": (_i32, [_DP]),
     "drnmf_cell_profile": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _sz,
                                   _vp, _i32, C.POINTER(C.c_float)]),
     "drnmf_padded_f": (_i32, [_i32]),

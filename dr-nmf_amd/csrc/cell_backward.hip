@@ -553,7 +553,7 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     // ---- sequential pass: T replays of the per-frame graph in reverse time ---------------------
     DRNMF_HIP(h, hipMemsetAsync(bw, 0, L.off_dh0, stream));   // dstate .. counters
     const dim3 grid_a((unsigned)round_up(W.numA, 8), (unsigned)numM);
-    const dim3 grid_b((unsigned)round_up(nft * W.KS, 8), (unsigned)numM);
+    const dim3 grid_b((unsigned)round_up(nft * W.KS, 8), (unsigned)(numM / W.RB));
 
     EdgeArgs ea;
     ea.hall = hall; ea.d_out = d_out; ea.dz_all = dz_all; ea.ia_last = ia_of(K - 1);
@@ -634,7 +634,7 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, &ea));
         for (int k = K - 1; k >= 1; --k) {
             CellBArgs b = make_b(k);
-            DRNMF_HIP(h, add(pick_b_func(W.nch_ks), grid_b, 64 * NW_B, &b));
+            DRNMF_HIP(h, add(pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, &b));
             BwdAArgs a = make_a(k);
             DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, &a));
         }

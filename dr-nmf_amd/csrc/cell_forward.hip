@@ -63,18 +63,19 @@ struct CellAArgs {
 };
 
 // G = 16-bin chunks handled per wave per group (all of a group's operand loads are issued before
-// its first MFMA so that one memory round trip covers the group).
-template <int G, int KS, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN>
+// its first MFMA so that one memory round trip covers the group).  RB = 16-row blocks per
+// workgroup (see cell_b_kernel): every dictionary operand feeds RB row blocks.
+template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN>
 __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     constexpr bool WRITE_OUT = IS_LAST || ALL_HIDDEN;
-    __shared__ __attribute__((aligned(16))) float red[NW_A * ROWS * ATOMS];   // [NW][16][32]
+    __shared__ __attribute__((aligned(16))) float red[NW_A * RB * ROWS * ATOMS];   // [NW][RB][16][32]
 
-    // 2-D grid (atom block [padded to a multiple of 8], row tile): workgroups are dealt
+    // 2-D grid (atom block [padded to a multiple of 8], row tile group): workgroups are dealt
     // round-robin to the 8 XCDs by linear id = x + y * gridDim.x, gridDim.x % 8 == 0, so the row
     // tiles that share one dictionary slice (same x) land on the same XCD / L2.  The padded
     // blocks redo the last atom block with every store predicated off: no early exit, so all
     // kernel arguments arrive in ONE scalar-load round trip ahead of the operand loads.
-    const int m = blockIdx.y;
+    const int mb0 = blockIdx.y * RB;              // first 16-row block of this workgroup
     const bool live = (int)blockIdx.x < a.numA;
     const int ab = live ? (int)blockIdx.x : a.numA - 1;
 
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int l = tid & 63, j = l & 15, q = l >> 4;
     const int Fp = a.Fp, Np = a.Np;
-    const int row0 = m * ROWS, n0 = ab * ATOMS;
+    const int n0 = ab * ATOMS;
     const size_t pstride = (size_t)a.Bp * Fp;     // one r partial
 
     int t = 0;
@@ -92,8 +93,9 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     }
     const float* rsrc = IS_FIRST ? a.rsrc + (size_t)t * pstride : a.rsrc;
     const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
-    // A: block (m, c) of Rp, lane (row j, slot q) reads the float4 {s = 0..3} <-> f = 16c+4s+q
-    const float* arow = rsrc + (size_t)m * nft * 256 + j * 16 + q * 4;            // + 256*c
+    // A: block (mb, c) of Rp, lane (row j, slot q) reads the float4 {s = 0..3} <-> f = 16c+4s+q
+    const float* arow = rsrc + (size_t)mb0 * nft * 256 + j * 16 + q * 4;          // + 256*c
+    const size_t astep = (size_t)nft * 256;                                        // per row block
     // B: blocks (c, ac0 | ac0+1) of Dp, rows 4s+q, atoms 2j, 2j+1 of the 32
     const float* brow = a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + q * 16 + (j & 7) * 2;
     const size_t bstep = (size_t)NAC * 256;                                        // per chunk c
@@ -102,19 +104,23 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // Loads are branch-free (out-of-range chunks are clamped to the last chunk and their A
     // operand zeroed) so that the compiler can retire them with counted vmcnt waits and the
     // MFMAs start as soon as the first chunk lands.
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb][0] = acc[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int per_wave = (a.nchunks - w + NW_A - 1) / NW_A;   // chunks owned by this wave (>= 0)
     const int clast = a.nchunks - 1;
     constexpr int NP = IS_FIRST ? 1 : KS;
 
-    f32x4 av[G][NP];
+    f32x4 av[G][RB][NP];
     f32x2 bv[G][4];
     auto load_chunk = [&](int base, int g) {
         int c = w + NW_A * (base + g);
         c = c > clast ? clast : c;
 #pragma unroll
-        for (int ks = 0; ks < NP; ++ks)
-            av[g][ks] = *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < NP; ++ks)
+                av[g][rb][ks] = *(const f32x4*)(arow + rb * astep + 256 * c + (size_t)ks * pstride);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
@@ -123,84 +129,107 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // issuing one chunk's operand loads for all waves takes about as long as one wave's MFMAs on
     // that chunk.  Loads run PF chunks ahead of the MFMAs (enough to cover the L2/fabric latency)
     // and the two streams overlap instead of adding up.
-    constexpr int PF = G < 3 ? G : 3;   // measured: 2..4 equivalent (250k frames/s), 6 slower (241k)
+    constexpr int PF0 = 3;   // RB = 1 measured: 2..4 equivalent (250k frames/s), 6 slower
+    constexpr int PF = G < PF0 ? G : PF0;
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
     // ---- epilogue operands (tiny, needed last; issued behind the GEMM operands) --------------
-    const int erow = (tid & 255) >> 4, ec = (tid & 15) * 2;   // waves 4.. mirror waves 0..3
-    const int rg = row0 + erow, n = n0 + ec;
-    const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
-    const f32x2 hp = *(const f32x2*)(a.h_in + hoff);
+    const int erow = (tid & 255) >> 4, ec = (tid & 15) * 2;
+    const int n = n0 + ec;
+    const size_t hoff0 = ((size_t)mb0 * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
+    const size_t hstep = (size_t)NAC * 256;                                        // per row block
     const f32x2 ia = *(const f32x2*)(a.inv_alpha + n);
     const f32x2 bs = *(const f32x2*)(a.bias + n);
     if (!IS_FIRST && WRITE_OUT) {
         t = *a.t_rd;
         if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
     }
-    float ps;
-    if (IS_FIRST) {
-        // sum(p) = sum over atom blocks of the row sums left by the previous frame's last layer,
-        // added in block order by 16 lanes + a fixed shuffle tree (deterministic)
-        const float* rp = a.rs_part + (size_t)(t & 1) * a.numA * a.Bp + rg;
-        float s = 0.f;
-        for (int b2 = (tid & 15); b2 < a.numA; b2 += 16) s += rp[(size_t)b2 * a.Bp];
-        s += __shfl_xor(s, 8, 16);
-        s += __shfl_xor(s, 4, 16);
-        s += __shfl_xor(s, 2, 16);
-        s += __shfl_xor(s, 1, 16);
-        ps = s;
-        if (blockIdx.x == 0 && tid < 256 && (tid & 15) == 0) {
-            a.psum[rg] = ps;
-            a.psum_all[(size_t)t * a.Bp + rg] = ps;
-        }
-    } else {
-        ps = a.psum[rg];
-    }
-    bool vld = true;
-    if (WRITE_OUT) vld = a.valid[(size_t)t * a.Bp + rg] != 0;
+    f32x2 hp[RB];
+    float ps[RB];
+    bool vld[RB];
     // tail bins (F = 16*nchunks + ntail): residual r_tail = x_tail - sum over atom blocks of the
     // partial dot products left by the previous layer.  Only the LOADS are issued here; they are
     // reduced after the MFMA loop (consuming them now would force an in-order vmcnt wait on every
     // operand load issued so far).
-    float xt[MAX_TAIL] = {0.f, 0.f};
-    float qv[MAX_TAIL][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float xt[RB][MAX_TAIL];
+    float qv[RB][MAX_TAIL][4];
     f32x2 dt[MAX_TAIL] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < MAX_TAIL; ++i) {
         if (i >= a.ntail) continue;
         const size_t toff = ((size_t)a.nchunks * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
         dt[i] = *(const f32x2*)(a.Dn + toff);
-        if (IS_FIRST) {
-            // packed input: bin 16*nchunks + i sits at tile nchunks, position perm(i) = 4*i
-            xt[i] = rsrc[((size_t)m * nft + a.nchunks) * 256 + erow * 16 + 4 * i];
-        } else {
-            xt[i] = a.xtail[(size_t)i * a.Bp + rg];
-            const float* qp = a.q_in + (size_t)i * a.Bp + rg;
+    }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {   // atom blocks (tid&15) + 16u: covers numA <= 64 here
-                const int b2 = (tid & 15) + 16 * u;
-                if (b2 < a.numA) qv[i][u] = qp[(size_t)b2 * MAX_TAIL * a.Bp];
+    for (int rb = 0; rb < RB; ++rb) {
+        const int rg = (mb0 + rb) * ROWS + erow;
+        hp[rb] = *(const f32x2*)(a.h_in + hoff0 + rb * hstep);
+        if (IS_FIRST) {
+            // sum(p) = sum over atom blocks of the row sums left by the previous frame's last
+            // layer, added in block order by 16 lanes + a fixed shuffle tree (deterministic)
+            const float* rp = a.rs_part + (size_t)(t & 1) * a.numA * a.Bp + rg;
+            float s = 0.f;
+            for (int b2 = (tid & 15); b2 < a.numA; b2 += 16) s += rp[(size_t)b2 * a.Bp];
+            s += __shfl_xor(s, 8, 16);
+            s += __shfl_xor(s, 4, 16);
+            s += __shfl_xor(s, 2, 16);
+            s += __shfl_xor(s, 1, 16);
+            ps[rb] = s;
+            if (blockIdx.x == 0 && (tid & 15) == 0) {
+                a.psum[rg] = s;
+                a.psum_all[(size_t)t * a.Bp + rg] = s;
+            }
+        } else {
+            ps[rb] = a.psum[rg];
+        }
+        vld[rb] = true;
+        if (WRITE_OUT) vld[rb] = a.valid[(size_t)t * a.Bp + rg] != 0;
+#pragma unroll
+        for (int i = 0; i < MAX_TAIL; ++i) {
+            xt[rb][i] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qv[rb][i][u] = 0.f;
+            if (i >= a.ntail) continue;
+            if (IS_FIRST) {
+                // packed input: bin 16*nchunks + i sits at tile nchunks, position perm(i) = 4*i
+                xt[rb][i] = rsrc[((size_t)(mb0 + rb) * nft + a.nchunks) * 256 + erow * 16 + 4 * i];
+            } else {
+                xt[rb][i] = a.xtail[(size_t)i * a.Bp + rg];
+                const float* qp = a.q_in + (size_t)i * a.Bp + rg;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {   // atom blocks (tid&15) + 16u: covers numA <= 64 here
+                    const int b2 = (tid & 15) + 16 * u;
+                    if (b2 < a.numA) qv[rb][i][u] = qp[(size_t)b2 * MAX_TAIL * a.Bp];
+                }
             }
         }
     }
 
-    // ---- GEMM:  g[16 x 32] = r[16 x F] . Dn[F x 32] -------------------------------------------
+    // ---- GEMM:  g[16*RB x 32] = r[16*RB x F] . Dn[F x 32] ---------------------------------------
     auto compute_chunk = [&](int base, int g) {
-        f32x4 r4 = av[g][0];
+        const bool ok = base + g < per_wave;
+        f32x4 r4[RB];
 #pragma unroll
-        for (int ks = 1; ks < NP; ++ks) r4 += av[g][ks];
-        if (IS_FIRST && blockIdx.x == 0 && base + g < per_wave) {
-            // republish this row tile's x_t chunk at a frame-independent address (cell_b reads
-            // it without a dependent frame-index load)
-            const int c = w + NW_A * (base + g);
-            *(f32x4*)(a.xcur + (size_t)m * nft * 256 + 256 * c + j * 16 + q * 4) = r4;
+        for (int rb = 0; rb < RB; ++rb) {
+            r4[rb] = av[g][rb][0];
+#pragma unroll
+            for (int ks = 1; ks < NP; ++ks) r4[rb] += av[g][rb][ks];
+            if (IS_FIRST && blockIdx.x == 0 && ok) {
+                // republish this row tile's x_t chunk at a frame-independent address (cell_b
+                // reads it without a dependent frame-index load)
+                const int c = w + NW_A * (base + g);
+                *(f32x4*)(a.xcur + (size_t)(mb0 + rb) * nft * 256 + 256 * c + j * 16 + q * 4) = r4[rb];
+            }
+            if (!ok) r4[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (base + g >= per_wave) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            acc0 = mfma16(r4[s], bv[g][s][0], acc0);
-            acc1 = mfma16(r4[s], bv[g][s][1], acc1);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                acc[rb][0] = mfma16(r4[rb][s], bv[g][s][0], acc[rb][0]);
+                acc[rb][1] = mfma16(r4[rb][s], bv[g][s][1], acc[rb][1]);
+            }
         }
     };
     // sched_barriers pin the interleave (the scheduler would otherwise regroup loads and MFMAs);
@@ -221,93 +250,100 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
 
     // ---- cross-wave reduction of the 4 F-splits through LDS --------------------------------
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        f32x2 pr = {acc0[v], acc1[v]};
-        *(f32x2*)(red + (w * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
-    }
-    __syncthreads();
-    if (tid >= 256) return;   // the elementwise epilogue is 256 threads wide
-    f32x2 gsum = *(const f32x2*)(red + (0 * ROWS + erow) * ATOMS + ec);
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int ww = 1; ww < NW_A; ++ww) {
-        const f32x2 p2 = *(const f32x2*)(red + (ww * ROWS + erow) * ATOMS + ec);
-        gsum[0] += p2[0];
-        gsum[1] += p2[1];
-    }
-
-#pragma unroll
-    for (int i = 0; i < MAX_TAIL; ++i) {   // rank-1 update per tail bin
-        if (i >= a.ntail) continue;
-        float rt = xt[i];
-        if (IS_FIRST) {
-            if (blockIdx.x == 0 && (tid & 15) == 0) a.xtail[(size_t)i * a.Bp + rg] = xt[i];
-        } else {
-            float sq = (qv[i][0] + qv[i][1]) + (qv[i][2] + qv[i][3]);
-            const float* qp = a.q_in + (size_t)i * a.Bp + rg;
-            for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16)      // numA > 64 only
-                sq += qp[(size_t)b2 * MAX_TAIL * a.Bp];
-            sq += __shfl_xor(sq, 8, 16);
-            sq += __shfl_xor(sq, 4, 16);
-            sq += __shfl_xor(sq, 2, 16);
-            sq += __shfl_xor(sq, 1, 16);
-            rt -= sq;
+        for (int v = 0; v < 4; ++v) {
+            f32x2 pr = {acc[rb][0][v], acc[rb][1][v]};
+            *(f32x2*)(red + ((w * RB + rb) * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
         }
-        gsum[0] = fmaf(rt, dt[i][0], gsum[0]);
-        gsum[1] = fmaf(rt, dt[i][1], gsum[1]);
-    }
+    __syncthreads();
 
-    // ---- fused update: soft-threshold / non-negativity projection --------------------------
-    f32x2 hn;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        float pre;
-        if (IS_FIRST) pre = a.u0d * hp[e] + a.u0o * (ps - hp[e]);
-        else pre = hp[e] + a.uko * ps;
-        pre += gsum[e] * ia[e] + bs[e];
-        hn[e] = fmaxf(pre, 0.f);
-    }
+    for (int rb = 0; rb < RB; ++rb) {
+        const int rg = (mb0 + rb) * ROWS + erow;
+        const size_t hoff = hoff0 + rb * hstep;
+        f32x2 gsum = *(const f32x2*)(red + ((0 * RB + rb) * ROWS + erow) * ATOMS + ec);
+#pragma unroll
+        for (int ww = 1; ww < NW_A; ++ww) {
+            const f32x2 p2 = *(const f32x2*)(red + ((ww * RB + rb) * ROWS + erow) * ATOMS + ec);
+            gsum[0] += p2[0];
+            gsum[1] += p2[1];
+        }
 
-    const bool row_live = live && rg < a.B;
-    if (WRITE_OUT && row_live) {
-        // K.rnn masking: a masked step repeats the previous output (zeros before the first
-        // valid step)
-        float* orow = a.out + ((size_t)rg * a.T + t) * a.out_width + a.out_off;
+#pragma unroll
+        for (int i = 0; i < MAX_TAIL; ++i) {   // rank-1 update per tail bin
+            if (i >= a.ntail) continue;
+            float rt = xt[rb][i];
+            if (IS_FIRST) {
+                if (blockIdx.x == 0 && (tid & 15) == 0) a.xtail[(size_t)i * a.Bp + rg] = xt[rb][i];
+            } else {
+                float sq = (qv[rb][i][0] + qv[rb][i][1]) + (qv[rb][i][2] + qv[rb][i][3]);
+                const float* qp = a.q_in + (size_t)i * a.Bp + rg;
+                for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16)      // numA > 64 only
+                    sq += qp[(size_t)b2 * MAX_TAIL * a.Bp];
+                sq += __shfl_xor(sq, 8, 16);
+                sq += __shfl_xor(sq, 4, 16);
+                sq += __shfl_xor(sq, 2, 16);
+                sq += __shfl_xor(sq, 1, 16);
+                rt -= sq;
+            }
+            gsum[0] = fmaf(rt, dt[i][0], gsum[0]);
+            gsum[1] = fmaf(rt, dt[i][1], gsum[1]);
+        }
+
+        // ---- fused update: soft-threshold / non-negativity projection ----------------------
+        f32x2 hn;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (n + e < a.N) {
-                float o = hn[e];
-                if (!vld) o = (t > 0) ? orow[n + e - (ptrdiff_t)a.out_width] : 0.f;
-                orow[n + e] = o;
+            float pre;
+            if (IS_FIRST) pre = a.u0d * hp[rb][e] + a.u0o * (ps[rb] - hp[rb][e]);
+            else pre = hp[rb][e] + a.uko * ps[rb];
+            pre += gsum[e] * ia[e] + bs[e];
+            hn[e] = fmaxf(pre, 0.f);
+        }
+
+        const bool row_live = live && rg < a.B;
+        if (WRITE_OUT && row_live) {
+            // K.rnn masking: a masked step repeats the previous output (zeros before the first
+            // valid step)
+            float* orow = a.out + ((size_t)rg * a.T + t) * a.out_width + a.out_off;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (n + e < a.N) {
+                    float o = hn[e];
+                    if (!vld[rb]) o = (t > 0) ? orow[n + e - (ptrdiff_t)a.out_width] : 0.f;
+                    orow[n + e] = o;
+                }
             }
         }
-    }
-    if (!live) return;
-    if (IS_LAST) {
-        // ... and keeps the previous state
-        f32x2 st = hn;
-        if (!vld) st = IS_FIRST ? hp : *(const f32x2*)(a.state + hoff);
-        *(f32x2*)(a.state + hoff) = st;
-        float s = st[0] + st[1];
-        s += __shfl_xor(s, 8, 16);
-        s += __shfl_xor(s, 4, 16);
-        s += __shfl_xor(s, 2, 16);
-        s += __shfl_xor(s, 1, 16);
-        if ((tid & 15) == 0)
-            a.rs_part[((size_t)((t + 1) & 1) * a.numA + ab) * a.Bp + rg] = s;
-    } else {
-        *(f32x2*)(a.h_out + hoff) = hn;
-        // tail bins of the next layer's x^: partial dot product over this block's 32 atoms
+        if (!live) continue;
+        if (IS_LAST) {
+            // ... and keeps the previous state
+            f32x2 st = hn;
+            if (!vld[rb]) st = IS_FIRST ? hp[rb] : *(const f32x2*)(a.state + hoff);
+            *(f32x2*)(a.state + hoff) = st;
+            float s = st[0] + st[1];
+            s += __shfl_xor(s, 8, 16);
+            s += __shfl_xor(s, 4, 16);
+            s += __shfl_xor(s, 2, 16);
+            s += __shfl_xor(s, 1, 16);
+            if ((tid & 15) == 0)
+                a.rs_part[((size_t)((t + 1) & 1) * a.numA + ab) * a.Bp + rg] = s;
+        } else {
+            *(f32x2*)(a.h_out + hoff) = hn;
+            // tail bins of the next layer's x^: partial dot product over this block's 32 atoms
 #pragma unroll
-        for (int i = 0; i < MAX_TAIL; ++i) {
-            if (i >= a.ntail) continue;
-            const size_t toff = ((size_t)a.nchunks * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
-            const f32x2 dn = *(const f32x2*)(a.Dn_next + toff);
-            float sq = hn[0] * dn[0] + hn[1] * dn[1];
-            sq += __shfl_xor(sq, 8, 16);
-            sq += __shfl_xor(sq, 4, 16);
-            sq += __shfl_xor(sq, 2, 16);
-            sq += __shfl_xor(sq, 1, 16);
-            if ((tid & 15) == 0) a.q_out[((size_t)ab * MAX_TAIL + i) * a.Bp + rg] = sq;
+            for (int i = 0; i < MAX_TAIL; ++i) {
+                if (i >= a.ntail) continue;
+                const size_t toff = ((size_t)a.nchunks * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
+                const f32x2 dn = *(const f32x2*)(a.Dn_next + toff);
+                float sq = hn[0] * dn[0] + hn[1] * dn[1];
+                sq += __shfl_xor(sq, 8, 16);
+                sq += __shfl_xor(sq, 4, 16);
+                sq += __shfl_xor(sq, 2, 16);
+                sq += __shfl_xor(sq, 1, 16);
+                if ((tid & 15) == 0) a.q_out[((size_t)ab * MAX_TAIL + i) * a.Bp + rg] = sq;
+            }
         }
     }
 }
@@ -415,50 +451,46 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
     if (tid == 0) { tptr[0] = 0; tptr[16] = 0; }
 }
 
-template <int G, int KS, bool AH>
+template <int G, int KS, int RB, bool AH>
 void* a_func(bool first, bool last) {
-    if (first && last) return (void*)&cell_a_kernel<G, KS, true, true, AH>;
-    if (first) return (void*)&cell_a_kernel<G, KS, true, false, AH>;
-    if (last) return (void*)&cell_a_kernel<G, KS, false, true, AH>;
-    return (void*)&cell_a_kernel<G, KS, false, false, AH>;
+    if (first && last) return (void*)&cell_a_kernel<G, KS, RB, true, true, AH>;
+    if (first) return (void*)&cell_a_kernel<G, KS, RB, true, false, AH>;
+    if (last) return (void*)&cell_a_kernel<G, KS, RB, false, true, AH>;
+    return (void*)&cell_a_kernel<G, KS, RB, false, false, AH>;
 }
 
-template <int KS, bool AH>
+template <int KS, int RB, bool AH>
 void* a_func_g(int per_wave, bool first, bool last) {
-    // G chunks per wave per group; operand registers G * (4*KS + 8): large KS pairs with small G
-    if (per_wave <= 3) return a_func<3, KS, AH>(first, last);
-    if (per_wave <= 5 || KS >= 4) return a_func<5, KS, AH>(first, last);
-    return a_func<9, KS, AH>(first, last);
+    // G chunks per wave per group; operand registers G * (4*KS*RB + 8): large KS pairs with small G
+    if (per_wave <= 3) return a_func<3, KS, RB, AH>(first, last);
+    if (per_wave <= 5 || KS * RB >= 4) return a_func<5, KS, RB, AH>(first, last);
+    return a_func<9, KS, RB, AH>(first, last);
 }
 
 template <bool AH>
-void* pick_a_func_ah(int per_wave, int KS, bool first, bool last) {
+void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last) {
+    // row-blocked variants exist for KS <= 2 (workspace_layout never pairs RB > 1 with more)
+    if (RB == 2) return KS == 1 ? a_func_g<1, 2, AH>(per_wave, first, last)
+                                : a_func_g<2, 2, AH>(per_wave, first, last);
     switch (KS) {
-        case 1: return a_func_g<1, AH>(per_wave, first, last);
-        case 2: return a_func_g<2, AH>(per_wave, first, last);
-        case 4: return a_func_g<4, AH>(per_wave, first, last);
-        default: return a_func_g<8, AH>(per_wave, first, last);
+        case 1: return a_func_g<1, 1, AH>(per_wave, first, last);
+        case 2: return a_func_g<2, 1, AH>(per_wave, first, last);
+        case 4: return a_func_g<4, 1, AH>(per_wave, first, last);
+        default: return a_func_g<8, 1, AH>(per_wave, first, last);
     }
 }
 
-void* pick_a_func(int nchunks, int KS, bool first, bool last, bool all_hidden) {
+void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_hidden) {
     const int per_wave = (nchunks + NW_A - 1) / NW_A;
-    return all_hidden ? pick_a_func_ah<true>(per_wave, KS, first, last)
-                      : pick_a_func_ah<false>(per_wave, KS, first, last);
+    return all_hidden ? pick_a_func_ah<true>(per_wave, KS, RB, first, last)
+                      : pick_a_func_ah<false>(per_wave, KS, RB, first, last);
 }
 
 }  // namespace
 
-static size_t chained_workspace_bytes(const drnmf_cell_desc_t* d, int G);
-
 extern "C" size_t drnmf_cell_workspace_bytes(const drnmf_cell_desc_t* d) {
     if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0) return 0;
-    size_t best = workspace_layout(d).total;
-    for (int G = 2; G <= 8; ++G) {
-        const size_t t = chained_workspace_bytes(d, G);
-        if (t > best) best = t;
-    }
-    return best;
+    return workspace_layout(d).total;
 }
 
 static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
@@ -466,10 +498,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                                  float u0_diag, float u0_off, float uk_off, float* h_out,
                                  void* workspace, size_t workspace_bytes, void* stream_,
                                  int profile_frames, float* out_us,
-                                 hipGraphExec_t* out_exec = nullptr,
                                  const float* initial_state = nullptr) {
-    // out_exec != NULL: enqueue the prologue and build/find the frame graph, but leave the T
-    // replays to the caller (who interleaves them with other chains)
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;
@@ -525,10 +554,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
         key.push_back(b0); key.push_back(b1); key.push_back(b2);
     }
-    const bool use_graph = (getenv("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0) ||
-                           out_exec != nullptr;
+    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0;
 
-    const int numM = W.Bp / ROWS, nft = W.nft_main;   // MFMA bin tiles (tail bins handled apart)
+    const int numM = W.Bp / (ROWS * W.RB), nft = W.nft_main;   // MFMA bin tiles (tail bins handled apart)
     const dim3 grid_a((unsigned)round_up(W.numA, 8), (unsigned)numM);
     const dim3 grid_b((unsigned)round_up(nft * W.KS, 8), (unsigned)numM);
     const float* Dn_base = (const float*)(pb + L.off_dn);
@@ -605,14 +633,14 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 CellAArgs a = make_a(k);
                 void* kp[1] = {&a};
                 DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
-                DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, k == 0, k == K - 1,
+                DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1,
                                                          d->return_all_hidden != 0),
                                              grid_a, dim3(64 * NW_A), kp, 0, stream));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     void* kb[1] = {&b};
                     DRNMF_HIP(h, mark(1));
-                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks), grid_b, dim3(64 * NW_B), kb, 0,
+                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks, W.RB), grid_b, dim3(64 * NW_B), kb, 0,
                                                  stream));
                 }
             }
@@ -677,10 +705,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         };
         for (int k = 0; k < K; ++k) {
             CellAArgs a = make_a(k);
-            DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 64 * NW_A, &a));
+            DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 64 * NW_A, &a));
             if (k < K - 1) {
                 CellBArgs b = make_b(k);
-                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks), grid_b, 64 * NW_B, &b));
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, &b));
             }
         }
         if (K == 1) {
@@ -691,113 +719,16 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         h->graphs.push_back(ge);
         entry = &h->graphs.back();
     }
-    if (out_exec) {
-        *out_exec = entry->exec;
-        return DRNMF_OK;
-    }
     for (int t = 0; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(entry->exec, stream));
     return DRNMF_OK;
-}
-
-// ---- concurrent utterance chains ------------------------------------------------------------------
-// The frame kernels are latency-bound (launch boundary + cold-L2 fill; MFMA and L2 bandwidth are
-// ~15 % busy), and utterances are independent, so the batch is split into row groups that run as
-// independent chains on side streams: one chain's boundary/fill latency overlaps another chain's
-// compute.  Forked from and joined to the caller's stream with events.
-static int choose_chains(const drnmf_cell_desc_t* d) {
-    if (d->return_all_hidden) return 1;              // training keeps one workspace for the BPTT
-    // Measured on MI355X (C2, B=64): 2 chains 0.78x, 4 chains 0.34x of the single-chain rate --
-    // kernels from different queues do not overlap usefully (every kernel boundary writes back
-    // and invalidates the L2s chip-wide).  Kept as an opt-in experiment only.
-    int g = 1;
-    if (const char* e = getenv("DRNMF_CHAINS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 8) g = v;
-    }
-    while (g > 1 && d->B / g < 1) g >>= 1;
-    if (getenv("DRNMF_NO_GRAPH")) g = 1;
-    return g;
-}
-
-static void chain_rows(int B, int G, int g, int* b0, int* b1) {
-    // whole 16-row tiles per chain where possible
-    const int tiles = (B + 15) / 16;
-    const int base = tiles / G, rem = tiles % G;
-    const int t0 = g * base + (g < rem ? g : rem);
-    const int t1 = t0 + base + (g < rem ? 1 : 0);
-    *b0 = t0 * 16 < B ? t0 * 16 : B;
-    *b1 = t1 * 16 < B ? t1 * 16 : B;
-}
-
-static size_t chained_workspace_bytes(const drnmf_cell_desc_t* d, int G) {
-    size_t tot = 0;
-    for (int g = 0; g < G; ++g) {
-        int b0, b1;
-        chain_rows(d->B, G, g, &b0, &b1);
-        if (b1 <= b0) continue;
-        drnmf_cell_desc_t dg = *d;
-        dg.B = b1 - b0;
-        tot += workspace_layout(&dg).total;
-    }
-    return tot;
 }
 
 extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
                                       float mask_value, const void* params, const float* log_h0,
                                       float u0_diag, float u0_off, float uk_off, float* h_out,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!h) return DRNMF_ERR_INVALID_ARG;
-    int rc = validate_cell_desc(h, d);
-    if (rc) return rc;
-    const int G = choose_chains(d);
-    if (G <= 1)
-        return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off,
-                                 h_out, workspace, workspace_bytes, stream_, 0, nullptr);
-    if (!x || !params || !log_h0 || !h_out || !workspace)
-        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_forward: NULL pointer argument");
-    if (workspace_bytes < chained_workspace_bytes(d, G))
-        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "cell_forward: workspace %zu < required %zu",
-                   workspace_bytes, chained_workspace_bytes(d, G));
-    hipStream_t stream = (hipStream_t)stream_;
-    while ((int)h->side_streams.size() < G) {
-        hipStream_t s;
-        hipEvent_t e;
-        DRNMF_HIP(h, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        DRNMF_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->side_streams.push_back(s);
-        h->side_done.push_back(e);
-    }
-    if (!h->fork_event) DRNMF_HIP(h, hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming));
-    DRNMF_HIP(h, hipEventRecord(h->fork_event, stream));
-    const int width = d->N;   // (return_all_hidden never takes this path)
-    std::vector<hipGraphExec_t> exec(G, nullptr);
-    std::vector<int> live(G, 0);
-    size_t woff = 0;
-    for (int g = 0; g < G; ++g) {
-        int b0, b1;
-        chain_rows(d->B, G, g, &b0, &b1);
-        if (b1 <= b0) continue;
-        drnmf_cell_desc_t dg = *d;
-        dg.B = b1 - b0;
-        const size_t wbytes = workspace_layout(&dg).total;
-        DRNMF_HIP(h, hipStreamWaitEvent(h->side_streams[g], h->fork_event, 0));
-        rc = cell_forward_impl(h, &dg, x + (size_t)b0 * d->T * d->F, mask_value, params, log_h0,
-                               u0_diag, u0_off, uk_off, h_out + (size_t)b0 * d->T * width,
-                               (char*)workspace + woff, wbytes, h->side_streams[g], 0, nullptr,
-                               &exec[g]);
-        if (rc) return rc;
-        live[g] = 1;
-        woff += wbytes;
-    }
-    for (int t = 0; t < d->T; ++t)
-        for (int g = 0; g < G; ++g)
-            if (live[g]) DRNMF_HIP(h, hipGraphLaunch(exec[g], h->side_streams[g]));
-    for (int g = 0; g < G; ++g) {
-        if (!live[g]) continue;
-        DRNMF_HIP(h, hipEventRecord(h->side_done[g], h->side_streams[g]));
-        DRNMF_HIP(h, hipStreamWaitEvent(stream, h->side_done[g], 0));
-    }
-    return DRNMF_OK;
+    return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
+                             workspace, workspace_bytes, stream_, 0, nullptr);
 }
 
 extern "C" int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d,
@@ -807,8 +738,7 @@ extern "C" int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cel
                                                float* final_state, float* h_out, void* workspace,
                                                size_t workspace_bytes, void* stream_) {
     int rc = cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
-                               workspace, workspace_bytes, stream_, 0, nullptr, nullptr,
-                               initial_state);
+                               workspace, workspace_bytes, stream_, 0, nullptr, initial_state);
     if (rc || !final_state) return rc;
     const Workspace W = workspace_layout(d);
     const size_t tot = (size_t)d->B * d->N;
@@ -817,11 +747,6 @@ extern "C" int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cel
                        final_state, d->B, d->N, W.Np);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
-}
-
-extern "C" int32_t drnmf_cell_chains(const drnmf_cell_desc_t* d) {
-    if (!d || d->B <= 0) return 0;
-    return choose_chains(d);
 }
 
 extern "C" int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,

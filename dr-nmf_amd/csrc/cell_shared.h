@@ -23,14 +23,17 @@ struct CellBArgs {
     int Bp, Fp, Np, nft, KS, logKS, nch_ks;   // nch_ks = 16-atom chunks per atom range
 };
 
-// x^ partial of one (row tile, bin tile, atom range) and the residual partial
-//   rpart[ks] = (ks == 0 ? x_t : 0) - h[16 x range] . Dn_next[16 bins x range]^T.
-// GB = 16-atom chunks per wave per group.
-template <int GB, int NW = 8>
+// x^ partial of one (row tile group, bin tile, atom range) and the residual partial
+//   rpart[ks] = (ks == 0 ? x_t : 0) - h[16*RB x range] . Dn_next[16 bins x range]^T.
+// GB = 16-atom chunks per wave per group.  RB = 16-row blocks per workgroup: large batches (the
+// reference predicts in slabs of 250 utterances, enhance.py:1189-1193) reuse every dictionary
+// operand for RB row blocks, which divides the operand traffic per flop by up to (1 + RB) / 2RB.
+template <int GB, int RB = 1, int NW = 8>
 __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[NW * 16 * 16];
-    // 2-D grid ((bin tile, atom range) padded to a multiple of 8, row tile): see cell_a_kernel.
-    // KS is a power of two.  Padded blocks redo the last tile with the store predicated off.
+    __shared__ __attribute__((aligned(16))) float red[NW * RB * 16 * 16];
+    // 2-D grid ((bin tile, atom range) padded to a multiple of 8, row tile group): see
+    // cell_a_kernel.  KS is a power of two.  Padded blocks redo the last tile with the store
+    // predicated off.
     const int m = blockIdx.y;
     const bool live = (int)blockIdx.x < a.nft * a.KS;
     const int rest = live ? (int)blockIdx.x : a.nft * a.KS - 1;
@@ -48,40 +51,52 @@ __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
     const int clast = nch - 1;
 
     const int NAC = Np / 16;
-    // blocks (m, cbase+c) of Hp and (ft, cbase+c) of Dp: lane (j, q) reads the float4 of atoms
+    // blocks (mb, cbase+c) of Hp and (ft, cbase+c) of Dp: lane (j, q) reads the float4 of atoms
     // 16c + 4q + {0..3} in row j -> one contiguous 1 KB block per wave instruction
-    const float* arow = a.h + ((size_t)m * NAC + cbase) * 256 + j * 16 + q * 4;          // + 256*c
+    const float* arow = a.h + ((size_t)m * RB * NAC + cbase) * 256 + j * 16 + q * 4;     // + 256*c
+    const size_t astep = (size_t)NAC * 256;                                              // per row block
     const float* brow = a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;   // + 256*c
 
     // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
-    f32x4 av[GB], bv[GB];
+    f32x4 av[GB][RB], bv[GB];
     auto load_chunk = [&](int base, int g) {
         int c = w + NW * (base + g);
         c = c > clast ? clast : c;
-        av[g] = *(const f32x4*)(arow + 256 * c);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) av[g][rb] = *(const f32x4*)(arow + rb * astep + 256 * c);
         bv[g] = *(const f32x4*)(brow + 256 * c);
     };
     // software pipeline: loads run PF chunks ahead of the MFMAs (see cell_a_kernel)
-    constexpr int PF = GB < 6 ? GB : 6;
+    constexpr int PF0 = RB > 1 ? 3 : 6;
+    constexpr int PF = GB < PF0 ? GB : PF0;
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
     // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
     const int erow = (tid & 255) >> 4, ecol = tid & 15;
     // (buffers keep Fp/16 tiles per row tile even when only a.nft of them are MFMA tiles)
-    const size_t eoff = ((size_t)m * (Fp / 16) + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
-    float xv = 0.f;
-    if (a.xp != nullptr && ks == 0) xv = a.xp[eoff];
+    const size_t eoff = ((size_t)m * RB * (Fp / 16) + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
+    const size_t estep = (size_t)(Fp / 16) * 256;                                        // per row block
+    float xv[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        xv[rb] = 0.f;
+        if (a.xp != nullptr && ks == 0) xv[rb] = a.xp[eoff + rb * estep];
+    }
 
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb][0] = acc[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute_chunk = [&](int base, int g) {
-        f32x4 a4 = av[g];
-        if (base + g >= per_wave) a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        // two independent accumulator chains hide the 40-cycle dependent MFMA latency
+        const bool ok = base + g < per_wave;
+        // two independent accumulator chains per row block hide the dependent MFMA latency
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (s & 1) acc1 = mfma16(a4[s], bv[g][s], acc1);
-            else acc0 = mfma16(a4[s], bv[g][s], acc0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float a1 = ok ? av[g][rb][s] : 0.f;
+                acc[rb][s & 1] = mfma16(a1, bv[g][s], acc[rb][s & 1]);
+            }
         }
     };
     for (int base = 0; base < per_wave; base += GB) {
@@ -98,14 +113,20 @@ __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
         }
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) red[(w * 16 + 4 * q + v) * 16 + j] = acc0[v] + acc1[v];
-    __syncthreads();
-    float s = 0.f;
-    if (tid < 256) {
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) s += red[(ww * 16 + erow) * 16 + ecol];
+        for (int v = 0; v < 4; ++v)
+            red[((w * RB + rb) * 16 + 4 * q + v) * 16 + j] = acc[rb][0][v] + acc[rb][1][v];
+    __syncthreads();
+    if (tid >= 256) return;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        float s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += red[((ww * RB + rb) * 16 + erow) * 16 + ecol];
+        if (live)
+            a.rpart[(size_t)ks * a.Bp * Fp + eoff + rb * estep] = (a.xp != nullptr) ? xv[rb] - s : s;
     }
-    if (live && tid < 256) a.rpart[(size_t)ks * a.Bp * Fp + eoff] = (a.xp != nullptr) ? xv - s : s;
 }
 
 __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
@@ -114,23 +135,38 @@ struct Workspace {
     size_t off_xp, off_valid, off_seen, off_psum_all, off_rpart, off_h0, off_h1, off_state, off_rs,
         off_psum, off_t, total;
     int Bp, Fp, Np, numA, KS, nch_ks;
+    int RB;                // 16-row blocks per workgroup (1 or 2); Bp is a multiple of 16*RB
     int nft_main, ntail;   // forward: bins 16*nft_main .. F-1 (at most MAX_TAIL) are handled outside the MFMA tiles
     size_t off_qpart, off_xtail, off_xcur;
 };
 
 Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     Workspace W;
-    W.Bp = pad_b(d->B);
     W.Fp = pad_f(d->F);
     W.Np = pad_n(d->N);
     W.numA = W.Np / ATOMS;
-    // atom ranges per (row tile, bin tile) in cell_b: enough workgroups to cover the 256 CUs
     W.ntail = (d->F % 16 != 0 && d->F % 16 <= MAX_TAIL && d->F > 16) ? d->F % 16 : 0;
     W.nft_main = W.ntail ? d->F / 16 : W.Fp / 16;
-    const int tiles = (W.Bp / ROWS) * W.nft_main;
+    // Row blocks per workgroup.  Measured on MI355X (F=513, N=2000, K=25; frames/s with 1 / 2 / 4
+    // row blocks): B=128 343k / 332k / 206k, B=256 431k / 486k / 399k, B=512 526k / 572k / 537k,
+    // B=1024 577k / 636k / 595k -- two blocks pay once every CU holds >= 2 such workgroups; four
+    // leave too few waves per CU to hide the operand latency.
+    W.RB = 1;
+    {
+        const int groups = round_up(d->B, ROWS * 2) / (ROWS * 2);
+        if (groups * W.numA >= 500 && groups * W.nft_main * 2 >= 500) W.RB = 2;
+    }
+    if (const char* e = getenv("DRNMF_RB")) {   // tuning aid: force the row blocking
+        const int v = atoi(e);
+        if (v == 1 || v == 2) W.RB = v;
+    }
+    W.Bp = round_up(d->B, ROWS * W.RB);
+    // atom ranges per (row tile group, bin tile) in cell_b: enough workgroups to cover the 256
+    // CUs (row-blocked kernels are instantiated for KS <= 2 only)
+    const int tiles = (W.Bp / (ROWS * W.RB)) * W.nft_main;
     const int nchN = W.Np / 16;
     int KS = 1;
-    while (KS < MAX_KS && tiles * KS < 224 && nchN / (KS * 2) >= 4) KS *= 2;
+    while (KS < (W.RB > 1 ? 2 : MAX_KS) && tiles * KS < 224 && nchN / (KS * 2) >= 4) KS *= 2;
     W.KS = KS;
     W.nch_ks = (nchN + KS - 1) / KS;
     size_t o = 0;
@@ -153,11 +189,16 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     return W;
 }
 
-void* pick_b_func(int nch_ks) {
+template <int RB>
+void* pick_b_func_rb(int nch_ks) {
     const int per_wave = (nch_ks + 7) / 8;
-    if (per_wave <= 2) return (void*)&cell_b_kernel<2>;
-    if (per_wave <= 4) return (void*)&cell_b_kernel<4>;
-    return (void*)&cell_b_kernel<8>;
+    if (per_wave <= 2) return (void*)&cell_b_kernel<2, RB>;
+    if (per_wave <= 4) return (void*)&cell_b_kernel<4, RB>;
+    return (void*)&cell_b_kernel<8, RB>;
+}
+void* pick_b_func(int nch_ks, int RB = 1) {
+    if (RB == 2) return pick_b_func_rb<2>(nch_ks);
+    return pick_b_func_rb<1>(nch_ks);
 }
 
 }  // namespace

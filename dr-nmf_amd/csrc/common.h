@@ -38,10 +38,6 @@ struct drnmf_handle_s {
     int device = 0;
     char err[512] = {0};
     std::vector<GraphEntry> graphs;
-    // side streams + events for concurrent utterance chains (created lazily, cell_forward.hip)
-    std::vector<hipStream_t> side_streams;
-    std::vector<hipEvent_t> side_done;
-    hipEvent_t fork_event = nullptr;
 };
 
 extern char g_create_err[512];

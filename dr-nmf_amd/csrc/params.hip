@@ -47,9 +47,6 @@ extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
-    for (auto s : h->side_streams) (void)hipStreamDestroy(s);
-    for (auto e : h->side_done) (void)hipEventDestroy(e);
-    if (h->fork_event) (void)hipEventDestroy(h->fork_event);
     delete h;
     return DRNMF_OK;
 }

@@ -99,10 +99,6 @@ int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d
                                     const float* initial_state, float* final_state, float* h_out,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
-/* Number of independent utterance chains drnmf_cell_forward will run concurrently for this
- * descriptor (row groups on internal side streams, forked from / joined to the caller's stream). */
-int32_t drnmf_cell_chains(const drnmf_cell_desc_t* d);
-
 /* Measurement aid (no reference counterpart; used by bench.py only): runs the first `frames`
  * frames of the same forward with plain launches, every launch bracketed by HIP events on
  * `stream`, SYNCHRONISES the stream, and returns mean durations in microseconds:

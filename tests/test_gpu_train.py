@@ -70,6 +70,7 @@ def _autograd(model, P, wmask, K, square, snmf_cost_l1_weight=None):
          trainable=("log_D", "log_alph", "log_lam1")),
     dict(B=3, T=6, F=21, r=6, K=3, untied=("log_D",), masked_head=True),
     dict(B=17, T=3, F=257, r=20, K=2, untied=("log_D", "log_alph")),
+    dict(B=250, T=2, F=513, r=1000, K=2, untied=("log_D", "log_alph")),   # row-blocked kernels
 ])
 def test_gradients_match_autograd(dev, cfg):
     cfg = dict(cfg)
@@ -90,8 +91,18 @@ def test_gradients_match_autograd(dev, cfg):
         r_ = ref[name_map.get(n, n)]
         assert r_ is not None, n
         scale = max(np.max(np.abs(r_)), 1e-12)
-        err = np.max(np.abs(g - r_)) / scale
-        assert err <= G_TOL, "%s: rel err %.3e (max ref %.3e)" % (n, err, scale)
+        if cfg["B"] * cfg["r"] >= 100000:
+            # ~1e6 activations: a handful sit within fp32 rounding of the relu kink and take the
+            # other branch than the fp64 reference (measured: 1 flip at B=130 -> one atom of every
+            # gradient off by that row's dh, all other elements 2e-5).  Bound the outliers'
+            # number and the error in norm instead of the maximum.
+            bad = np.abs(g - r_) > G_TOL * scale
+            assert bad.mean() <= 1e-3, "%s: %d elements off" % (n, bad.sum())
+            l2 = np.linalg.norm(g - r_) / max(np.linalg.norm(r_), 1e-12)
+            assert l2 <= G_TOL, "%s: rel L2 err %.3e" % (n, l2)
+        else:
+            err = np.max(np.abs(g - r_)) / scale
+            assert err <= G_TOL, "%s: rel err %.3e (max ref %.3e)" % (n, err, scale)
         checked += 1
     assert checked >= 4
 
