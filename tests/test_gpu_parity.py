@@ -475,3 +475,52 @@ def test_sdr_vs_oracle(dev, nsampl, flen):
     # correlations alone (no solve): exact to fp64 rounding of different summation orders
     want2 = O.sdr_db(est[2, :nsampl - 100], ref[2, :nsampl - 100], flen)
     assert abs(out[2] - want2) <= 1e-3                                # padding changes nothing
+
+
+def test_c_abi_status_codes_and_messages(dev):
+    """Error behaviour of the boundary: every export returns a status, never
+    throws or aborts, and drnmf_last_error carries the reason.  Empty inputs (B or T = 0) are
+    invalid arguments, as Keras rejects an empty batch."""
+    import ctypes as C
+    from drnmf_amd import _capi, ops
+    L = _capi.lib()
+    h = _capi.handle(0)
+    P, alt, labels, N = _problem(2, 3, 21, 6, 2)
+    _, params, desc = _run_cell(dev, P, alt, labels, N, 2)
+    x = torch.from_numpy(P["X"]).to(dev)
+    out = torch.empty((2, 3, N), dtype=torch.float32, device=dev)
+    ws = ops.cell_workspace(desc, dev)
+    lh0 = torch.zeros(N, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fwd(d, xx=x, pp=params, oo=out, w=ws, wbytes=None):
+        return L.drnmf_cell_forward(h, C.byref(d), _capi.ptr(xx), -1.0, _capi.ptr(pp),
+                                    _capi.ptr(lh0), 1.0, 0.0, 0.0, _capi.ptr(oo), _capi.ptr(w),
+                                    w.numel() if wbytes is None else wbytes, st)
+    assert fwd(desc) == 0
+    for field, val in (("B", 0), ("T", 0), ("K", 0), ("n_D", 3), ("alph_len", 5)):
+        bad = ops.make_desc(2, 3, 21, N, 2, n_D=2, n_alph=2)
+        setattr(bad, field, val)
+        assert fwd(bad) == -1, field
+        assert len(L.drnmf_last_error(h)) > 0
+    assert fwd(desc, xx=None) == -1                                   # NULL pointer
+    assert fwd(desc, wbytes=1024) == -4                               # workspace too small
+    assert b"workspace" in L.drnmf_last_error(h)
+    big = torch.empty(ws.numel() + 256, dtype=torch.uint8, device=dev)
+    assert fwd(desc, w=big[4:], wbytes=ws.numel()) == -1              # misaligned workspace
+    assert L.drnmf_cell_workspace_bytes(None) == 0
+    assert L.drnmf_cell_forward(None, C.byref(desc), None, 0.0, None, None, 0.0, 0.0, 0.0, None,
+                                None, 0, None) == -1                  # NULL handle
+    # the Python layer turns the codes into exceptions
+    with pytest.raises(ValueError):
+        ops.cell_forward(x[:, :0], -1.0, params, ops.make_desc(2, 0, 21, N, 2, n_D=2, n_alph=2),
+                         lh0, (1.0, 0.0, 0.0))
+    Wd, H0 = torch.rand((21, N), device=dev), torch.rand((3, N), device=dev)
+    with pytest.raises(ValueError):
+        ops.ista_forward(x[0].abs(), Wd, H0.clone(), 0.1, 0.0, 2)     # alph must be > 0
+    Hk = ops.ista_forward(x[0].abs(), Wd, H0.clone(), 0.1, 1.0, 0)    # K = 0: `for k in range(0)`
+    assert torch.equal(Hk, H0)
+    with pytest.raises(ValueError):
+        ops.stft_mag(torch.zeros((1, 100), device=dev), N=100, hop=25)   # N not a power of two
+    torch.cuda.synchronize()
+    assert fwd(desc) == 0                                             # the handle is still usable
