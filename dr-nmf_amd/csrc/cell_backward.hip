@@ -44,8 +44,8 @@ struct EdgeArgs {
 
 __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
     __shared__ float sm[ROWS][ATOMS + 1];
-    const int m = blockIdx.y;
-    const int ab = blockIdx.x;
+    const int m = blockIdx.x >> 3;                          // grid layout: see cell_a_kernel
+    const int ab = blockIdx.y * 8 + (blockIdx.x & 7);
     if (ab >= a.numA) return;
     const int tid = threadIdx.x;
     const int c = *a.c_rd;
@@ -144,9 +144,10 @@ struct BwdAArgs {
 template <int G, int KS>
 __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4 * ROWS * ATOMS];
-    const int m = blockIdx.y;
-    const bool live = (int)blockIdx.x < a.numA;
-    const int ab = live ? (int)blockIdx.x : a.numA - 1;
+    const int m = blockIdx.x >> 3;                          // grid layout: see cell_a_kernel
+    const int ab_raw = blockIdx.y * 8 + (blockIdx.x & 7);
+    const bool live = ab_raw < a.numA;
+    const int ab = live ? ab_raw : a.numA - 1;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63, j = l & 15, q = l >> 4;
@@ -552,8 +553,8 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
 
     // ---- sequential pass: T replays of the per-frame graph in reverse time ---------------------
     DRNMF_HIP(h, hipMemsetAsync(bw, 0, L.off_dh0, stream));   // dstate .. counters
-    const dim3 grid_a((unsigned)round_up(W.numA, 8), (unsigned)numM);
-    const dim3 grid_b((unsigned)round_up(nft * W.KS, 8), (unsigned)(numM / W.RB));
+    const dim3 grid_a(8u * (unsigned)numM, (unsigned)(round_up(W.numA, 8) / 8));
+    const dim3 grid_b(8u * (unsigned)(numM / W.RB), (unsigned)(round_up(nft * W.KS, 8) / 8));
 
     EdgeArgs ea;
     ea.hall = hall; ea.d_out = d_out; ea.dz_all = dz_all; ea.ia_last = ia_of(K - 1);

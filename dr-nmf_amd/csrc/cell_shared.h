@@ -31,12 +31,13 @@ struct CellBArgs {
 template <int GB, int RB = 1, int NW = 8>
 __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
     __shared__ __attribute__((aligned(16))) float red[NW * RB * 16 * 16];
-    // 2-D grid ((bin tile, atom range) padded to a multiple of 8, row tile group): see
+    // 2-D grid (x = 8 * row tile group + XCD slot, y = octet of (bin tile, atom range)): see
     // cell_a_kernel.  KS is a power of two.  Padded blocks redo the last tile with the store
     // predicated off.
-    const int m = blockIdx.y;
-    const bool live = (int)blockIdx.x < a.nft * a.KS;
-    const int rest = live ? (int)blockIdx.x : a.nft * a.KS - 1;
+    const int m = blockIdx.x >> 3;
+    const int rest_raw = blockIdx.y * 8 + (blockIdx.x & 7);
+    const bool live = rest_raw < a.nft * a.KS;
+    const int rest = live ? rest_raw : a.nft * a.KS - 1;
     const int ft = rest >> a.logKS, ks = rest & (a.KS - 1);
 
     const int tid = threadIdx.x;

@@ -25,6 +25,7 @@ def dev():
 def _setup(B, T, F, r, K, untied, untie_alph=False, square=False, seed=5, masked_head=False,
            trainable=("log_D", "log_alph")):
     from drnmf_amd import layers
+    np.random.seed(seed)          # log_h0's 'uniform' initialiser draws from the global generator
     P = O.synth_problem(B, T, F, r, seed=seed, ragged=True, density=0.15)
     if masked_head:
         P["X"][0, :2] = -1.0
@@ -82,7 +83,8 @@ def test_gradients_match_autograd(dev, cfg):
     flat = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(wmask)).clone()
     torch.cuda.synchronize()
     ref_loss, ref, cnt = _autograd(model, P, wmask, K, square)
-    assert abs(float(flat[-2]) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-9
+    big = cfg["B"] * cfg["r"] >= 100000
+    assert abs(float(flat[-2]) - ref_loss) <= (5e-5 if big else 1e-5) * abs(ref_loss) + 1e-9
     assert float(flat[-1]) == cnt
     name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
     checked = 0
@@ -91,7 +93,7 @@ def test_gradients_match_autograd(dev, cfg):
         r_ = ref[name_map.get(n, n)]
         assert r_ is not None, n
         scale = max(np.max(np.abs(r_)), 1e-12)
-        if cfg["B"] * cfg["r"] >= 100000:
+        if big:
             # ~1e6 activations: a handful sit within fp32 rounding of the relu kink and take the
             # other branch than the fp64 reference (measured: 1 flip at B=130 -> one atom of every
             # gradient off by that row's dh, all other elements 2e-5).  Bound the outliers'
