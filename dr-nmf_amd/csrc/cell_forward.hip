@@ -62,8 +62,7 @@ struct CellAArgs {
     int out_width, out_off, write_out;
 };
 
-// G = 16-bin chunks handled per wave per group (all of a group's operand loads are issued before
-// its first MFMA so that one memory round trip covers the group).  RB = 16-row blocks per
+// G = operand slots (16-bin chunks in flight per wave, prefetch distance G-1).  RB = 16-row blocks per
 // workgroup (see cell_b_kernel): every dictionary operand feeds RB row blocks.
 template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN>
 __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
@@ -117,8 +116,9 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
 
     f32x4 av[G][RB][NP];
     f32x2 bv[G][4];
-    auto load_chunk = [&](int base, int g) {
-        int c = w + NW_A * (base + g);
+    auto load_chunk = [&](int i, int g) {      // chunk i of this wave -> slot g
+        if (i >= per_wave && i > 0) return;    // wave-uniform: nothing past the last chunk
+        int c = w + NW_A * i;
         c = c > clast ? clast : c;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -133,10 +133,9 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // issuing one chunk's operand loads for all waves takes about as long as one wave's MFMAs on
     // that chunk.  Loads run PF chunks ahead of the MFMAs (enough to cover the L2/fabric latency)
     // and the two streams overlap instead of adding up.
-    constexpr int PF0 = 3;   // RB = 1 measured: 2..4 equivalent (250k frames/s), 6 slower
-    constexpr int PF = G < PF0 ? G : PF0;
+    constexpr int PF = G - 1;   // prefetch distance 2..4 measured equivalent, 6 slower (C2 shape)
 #pragma unroll
-    for (int g = 0; g < PF; ++g) load_chunk(0, g);
+    for (int g = 0; g < PF; ++g) load_chunk(g, g);
 
     // ---- epilogue operands (tiny, needed last; issued behind the GEMM operands) --------------
     const int erow = (tid & 255) >> 4, ec = (tid & 15) * 2;
@@ -158,11 +157,13 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // operand load issued so far).
     float xt[RB][MAX_TAIL];
     float qv[RB][MAX_TAIL][4];
-    f32x2 dt[MAX_TAIL] = {{0.f, 0.f}, {0.f, 0.f}};
+    // (unconditional loads: without tail bins they read tile row 0 and are never used -- a
+    // guarded load here makes hipcc wait for EVERY outstanding load before the GEMM loop)
+    f32x2 dt[MAX_TAIL];
+    const int trow = a.ntail > 0 ? a.nchunks : 0;
 #pragma unroll
     for (int i = 0; i < MAX_TAIL; ++i) {
-        if (i >= a.ntail) continue;
-        const size_t toff = ((size_t)a.nchunks * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
+        const size_t toff = ((size_t)trow * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
         dt[i] = *(const f32x2*)(a.Dn + toff);
     }
 #pragma unroll
@@ -237,15 +238,14 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
         }
     };
     // sched_barriers pin the interleave (the scheduler would otherwise regroup loads and MFMAs);
-    // the MFMAs retire their operands with counted vmcnt waits in issue order
+    // the MFMAs retire their operands with counted vmcnt waits in issue order.  The G operand
+    // slots rotate: chunk i lives in slot i mod G and its loads are issued PF = G-1 chunks ahead,
+    // so the register footprint does not grow with the number of chunks and the pipeline never
+    // drains between groups.
     for (int base = 0; base < per_wave; base += G) {
-        if (base > 0) {
-#pragma unroll
-            for (int g = 0; g < PF; ++g) load_chunk(base, g);
-        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (g + PF < G) load_chunk(base, g + PF);
+            load_chunk(base + g + PF, (g + PF) % G);
             __builtin_amdgcn_sched_barrier(0);
             compute_chunk(base, g);
             __builtin_amdgcn_sched_barrier(0);
@@ -465,10 +465,9 @@ void* a_func(bool first, bool last) {
 
 template <int KS, int RB, bool AH>
 void* a_func_g(int per_wave, bool first, bool last) {
-    // G chunks per wave per group; operand registers G * (4*KS*RB + 8): large KS pairs with small G
-    if (per_wave <= 3) return a_func<3, KS, RB, AH>(first, last);
-    if (per_wave <= 5 || KS * RB >= 4) return a_func<5, KS, RB, AH>(first, last);
-    return a_func<9, KS, RB, AH>(first, last);
+    // G operand slots; operand registers G * (4*KS*RB + 8)
+    if (per_wave <= 2) return a_func<2, KS, RB, AH>(first, last);
+    return a_func<4, KS, RB, AH>(first, last);
 }
 
 template <bool AH>

@@ -13,17 +13,17 @@ B="$ROOT/bench.py"
 # 1. the default bench line
 python3 "$B" > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"
 # 2. kernel trace + stats of the same command (1 step)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$B" --steps 1 --warmup 0 \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$B" --steps 1 --warmup 0 \
     --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 cp "$OUT"/stats/*/stats_kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null || \
     cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 # 3. PMC passes, 20 frames of the headline workload (cell + head only)
 SMALL="--frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-ista --no-train --no-slab"
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch" -o p -- python3 "$B" $SMALL \
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch" -o p -- python3 "$B" $SMALL \
     > /dev/null 2> "$OUT/pmc_fetch.err"
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d "$OUT/pmc_write" -o p -- python3 "$B" $SMALL \
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d "$OUT/pmc_write" -o p -- python3 "$B" $SMALL \
     > /dev/null 2> "$OUT/pmc_write.err"
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o p -- python3 "$B" $SMALL \
     > /dev/null 2> "$OUT/pmc_sq.err"
 python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_summary.json" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq"
