@@ -12,6 +12,8 @@ kernels do not cover raise NotImplementedError.
 """
 from collections import OrderedDict
 
+import re
+
 import numpy as np
 import torch
 
@@ -109,7 +111,9 @@ class _Layer(object):
 
     def __init__(self, name=None, **kwargs):
         if name is None:
-            base = type(self).__name__.lower()
+            # Keras' auto names: CamelCase -> snake_case + '_<n>' [K2.0.4-memory]
+            base = re.sub('(.)([A-Z][a-z0-9]+)', r'\1_\2', type(self).__name__)
+            base = re.sub('([a-z])([A-Z])', r'\1_\2', base).lower()
             i = _Layer._counters.get(base, 0) + 1
             _Layer._counters[base] = i
             name = '%s_%d' % (base, i)
@@ -121,7 +125,7 @@ class _Layer(object):
         return []
 
     def get_weights(self):
-        return [w.detach().cpu().numpy() for w in self.weights]
+        return [np.array(w.detach().cpu().numpy(), copy=True) for w in self.weights]
 
     def set_weights(self, weights):
         ws = self.weights
@@ -473,6 +477,15 @@ class SimpleDeepRNN(_Layer):
 
 # ------------------------------------------------------------------------------------------
 # build_unfolded_snmf  (enhance.py:209-317)
+def _require_h5py(path):
+    try:
+        import h5py
+        return h5py
+    except ImportError:
+        raise ImportError("reading/writing the Keras HDF5 weight file %r needs h5py, which this "
+                          "environment lacks; use a '.npz' path (same tree of names)" % path)
+
+
 # ------------------------------------------------------------------------------------------
 class UnfoldedSNMFModel(object):
     """Masking -> SimpleDeepRNN -> [:r]/[r:] -> DenseNonNegW x2 -> (square) -> A/(A+B).
@@ -489,13 +502,98 @@ class UnfoldedSNMFModel(object):
         return self.cell.weights + self.clean.weights + self.noise.weights
 
     def get_weights(self):
-        return [w.detach().cpu().numpy() for w in self.weights]
+        return [np.array(w.detach().cpu().numpy(), copy=True) for w in self.weights]
 
     def set_weights(self, weights):
         n = len(self.cell.weights)
         self.cell.set_weights(weights[:n])
         self.clean.set_weights(weights[n:n + 1])
         self.noise.set_weights(weights[n + 1:n + 2])
+
+    # -- weight files (enhance.py:1096, 1119-1129, 1135, 1160-1166: ModelCheckpoint(
+    #    save_weights_only=True) / save_weights / load_weights on Keras HDF5 files) ------------
+    def _weighted_layers(self):
+        return [l for l in self.layers if l.weights]
+
+    def weights_tree(self):
+        """Keras' save_weights layout as a flat dict: 'layer_names', '<layer>/weight_names' and one
+        array per '<layer>/<weight name>' (custom_layers.py:203-228 names the cell's weights
+        '<layer>_log_h0', '<layer>_<alt key>'; Dense kernels are 'kernel')."""
+        tree = {}
+        names = []
+        for l in self._weighted_layers():
+            names.append(l.name)
+            if hasattr(l, 'weight_names'):
+                wn = l.weight_names
+            elif len(l.weights) == 1:
+                wn = ['kernel']
+            else:
+                wn = ['weight_%d' % i for i in range(len(l.weights))]
+            tree[l.name + '/weight_names'] = np.array(wn)
+            for n, w in zip(wn, l.get_weights()):
+                tree[l.name + '/' + n] = w
+        tree['layer_names'] = np.array(names)
+        return tree
+
+    def load_weights_tree(self, tree):
+        """Inverse of weights_tree, with Keras' topological matching (layers that own weights, in
+        order); inside the recurrent cell weights are matched BY NAME, because the reference's
+        order there is Python-2 dict order (custom_layers.py:216-228)."""
+        file_layers = [str(n) for n in tree['layer_names']
+                       if len(tree[str(n) + '/weight_names']) > 0]
+        mine = self._weighted_layers()
+        if len(file_layers) != len(mine):
+            raise ValueError('weight file has %d layers with weights, the model has %d'
+                             % (len(file_layers), len(mine)))
+        for fname, layer in zip(file_layers, mine):
+            wn = [str(n) for n in tree[fname + '/weight_names']]
+            vals = [np.asarray(tree[fname + '/' + n]) for n in wn]
+            if hasattr(layer, 'weight_names'):
+                strip = lambda n, pre: n[len(pre) + 1:] if n.startswith(pre + '_') else n
+                by_key = {strip(n.split(':')[0], fname): v for n, v in zip(wn, vals)}
+                want = [strip(n, layer.name) for n in layer.weight_names]
+                missing = [k for k in want if k not in by_key]
+                if missing:
+                    raise ValueError('weight file lacks %s for layer %s' % (missing, layer.name))
+                vals = [by_key[k] for k in want]
+            layer.set_weights(vals)
+
+    def save_weights(self, path):
+        """'.npz': the weights_tree dict (numpy).  '.h5'/'.hdf5': the same tree written with h5py
+        in Keras 2.0.4's layout -- h5py is not part of this image, so that branch is unpinned."""
+        tree = self.weights_tree()
+        if path.endswith('.npz'):
+            np.savez(path, **tree)
+            return
+        h5py = _require_h5py(path)
+        with h5py.File(path, 'w') as f:
+            f.attrs['layer_names'] = [n.encode('utf8') for n in tree['layer_names']]
+            f.attrs['backend'] = b'theano'
+            f.attrs['keras_version'] = b'2.0.4'
+            for ln in tree['layer_names']:
+                g = f.create_group(str(ln))
+                wn = [str(n) for n in tree[str(ln) + '/weight_names']]
+                g.attrs['weight_names'] = [n.encode('utf8') for n in wn]
+                for n in wn:
+                    g.create_dataset(n, data=tree[str(ln) + '/' + n])
+
+    def load_weights(self, path):
+        if path.endswith('.npz'):
+            with np.load(path, allow_pickle=False) as z:
+                return self.load_weights_tree({k: z[k] for k in z.files})
+        h5py = _require_h5py(path)
+        dec = lambda b: b.decode('utf8') if isinstance(b, bytes) else str(b)
+        tree = {}
+        with h5py.File(path, 'r') as f:
+            g0 = f['model_weights'] if 'layer_names' not in f.attrs and 'model_weights' in f else f
+            names = [dec(n) for n in g0.attrs['layer_names']]
+            tree['layer_names'] = np.array(names)
+            for ln in names:
+                wn = [dec(n) for n in g0[ln].attrs['weight_names']]
+                tree[ln + '/weight_names'] = np.array(wn)
+                for n in wn:
+                    tree[ln + '/' + n] = np.asarray(g0[ln][n])
+        return self.load_weights_tree(tree)
 
     def forward(self, x, want_hidden=False):
         h = self.cell.call(x, mask_value=self.mask_value)

@@ -120,3 +120,52 @@ def test_build_unfolded_snmf_argument_errors():
     with pytest.raises(ValueError):
         layers.build_unfolded_snmf(dict(base, params_trainable=["log_D"],
                                         transform_before_irm="cube"))
+
+
+def test_weight_files_follow_keras_layout(tmp_path):
+    """save_weights / load_weights (enhance.py:1096-1166) on the Keras tree of names: layers with
+    weights in order, the cell's weights matched by name (the reference's order there is Python-2
+    dict order), a reference-style layer name accepted, missing weights rejected.  HDF5 itself
+    needs h5py (absent here): that branch must fail loudly."""
+    from drnmf_amd import layers
+    P = O.synth_problem(2, 3, 21, 6, seed=5)
+    p = dict(input_dim=21, hidden_dim=12, output_dim=21, mask_value=-1., maxseq=3, K_layers=2,
+             W=P["W"], alph=3.0, lam1=0.3, params_untied=["log_D"], params_trainable=["log_D"])
+    m = layers.build_unfolded_snmf(p, device="cpu")
+    cell_name = m.cell.name
+    assert re.match(r"simple_deep_rnn_\d+$", cell_name)
+    tree = m.weights_tree()
+    assert list(tree["layer_names"]) == [cell_name, "clean_est", "noise_est"]
+    assert tree[cell_name + "/weight_names"][0] == cell_name + "_log_h0"
+    assert tree["clean_est/kernel"].shape == (6, 21)
+    path = str(tmp_path / "w.npz")
+    m.save_weights(path)
+    w0 = m.get_weights()
+    m.set_weights([a + 1 for a in w0])
+    m.load_weights(path)
+    for a, b in zip(w0, m.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    # a file as the reference would write it: other layer names, the cell's weights in another order
+    ref = {"layer_names": np.array(["simple_deep_rnn_1", "time_distributed_1",
+                                    "time_distributed_2"])}
+    wn = [str(n) for n in tree[cell_name + "/weight_names"]]
+    order = [3, 0, 5, 1, 6, 2, 4][:len(wn)]
+    rn = ["simple_deep_rnn_1" + wn[i][len(cell_name):] for i in order]
+    ref["simple_deep_rnn_1/weight_names"] = np.array(rn)
+    for i, n in zip(order, rn):
+        ref["simple_deep_rnn_1/" + n] = tree[cell_name + "/" + wn[i]] * 2
+    for src, dst in (("clean_est", "time_distributed_1"), ("noise_est", "time_distributed_2")):
+        ref[dst + "/weight_names"] = np.array(["kernel"])
+        ref[dst + "/kernel"] = tree[src + "/kernel"] * 2
+    m.load_weights_tree(ref)
+    for a, b in zip(w0, m.get_weights()):
+        np.testing.assert_array_equal(2 * a, b)
+    bad = dict(ref)
+    bad["simple_deep_rnn_1/weight_names"] = np.array(rn[:-1])
+    with pytest.raises(ValueError):
+        m.load_weights_tree(bad)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            m.load_weights(str(tmp_path / "model.hdf5"))
