@@ -607,17 +607,24 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
         key.push_back(b0); key.push_back(b1); key.push_back(b2);
     }
+    // several frames per graph, as in the forward (cell_forward.hip)
+    int fpg_max = 800 / (2 * K - 1);         // ~800 kernel nodes per graph
+    fpg_max = fpg_max < 1 ? 1 : (fpg_max > 64 ? 64 : fpg_max);
+    if (fpg_max > T) fpg_max = T;
+    auto get_graph = [&](int fpg, hipGraphExec_t* out) -> int32_t {
+    std::vector<uint64_t> gkey = key;
+    gkey.push_back((uint64_t)fpg);
     GraphEntry* entry = nullptr;
     for (auto& g : h->graphs)
-        if (g.key == key) { entry = &g; break; }
+        if (g.key == gkey) { entry = &g; break; }
     if (!entry) {
-        if (h->graphs.size() >= 8) {
+        if (h->graphs.size() >= 24) {   // bounded cache shared with the forward: drop the oldest
             (void)hipGraphExecDestroy(h->graphs.front().exec);
             (void)hipGraphDestroy(h->graphs.front().graph);
             h->graphs.erase(h->graphs.begin());
         }
         GraphEntry ge;
-        ge.key = key;
+        ge.key = gkey;
         DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
         hipGraphNode_t last = nullptr;
         auto add = [&](void* func, dim3 grid, unsigned block, void* argp) -> hipError_t {
@@ -632,22 +639,38 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
             last = node;
             return e;
         };
-        DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, &ea));
-        for (int k = K - 1; k >= 1; --k) {
-            CellBArgs b = make_b(k);
-            DRNMF_HIP(h, add(pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, &b));
-            BwdAArgs a = make_a(k);
-            DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, &a));
-        }
-        if (K == 1) {
-            int* cp = cA;
-            DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, &cp));
+        for (int rep = 0; rep < fpg; ++rep) {
+            DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, &ea));
+            for (int k = K - 1; k >= 1; --k) {
+                CellBArgs b = make_b(k);
+                DRNMF_HIP(h, add(pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, &b));
+                BwdAArgs a = make_a(k);
+                DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, &a));
+            }
+            if (K == 1) {
+                int* cp = cA;
+                DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, &cp));
+            }
         }
         DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
         h->graphs.push_back(ge);
         entry = &h->graphs.back();
     }
-    for (int t = 0; t < T; ++t) DRNMF_HIP(h, hipGraphLaunch(entry->exec, stream));
+    *out = entry->exec;
+    return DRNMF_OK;
+    };
+    {
+        hipGraphExec_t exec_n = nullptr, exec_1 = nullptr;
+        int32_t grc = get_graph(fpg_max, &exec_n);
+        if (grc) return grc;
+        int t = 0;
+        for (; t + fpg_max <= T; t += fpg_max) DRNMF_HIP(h, hipGraphLaunch(exec_n, stream));
+        if (t < T) {
+            grc = get_graph(1, &exec_1);
+            if (grc) return grc;
+            for (; t < T; ++t) DRNMF_HIP(h, hipGraphLaunch(exec_1, stream));
+        }
+    }
     hipLaunchKernelGGL(bwd_edge_kernel, grid_a, dim3(256), 0, stream, ea);   // t = -1
     hipLaunchKernelGGL(dlogh0_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dh0_part,
                        log_h0, d_log_h0, N, W.Np, numM);

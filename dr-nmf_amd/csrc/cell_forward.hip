@@ -558,6 +558,17 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         key.push_back(b0); key.push_back(b1); key.push_back(b2);
     }
     const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0;
+    // frames per graph: the kernels advance the device-side frame counters themselves, so a
+    // graph may hold several frames' worth of nodes (fewer graph launches from the host)
+    // (measured at the C2 shape: 1 / 2 / 4 / 8 / 20 frames per graph -> 251.1k / 253.9k / 255.6k /
+    // 256.1k / 256.3k frames/s).  The remainder T mod FPG runs on a one-frame graph.
+    int fpg_max = 800 / (2 * d->K - 1);      // ~800 kernel nodes per graph
+    fpg_max = fpg_max < 1 ? 1 : (fpg_max > 64 ? 64 : fpg_max);
+    if (const char* e = getenv("DRNMF_FPG")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) fpg_max = v;
+    }
+    if (fpg_max > d->T) fpg_max = d->T;
 
     const int numM = W.Bp / (ROWS * W.RB), nft = W.nft_main;   // MFMA bin tiles (tail bins handled apart)
     const dim3 grid_a(8u * (unsigned)numM, (unsigned)(round_up(W.numA, 8) / 8));
@@ -677,9 +688,12 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         return DRNMF_OK;
     }
 
+    auto get_graph = [&](int fpg, hipGraphExec_t* out) -> int32_t {
+    std::vector<uint64_t> gkey = key;
+    gkey.push_back((uint64_t)fpg);
     GraphEntry* entry = nullptr;
     for (auto& g : h->graphs)
-        if (g.key == key) { entry = &g; break; }
+        if (g.key == gkey) { entry = &g; break; }
     if (!entry) {
         if (h->graphs.size() >= 24) {   // bounded cache: drop the oldest
             (void)hipGraphExecDestroy(h->graphs.front().exec);
@@ -687,7 +701,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             h->graphs.erase(h->graphs.begin());
         }
         GraphEntry ge;
-        ge.key = key;
+        ge.key = gkey;
         DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
         hipGraphNode_t last = nullptr;
         auto add = [&](void* func, dim3 grid, unsigned block, void* argp) -> hipError_t {
@@ -706,23 +720,37 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             last = node;
             return e;
         };
-        for (int k = 0; k < K; ++k) {
-            CellAArgs a = make_a(k);
-            DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 64 * NW_A, &a));
-            if (k < K - 1) {
-                CellBArgs b = make_b(k);
-                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, &b));
+        for (int rep = 0; rep < fpg; ++rep) {
+            for (int k = 0; k < K; ++k) {
+                CellAArgs a = make_a(k);
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 64 * NW_A, &a));
+                if (k < K - 1) {
+                    CellBArgs b = make_b(k);
+                    DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, &b));
+                }
             }
-        }
-        if (K == 1) {
-            int* tp = tA;
-            DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, &tp));
+            if (K == 1) {
+                int* tp = tA;
+                DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, &tp));
+            }
         }
         DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
         h->graphs.push_back(ge);
         entry = &h->graphs.back();
     }
-    for (int t = 0; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(entry->exec, stream));
+    *out = entry->exec;
+    return DRNMF_OK;
+    };
+    hipGraphExec_t exec_n = nullptr, exec_1 = nullptr;
+    int32_t grc = get_graph(fpg_max, &exec_n);
+    if (grc) return grc;
+    int t = 0;
+    for (; t + fpg_max <= d->T; t += fpg_max) DRNMF_HIP(h, hipGraphLaunch(exec_n, stream));
+    if (t < d->T) {
+        grc = get_graph(1, &exec_1);     // (may evict; exec_n is not used again)
+        if (grc) return grc;
+        for (; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(exec_1, stream));
+    }
     return DRNMF_OK;
 }
 
