@@ -16,7 +16,7 @@ DIV_ED, DIV_KL, DIV_BETA = 0, 1, 2
 class CellDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("B", "T", "F", "N", "K", "n_D", "n_alph", "alph_len", "n_lam",
-                 "return_all_hidden")]
+                 "return_all_hidden", "operand_f16")]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t

@@ -37,7 +37,7 @@
 namespace {
 
 struct CellAArgs {
-    const float* Dn;         // [Fp][Np]  this layer's unit-norm dictionary
+    const void* Dn;          // packed unit-norm dictionary of this layer (fp32 Dp, or the fp16 DpA packing)
     const float* inv_alpha;  // [Np]
     const float* bias;       // [Np]
     const float* rsrc;       // first layer: xp [T][Bp][Fp]; else rpart [KS][Bp][Fp]
@@ -53,7 +53,8 @@ struct CellAArgs {
     int* t_wr;               // counter to publish (or null)
     int t_wr_add;
     float u0d, u0o, uko;
-    const float* Dn_next;    // packed dictionary of layer k+1 (tail rows for the next x^ tail)
+    const float* Dtail;      // [MAX_TAIL][Np] tail-bin rows of this layer's dictionary
+    const float* Dtail_next; // the same of layer k+1 (for the next x^ tail partials)
     const float* q_in;       // [numA][MAX_TAIL][Bp] tail-bin x^ partials of the previous layer
     float* q_out;            // same, produced for the next layer
     float* xtail;            // [MAX_TAIL][Bp] tail bins of x_t (published by the first layer)
@@ -64,7 +65,9 @@ struct CellAArgs {
 
 // G = operand slots (16-bin chunks in flight per wave, prefetch distance G-1).  RB = 16-row blocks per
 // workgroup (see cell_b_kernel): every dictionary operand feeds RB row blocks.
-template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN>
+// HALF: residual and dictionary enter the matrix cores as fp16 (v_mfma_f32_16x16x16_f16: two MFMAs
+// per 16-bin chunk instead of eight), fp32 accumulation; everything else stays fp32.
+template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN, bool HALF = false>
 __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     constexpr bool WRITE_OUT = IS_LAST || ALL_HIDDEN;
     __shared__ __attribute__((aligned(16))) float red[NW_A * RB * ROWS * ATOMS];   // [NW][RB][16][32]
@@ -100,7 +103,9 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     const float* arow = rsrc + (size_t)mb0 * nft * 256 + j * 16 + q * 4;          // + 256*c
     const size_t astep = (size_t)nft * 256;                                        // per row block
     // B: blocks (c, ac0 | ac0+1) of Dp, rows 4s+q, atoms 2j, 2j+1 of the 32
-    const float* brow = a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + q * 16 + (j & 7) * 2;
+    const float* brow = (const float*)a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + q * 16 + (j & 7) * 2;
+    // fp16: DpA block (c, ac0 + j/8), lane's 8 halves = atoms 2(j%8), 2(j%8)+1 x k = 4q..4q+3
+    const f16* brow16 = (const f16*)a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + ((j & 7) * 4 + q) * 8;
     const size_t bstep = (size_t)NAC * 256;                                        // per chunk c
 
     // ---- GEMM operands first (critical path), wave w takes chunks c = w (mod 4) -------------
@@ -116,6 +121,7 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
 
     f32x4 av[G][RB][NP];
     f32x2 bv[G][4];
+    f16x4 bh[G][2];
     auto load_chunk = [&](int i, int g) {      // chunk i of this wave -> slot g
         if (i >= per_wave && i > 0) return;    // wave-uniform: nothing past the last chunk
         int c = w + NW_A * i;
@@ -125,9 +131,15 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
 #pragma unroll
             for (int ks = 0; ks < NP; ++ks)
                 av[g][rb][ks] = *(const f32x4*)(arow + rb * astep + 256 * c + (size_t)ks * pstride);
+        if (HALF) {
+            const f16x4* bp = (const f16x4*)(brow16 + (size_t)c * bstep);
+            bh[g][0] = bp[0];
+            bh[g][1] = bp[1];
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
+            for (int s = 0; s < 4; ++s)
+                bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
+        }
     };
     // Software pipeline: the texture path of a CU moves 64 B/clk and is shared by the 4 waves, so
     // issuing one chunk's operand loads for all waves takes about as long as one wave's MFMAs on
@@ -157,15 +169,11 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // operand load issued so far).
     float xt[RB][MAX_TAIL];
     float qv[RB][MAX_TAIL][4];
-    // (unconditional loads: without tail bins they read tile row 0 and are never used -- a
-    // guarded load here makes hipcc wait for EVERY outstanding load before the GEMM loop)
+    // (unconditional loads: a guarded load here makes hipcc wait for EVERY outstanding load
+    // before the GEMM loop; without tail bins the values are never used)
     f32x2 dt[MAX_TAIL];
-    const int trow = a.ntail > 0 ? a.nchunks : 0;
 #pragma unroll
-    for (int i = 0; i < MAX_TAIL; ++i) {
-        const size_t toff = ((size_t)trow * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
-        dt[i] = *(const f32x2*)(a.Dn + toff);
-    }
+    for (int i = 0; i < MAX_TAIL; ++i) dt[i] = *(const f32x2*)(a.Dtail + (size_t)i * Np + n);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int rg = (mb0 + rb) * ROWS + erow;
@@ -214,6 +222,9 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // ---- GEMM:  g[16*RB x 32] = r[16*RB x F] . Dn[F x 32] ---------------------------------------
     auto compute_chunk = [&](int base, int g) {
         const bool ok = base + g < per_wave;
+        // (wave-uniform) past the last chunk the slot's registers were never loaded: skip, do not
+        // multiply garbage by zero (an fp16 bit pattern is Inf/NaN one time in 32)
+        if (!ok) return;
         f32x4 r4[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -226,7 +237,15 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
                 const int c = w + NW_A * (base + g);
                 *(f32x4*)(a.xcur + (size_t)(mb0 + rb) * nft * 256 + 256 * c + j * 16 + q * 4) = r4[rb];
             }
-            if (!ok) r4[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (HALF) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const f16x4 rh = {(f16)r4[rb][0], (f16)r4[rb][1], (f16)r4[rb][2], (f16)r4[rb][3]};
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(rh, bh[g][0], acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(rh, bh[g][1], acc[rb][1], 0, 0, 0);
+            }
+            return;
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -339,8 +358,7 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
 #pragma unroll
             for (int i = 0; i < MAX_TAIL; ++i) {
                 if (i >= a.ntail) continue;
-                const size_t toff = ((size_t)a.nchunks * NAC + ac0 + (ec >> 4)) * 256 + i * 16 + (ec & 15);
-                const f32x2 dn = *(const f32x2*)(a.Dn_next + toff);
+                const f32x2 dn = *(const f32x2*)(a.Dtail_next + (size_t)i * Np + n);
                 float sq = hn[0] * dn[0] + hn[1] * dn[1];
                 sq += __shfl_xor(sq, 8, 16);
                 sq += __shfl_xor(sq, 4, 16);
@@ -455,38 +473,40 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
     if (tid == 0) { tptr[0] = 0; tptr[16] = 0; }
 }
 
-template <int G, int KS, int RB, bool AH>
+template <int G, int KS, int RB, bool AH, bool HALF>
 void* a_func(bool first, bool last) {
-    if (first && last) return (void*)&cell_a_kernel<G, KS, RB, true, true, AH>;
-    if (first) return (void*)&cell_a_kernel<G, KS, RB, true, false, AH>;
-    if (last) return (void*)&cell_a_kernel<G, KS, RB, false, true, AH>;
-    return (void*)&cell_a_kernel<G, KS, RB, false, false, AH>;
+    if (first && last) return (void*)&cell_a_kernel<G, KS, RB, true, true, AH, HALF>;
+    if (first) return (void*)&cell_a_kernel<G, KS, RB, true, false, AH, HALF>;
+    if (last) return (void*)&cell_a_kernel<G, KS, RB, false, true, AH, HALF>;
+    return (void*)&cell_a_kernel<G, KS, RB, false, false, AH, HALF>;
 }
 
-template <int KS, int RB, bool AH>
+template <int KS, int RB, bool AH, bool HALF>
 void* a_func_g(int per_wave, bool first, bool last) {
     // G operand slots; operand registers G * (4*KS*RB + 8)
-    if (per_wave <= 2) return a_func<2, KS, RB, AH>(first, last);
-    return a_func<4, KS, RB, AH>(first, last);
+    if (per_wave <= 2) return a_func<2, KS, RB, AH, HALF>(first, last);
+    return a_func<4, KS, RB, AH, HALF>(first, last);
 }
 
-template <bool AH>
+template <bool AH, bool HALF>
 void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last) {
     // row-blocked variants exist for KS <= 2 (workspace_layout never pairs RB > 1 with more)
-    if (RB == 2) return KS == 1 ? a_func_g<1, 2, AH>(per_wave, first, last)
-                                : a_func_g<2, 2, AH>(per_wave, first, last);
+    if (RB == 2) return KS == 1 ? a_func_g<1, 2, AH, HALF>(per_wave, first, last)
+                                : a_func_g<2, 2, AH, HALF>(per_wave, first, last);
     switch (KS) {
-        case 1: return a_func_g<1, 1, AH>(per_wave, first, last);
-        case 2: return a_func_g<2, 1, AH>(per_wave, first, last);
-        case 4: return a_func_g<4, 1, AH>(per_wave, first, last);
-        default: return a_func_g<8, 1, AH>(per_wave, first, last);
+        case 1: return a_func_g<1, 1, AH, HALF>(per_wave, first, last);
+        case 2: return a_func_g<2, 1, AH, HALF>(per_wave, first, last);
+        case 4: return a_func_g<4, 1, AH, HALF>(per_wave, first, last);
+        default: return a_func_g<8, 1, AH, HALF>(per_wave, first, last);
     }
 }
 
-void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_hidden) {
+void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_hidden, bool half) {
     const int per_wave = (nchunks + NW_A - 1) / NW_A;
-    return all_hidden ? pick_a_func_ah<true>(per_wave, KS, RB, first, last)
-                      : pick_a_func_ah<false>(per_wave, KS, RB, first, last);
+    if (half)   // forward only: the all-hidden output exists for the BPTT, which is fp32
+        return pick_a_func_ah<false, true>(per_wave, KS, RB, first, last);
+    return all_hidden ? pick_a_func_ah<true, false>(per_wave, KS, RB, first, last)
+                      : pick_a_func_ah<false, false>(per_wave, KS, RB, first, last);
 }
 
 }  // namespace
@@ -550,7 +570,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     const bool ablate = getenv("DRNMF_ABLATE") != nullptr;
     std::vector<uint64_t> key = {
         (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N, (uint64_t)d->K,
-        (uint64_t)d->n_D, (uint64_t)d->return_all_hidden, (uint64_t)(uintptr_t)params,
+        (uint64_t)d->n_D, (uint64_t)d->return_all_hidden + 2 * (uint64_t)(d->operand_f16 != 0),
+        (uint64_t)(uintptr_t)params,
         (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)ablate};
     {
         uint32_t b0, b1, b2;
@@ -573,9 +594,15 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     const int numM = W.Bp / (ROWS * W.RB), nft = W.nft_main;   // MFMA bin tiles (tail bins handled apart)
     const dim3 grid_a(8u * (unsigned)numM, (unsigned)(round_up(W.numA, 8) / 8));
     const dim3 grid_b(8u * (unsigned)numM, (unsigned)(round_up(nft * W.KS, 8) / 8));
-    const float* Dn_base = (const float*)(pb + L.off_dn);
-    const size_t dstride = (size_t)L.Fp * L.Np;
+    const bool half = d->operand_f16 != 0;
+    // per stored layer Fp*Np*4 bytes: the fp32 packing, or the fp16 DpA packing followed by DpB
+    const char* Dn_base = pb + L.off_dn;
+    const size_t dstride = (size_t)L.Fp * L.Np * 4;
     auto Dn_of = [&](int k) { return Dn_base + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
+    auto DnB_of = [&](int k) { return Dn_of(k) + (half ? dstride / 2 : 0); };
+    auto tail_of = [&](int k) {
+        return (const float*)(pb + L.off_tail) + (d->n_D == 1 ? 0 : (size_t)k * MAX_TAIL * L.Np);
+    };
 
     auto make_a = [&](int k) {
         CellAArgs a;
@@ -601,7 +628,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
         a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
         a.numA = W.numA; a.nchunks = nft; a.KS = W.KS; a.ntail = W.ntail;
-        a.Dn_next = Dn_of(k + 1 < K ? k + 1 : k);
+        a.Dtail = tail_of(k);
+        a.Dtail_next = tail_of(k + 1 < K ? k + 1 : k);
         float* qp = (float*)(ws + W.off_qpart);
         const size_t qstride = (size_t)W.numA * MAX_TAIL * W.Bp;
         a.q_in = qp + (size_t)((k + 1) & 1) * qstride;    // written by layer k-1
@@ -615,7 +643,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     };
     auto make_b = [&](int k) {   // between layer k and k+1
         CellBArgs b;
-        b.Dn_next = Dn_of(k + 1);
+        b.Dn_next = DnB_of(k + 1);
         b.h = hb[k & 1];
         b.xp = (const float*)(ws + W.off_xcur);
         b.rpart = rpart;
@@ -648,13 +676,13 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 void* kp[1] = {&a};
                 DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
                 DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1,
-                                                         d->return_all_hidden != 0),
+                                                         d->return_all_hidden != 0, half),
                                              grid_a, dim3(64 * NW_A), kp, 0, stream));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     void* kb[1] = {&b};
                     DRNMF_HIP(h, mark(1));
-                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks, W.RB), grid_b, dim3(64 * NW_B), kb, 0,
+                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks, W.RB, half), grid_b, dim3(64 * NW_B), kb, 0,
                                                  stream));
                 }
             }
@@ -723,10 +751,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         for (int rep = 0; rep < fpg; ++rep) {
             for (int k = 0; k < K; ++k) {
                 CellAArgs a = make_a(k);
-                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1, d->return_all_hidden != 0), grid_a, 64 * NW_A, &a));
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1, d->return_all_hidden != 0, half), grid_a, 64 * NW_A, &a));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
-                    DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, &b));
+                    DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB, half), grid_b, 64 * NW_B, &b));
                 }
             }
             if (K == 1) {

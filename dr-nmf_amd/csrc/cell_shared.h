@@ -9,12 +9,11 @@ namespace {
 constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
 constexpr int ATOMS = 32;   // atoms per cell_a workgroup
 constexpr int MAX_KS = 8;
-constexpr int MAX_TAIL = 2;   // STFT sizes are 2^k + 1: the odd bin(s) must not cost a whole 16-bin tile
 constexpr int NW_B = 8;    // waves per cell_b workgroup (more requests in flight per CU)
 constexpr int NW_A = 4;    // waves per cell_a workgroup (8 measured slower: 224k vs 232k frames/s)
 
 struct CellBArgs {
-    const float* Dn_next;    // [Fp][Np]  next layer's dictionary
+    const void* Dn_next;     // packed dictionary of the next layer (fp32 Dp, or the fp16 DpB packing)
     const float* h;          // [Bp][Np]  this layer's h
     const float* xp;         // [Bp][Fp] packed x of the CURRENT frame (republished by layer 0's cell_a,
                              // so this kernel needs no frame index); NULL: rpart[ks] = +acc (backward)
@@ -28,7 +27,9 @@ struct CellBArgs {
 // GB = 16-atom chunks per wave per group.  RB = 16-row blocks per workgroup: large batches (the
 // reference predicts in slabs of 250 utterances, enhance.py:1189-1193) reuse every dictionary
 // operand for RB row blocks, which divides the operand traffic per flop by up to (1 + RB) / 2RB.
-template <int GB, int RB = 1, int NW = 8>
+// HALF: both operands enter the matrix cores as fp16 (v_mfma_f32_16x16x16_f16: one MFMA per
+// 16-atom chunk instead of four), fp32 accumulation.
+template <int GB, int RB = 1, int NW = 8, bool HALF = false>
 __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
     __shared__ __attribute__((aligned(16))) float red[NW * RB * 16 * 16];
     // 2-D grid (x = 8 * row tile group + XCD slot, y = octet of (bin tile, atom range)): see
@@ -56,16 +57,19 @@ __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
     // 16c + 4q + {0..3} in row j -> one contiguous 1 KB block per wave instruction
     const float* arow = a.h + ((size_t)m * RB * NAC + cbase) * 256 + j * 16 + q * 4;     // + 256*c
     const size_t astep = (size_t)NAC * 256;                                              // per row block
-    const float* brow = a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;   // + 256*c
+    const float* brow = (const float*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;
+    const f16* brow16 = (const f16*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;
 
     // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
     f32x4 av[GB][RB], bv[GB];
+    f16x4 bh[GB];
     auto load_chunk = [&](int base, int g) {
         int c = w + NW * (base + g);
         c = c > clast ? clast : c;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) av[g][rb] = *(const f32x4*)(arow + rb * astep + 256 * c);
-        bv[g] = *(const f32x4*)(brow + 256 * c);
+        if (HALF) bh[g] = *(const f16x4*)(brow16 + 256 * c);
+        else bv[g] = *(const f32x4*)(brow + 256 * c);
     };
     // software pipeline: loads run PF chunks ahead of the MFMAs (see cell_a_kernel)
     constexpr int PF0 = RB > 1 ? 3 : 6;
@@ -91,6 +95,16 @@ __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
     auto compute_chunk = [&](int base, int g) {
         const bool ok = base + g < per_wave;
         // two independent accumulator chains per row block hide the dependent MFMA latency
+        if (HALF) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                f16x4 ah;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ah[e] = ok ? (f16)av[g][rb][e] : (f16)0.f;
+                acc[rb][g & 1] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh[g], acc[rb][g & 1], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -190,16 +204,17 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     return W;
 }
 
-template <int RB>
+template <int RB, bool HALF>
 void* pick_b_func_rb(int nch_ks) {
     const int per_wave = (nch_ks + 7) / 8;
-    if (per_wave <= 2) return (void*)&cell_b_kernel<2, RB>;
-    if (per_wave <= 4) return (void*)&cell_b_kernel<4, RB>;
-    return (void*)&cell_b_kernel<8, RB>;
+    if (per_wave <= 2) return (void*)&cell_b_kernel<2, RB, 8, HALF>;
+    if (per_wave <= 4) return (void*)&cell_b_kernel<4, RB, 8, HALF>;
+    return (void*)&cell_b_kernel<8, RB, 8, HALF>;
 }
-void* pick_b_func(int nch_ks, int RB = 1) {
-    if (RB == 2) return pick_b_func_rb<2>(nch_ks);
-    return pick_b_func_rb<1>(nch_ks);
+void* pick_b_func(int nch_ks, int RB = 1, bool half = false) {
+    if (half) return RB == 2 ? pick_b_func_rb<2, true>(nch_ks) : pick_b_func_rb<1, true>(nch_ks);
+    if (RB == 2) return pick_b_func_rb<2, false>(nch_ks);
+    return pick_b_func_rb<1, false>(nch_ks);
 }
 
 }  // namespace

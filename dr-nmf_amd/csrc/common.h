@@ -57,10 +57,18 @@ extern char g_create_err[512];
         }                                                                                \
     } while (0)
 
-// params block layout (see drnmf_prepare_params)
+constexpr int MAX_TAIL = 2;   // STFT sizes are 2^k + 1: the odd bin(s) must not cost a whole 16-bin tile
+
+using f16 = _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+// params block layout (see drnmf_prepare_params).  off_dn: per stored layer either the fp32
+// tile-packed dictionary Dp[ft][ac][f%16][n%16] or, with operand_f16, two fp16 packings of the same
+// bytes in total (cell_a's, then cell_b's; params.hip).  off_tail: fp32 rows of the tail bins
+// [n_D][MAX_TAIL][Np] (fp16-rounded values in operand_f16 mode).
 struct ParamsLayout {
     int Fp, Np;
-    size_t off_dn, off_colnorm, off_inv_alpha, off_bias, total;
+    size_t off_dn, off_colnorm, off_inv_alpha, off_bias, off_tail, total;
 };
 static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     ParamsLayout L;
@@ -71,6 +79,7 @@ static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     L.off_colnorm = o;   o += round_up_sz((size_t)d->n_D * L.Np * sizeof(float), 256);
     L.off_inv_alpha = o; o += round_up_sz((size_t)d->K * L.Np * sizeof(float), 256);
     L.off_bias = o;      o += round_up_sz((size_t)d->K * L.Np * sizeof(float), 256);
+    L.off_tail = o;      o += round_up_sz((size_t)d->n_D * MAX_TAIL * L.Np * sizeof(float), 256);
     L.total = o;
     return L;
 }

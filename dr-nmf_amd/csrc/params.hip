@@ -63,6 +63,11 @@ int validate_cell_desc(drnmf_handle_t h, const drnmf_cell_desc_t* d) {
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "n_D/n_alph/n_lam must be 1 or K");
     if (d->alph_len != 1 && d->alph_len != d->N)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "alph_len must be 1 or N");
+    if (d->operand_f16 != 0 && d->operand_f16 != 1)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "operand_f16 must be 0 or 1");
+    if (d->operand_f16 && d->return_all_hidden)
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
+                   "operand_f16 is a forward-only mode (return_all_hidden feeds the fp32 BPTT)");
     if ((int64_t)d->B * d->T * (int64_t)d->N * (d->return_all_hidden ? d->K : 1) >= (1ll << 40))
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "output tensor too large");
     return DRNMF_OK;
@@ -75,19 +80,42 @@ extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
 
 // One thread per (stored layer, atom column): pass 1 accumulates sum_f exp(log_D)^2 in f order,
 // pass 2 writes exp(log_D)/sqrt(sum) -- enhance.py:177-178 / 190-191 -- into the TILE-PACKED
-// dictionary Dp[ft][ac][f%16][n%16] (1 KB blocks of 16 bins x 16 atoms; see cell_forward.hip).
-// Padded rows/columns are written as zeros.
+// dictionary (1 KB blocks of 16 bins x 16 atoms; see cell_forward.hip).  Padded rows/columns are
+// written as zeros.  HALF = false: fp32 Dp[ft][ac][f%16][n%16].  HALF = true: two fp16 packings,
+//   A (cell_a, contracts bins):  DpA[ft][ac][p][q][a][e] = Dn[16 ft + 4e + q][16 ac + 2p + a]
+//                                (MFMA k = 4q+e; a lane's two atoms 2p, 2p+1 are one 16-byte load)
+//   B (cell_b, contracts atoms): DpB[ft][ac][f%16][n%16] = Dn[f][n]
+// each Fp*Np halves; a wave's operand load covers contiguous 512-byte blocks.
+// tail[layer][i][n] = Dn[16*(F/16) + i][n] for the (at most MAX_TAIL) bins past the last full tile.
+template <bool HALF>
 __global__ void __launch_bounds__(256)
-prep_dict_kernel(const float* __restrict__ log_D, float* __restrict__ Dn,
-                 float* __restrict__ colnorm, int F, int N, int Fp, int Np) {
+prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
+                 float* __restrict__ colnorm, float* __restrict__ tail, int F, int N, int Fp,
+                 int Np) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int layer = blockIdx.y;
     if (n >= Np) return;
     const int NAC = Np / 16;
-    float* dn = Dn + (size_t)layer * Fp * Np + (size_t)(n >> 4) * 256 + (n & 15);
-    auto at = [&](int f) -> float& { return dn[(size_t)(f >> 4) * NAC * 256 + (f & 15) * 16]; };
+    const size_t lstride = (size_t)Fp * Np;
+    float* dn = (float*)Dn_ + (size_t)layer * lstride + (size_t)(n >> 4) * 256 + (n & 15);
+    f16* dA = (f16*)Dn_ + (size_t)layer * 2 * lstride;
+    f16* dB = dA + lstride;
+    auto put = [&](int f, float v) {
+        if (!HALF) {
+            dn[(size_t)(f >> 4) * NAC * 256 + (f & 15) * 16] = v;
+        } else {
+            const size_t blk = ((size_t)(f >> 4) * NAC + (n >> 4)) * 256;
+            const int fi = f & 15;
+            const int n16 = n & 15;                                      // q = fi%4, e = fi/4
+            dA[blk + (((n16 >> 1) * 4 + (fi & 3)) * 2 + (n16 & 1)) * 4 + (fi >> 2)] = (f16)v;
+            dB[blk + fi * 16 + (n & 15)] = (f16)v;
+        }
+    };
+    const int t0 = (F / 16) * 16;
+    float* tl = tail + (size_t)layer * MAX_TAIL * Np + n;
     if (n >= N) {
-        for (int f = 0; f < Fp; ++f) at(f) = 0.f;
+        for (int f = 0; f < Fp; ++f) put(f, 0.f);
+        for (int i = 0; i < MAX_TAIL; ++i) tl[(size_t)i * Np] = 0.f;
         colnorm[(size_t)layer * Np + n] = 1.f;
         return;
     }
@@ -99,8 +127,15 @@ prep_dict_kernel(const float* __restrict__ log_D, float* __restrict__ Dn,
     }
     const float nrm = sqrtf(s);
     colnorm[(size_t)layer * Np + n] = nrm;
-    for (int f = 0; f < F; ++f) at(f) = expf(ld[(size_t)f * N + n]) / nrm;
-    for (int f = F; f < Fp; ++f) at(f) = 0.f;
+    for (int f = 0; f < F; ++f) {
+        float v = expf(ld[(size_t)f * N + n]) / nrm;
+        put(f, v);
+        if (HALF) v = (float)(f16)v;
+        if (f >= t0 && f - t0 < MAX_TAIL) tl[(size_t)(f - t0) * Np] = v;
+    }
+    for (int f = F; f < Fp; ++f) put(f, 0.f);
+    for (int i = 0; i < MAX_TAIL; ++i)
+        if (t0 + i >= F) tl[(size_t)i * Np] = 0.f;
 }
 
 // 1/alpha[n] and b[n] = -lam/alpha[n] per layer (enhance.py:187-194, 201-203).  Padded atoms get
@@ -136,9 +171,14 @@ extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_
     const ParamsLayout L = params_layout(d);
     char* base = (char*)params;
     dim3 g1((L.Np + 255) / 256, d->n_D);
-    hipLaunchKernelGGL(prep_dict_kernel, g1, dim3(256), 0, stream, log_D,
-                       (float*)(base + L.off_dn), (float*)(base + L.off_colnorm), d->F, d->N,
-                       L.Fp, L.Np);
+    if (d->operand_f16)
+        hipLaunchKernelGGL(prep_dict_kernel<true>, g1, dim3(256), 0, stream, log_D,
+                           (void*)(base + L.off_dn), (float*)(base + L.off_colnorm),
+                           (float*)(base + L.off_tail), d->F, d->N, L.Fp, L.Np);
+    else
+        hipLaunchKernelGGL(prep_dict_kernel<false>, g1, dim3(256), 0, stream, log_D,
+                           (void*)(base + L.off_dn), (float*)(base + L.off_colnorm),
+                           (float*)(base + L.off_tail), d->F, d->N, L.Fp, L.Np);
     dim3 g2((L.Np + 255) / 256, d->K);
     hipLaunchKernelGGL(prep_scalars_kernel, g2, dim3(256), 0, stream, log_alph, log_lam1,
                        (float*)(base + L.off_inv_alpha), (float*)(base + L.off_bias), d->N, L.Np,

@@ -259,8 +259,13 @@ class SimpleDeepRNN(_Layer):
                  dropout_W=0., dropout_U=0., K_layers=1, alt_params=None, keys_trainable=None,
                  maps_from_alt=None, flag_connect_input_to_layers=False, flag_nonnegative=False,
                  flag_return_all_hidden=False, return_sequences=False, input_shape=None,
-                 stateful=False, device=None, **kwargs):
+                 stateful=False, device=None, operand_dtype='float32', **kwargs):
         super(SimpleDeepRNN, self).__init__(**kwargs)
+        # extension (BASELINE config 5): 'float16' rounds dictionary and activations to fp16 where
+        # they enter the matrix cores (fp32 accumulation and state); inference only
+        if operand_dtype not in ('float32', 'float16'):
+            raise ValueError("operand_dtype must be 'float32' or 'float16'")
+        self.operand_dtype = operand_dtype
         self.units = self.output_dim = int(output_dim)
         self.init, self.inner_init, self.activation = init, inner_init, activation
         self.W_regularizer, self.U_regularizer, self.b_regularizer = (W_regularizer,
@@ -385,7 +390,8 @@ class SimpleDeepRNN(_Layer):
         lab = self.maps_from_alt.labels_per_k
         alph_len = int(self._alt[lab['log_alph'][0]].numel())
         return ops.make_desc(B, T, self.input_dim, self.output_dim, self.K_layers, nD, nA,
-                             alph_len, nL, self.flag_return_all_hidden)
+                             alph_len, nL, self.flag_return_all_hidden,
+                             operand_f16=self.operand_dtype == 'float16')
 
     def _stacked_meta(self, name):
         lab = self.maps_from_alt.labels_per_k[name]
@@ -435,6 +441,9 @@ class SimpleDeepRNN(_Layer):
     def forward_train(self, x, mask_value=None):
         """Forward that keeps every layer's hidden state: returns hall [B,T,K*N] (the last N
         columns are the layer output) and leaves the workspace ready for `backward`."""
+        if self.operand_dtype != 'float32':
+            raise NotImplementedError("training runs on fp32 operands (operand_dtype='float16' is "
+                                      "an inference mode)")
         if not self.built:
             self.build(tuple(x.shape))
         B, T, F = x.shape
@@ -876,7 +885,8 @@ def build_unfolded_snmf(params_unfolded_snmf, device=None):
     cell = SimpleDeepRNN(hidden_dim, input_shape=(maxseq, input_dim), return_sequences=True,
                          activation='relu', K_layers=K_layers, alt_params=alt_params,
                          keys_trainable=keys_trainable, maps_from_alt=maps_from_alt,
-                         flag_connect_input_to_layers=True, flag_nonnegative=True, device=device)
+                         flag_connect_input_to_layers=True, flag_nonnegative=True, device=device,
+                         operand_dtype=p.get('operand_dtype', 'float32'))
     cell.build((None, maxseq, input_dim))
     r = hidden_dim // 2
     log_W_clean = np.log(np.float32(1e-7) + W_noisy[:, :r])               # enhance.py:282

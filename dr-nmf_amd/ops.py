@@ -26,9 +26,11 @@ def _f32c(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def make_desc(B, T, F, N, K, n_D=1, n_alph=1, alph_len=1, n_lam=1, return_all_hidden=False):
+def make_desc(B, T, F, N, K, n_D=1, n_alph=1, alph_len=1, n_lam=1, return_all_hidden=False,
+              operand_f16=False):
     return _capi.CellDesc(int(B), int(T), int(F), int(N), int(K), int(n_D), int(n_alph),
-                          int(alph_len), int(n_lam), int(bool(return_all_hidden)))
+                          int(alph_len), int(n_lam), int(bool(return_all_hidden)),
+                          int(bool(operand_f16)))
 
 
 def prepare_params(desc, log_D, log_alph, log_lam1, out=None):

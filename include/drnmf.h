@@ -54,6 +54,10 @@ typedef struct drnmf_cell_desc {
     int32_t alph_len;       /* 1 (scalar alph) or N (untie_alph, enhance.py:225-226)           */
     int32_t n_lam;          /* 1 or K                                                          */
     int32_t return_all_hidden; /* flag_return_all_hidden (custom_layers.py:344-346,371-372)    */
+    int32_t operand_f16;       /* 0: fp32 MFMA operands (the reference's float32).  1: dictionary
+                                * and activations rounded to fp16 where they enter the matrix
+                                * cores, fp32 accumulation and state (BASELINE config 5; forward
+                                * only -- drnmf_cell_backward returns DRNMF_ERR_UNSUPPORTED)      */
 } drnmf_cell_desc_t;
 
 int32_t drnmf_version(void);

@@ -168,13 +168,36 @@ def cell_forward_dense(x, Wk, Uk, bk, Sk, log_h0, mask_value=-1.0, return_all_hi
 
 
 def cell_forward_factored(x, layers, u, log_h0, mask_value=-1.0, return_all_hidden=False,
-                          dtype=np.float64, initial_state=None, return_state=False):
+                          dtype=np.float64, initial_state=None, return_state=False,
+                          operand_dtype=None):
     """Same recurrence in the factored ISTA form (never materialises S_k or U_k):
         layer 0 : relu(u0d*p + u0o*(sum(p)-p) + (x Dn_0)*ia_0 + b_0)
         layer k : relu(h + ((x - h Dn_k^T) Dn_k)*ia_k + b_k + uko*sum(p))
-    layers = maps_factored(...); u = u_scalars(...)."""
+    layers = maps_factored(...); u = u_scalars(...).
+    operand_dtype=np.float16 emulates BASELINE config 5 ("fp16 MFMA with fp32 accumulate") the way
+    the device path defines it: the dictionary is rounded to fp16 everywhere; x_t, h and the
+    residual are rounded to fp16 where they are matrix-core operands, i.e. on the bins of whole
+    16-bin tiles -- the 1-2 odd bins of a 2^k+1 STFT are contracted outside the matrix cores with
+    unrounded activations; sums, state and the update stay in `dtype`."""
     x = np.asarray(x, dtype=dtype)
     B, T, F = x.shape
+    if operand_dtype is not None:
+        rq = lambda a_: np.asarray(a_, dtype=dtype).astype(operand_dtype).astype(dtype)
+        layers = [(rq(Dn_), ia_, b_) for Dn_, ia_, b_ in layers]
+        nt = F % 16 if (F % 16 != 0 and F % 16 <= 2 and F > 16) else 0
+        Fm = F - nt
+
+        def xhat_of(h_, Dn_):             # h Dn^T
+            out_ = np.empty((h_.shape[0], F), dtype=dtype)
+            out_[:, :Fm] = rq(h_) @ Dn_[:Fm].T
+            out_[:, Fm:] = h_ @ Dn_[Fm:].T
+            return out_
+
+        def corr_of(r_, Dn_):             # r Dn
+            return rq(r_[:, :Fm]) @ Dn_[:Fm] + r_[:, Fm:] @ Dn_[Fm:]
+    else:
+        xhat_of = lambda h_, Dn_: h_ @ Dn_.T
+        corr_of = lambda r_, Dn_: r_ @ Dn_
     K = len(layers)
     N = layers[0][0].shape[1]
     u0d, u0o, uko = (dtype(v) for v in u)
@@ -192,12 +215,12 @@ def cell_forward_factored(x, layers, u, log_h0, mask_value=-1.0, return_all_hidd
         xt = xm[:, t]
         hidden = []
         Dn, ia, b = layers[0]
-        h = relu(u0d * p + u0o * (ps - p) + (xt @ Dn) * ia + b)
+        h = relu(u0d * p + u0o * (ps - p) + corr_of(xt, Dn) * ia + b)
         hidden.append(h)
         for k in range(1, K):
             Dn, ia, b = layers[k]
-            r = xt - h @ Dn.T
-            h = relu(h + (r @ Dn) * ia + b + uko * ps)
+            r = xt - xhat_of(h, Dn)
+            h = relu(h + corr_of(r, Dn) * ia + b + uko * ps)
             hidden.append(h)
         out = np.concatenate(hidden, axis=1) if return_all_hidden else h
         v = valid[:, t][:, None]

@@ -42,7 +42,8 @@ def _problem(B, T, F, r, K, untied=("log_D", "log_alph"), untie_alph=False, ragg
     return P, alt, labels, N
 
 
-def _run_cell(dev, P, alt, labels, N, K, mask_value=-1.0, return_all_hidden=False):
+def _run_cell(dev, P, alt, labels, N, K, mask_value=-1.0, return_all_hidden=False,
+              operand_f16=False):
     from drnmf_amd import ops
     X = P["X"]
     B, T, F = X.shape
@@ -50,7 +51,7 @@ def _run_cell(dev, P, alt, labels, N, K, mask_value=-1.0, return_all_hidden=Fals
     logD, logA, logL = stack("log_D"), stack("log_alph"), stack("log_lam1")
     desc = ops.make_desc(B, T, F, N, K, n_D=logD.shape[0], n_alph=logA.shape[0],
                          alph_len=int(np.asarray(logA[0]).size), n_lam=logL.shape[0],
-                         return_all_hidden=return_all_hidden)
+                         return_all_hidden=return_all_hidden, operand_f16=operand_f16)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     params = ops.prepare_params(desc, t(logD), t(logA.reshape(logA.shape[0], -1)),
                                 t(logL.reshape(-1)))
@@ -524,3 +525,38 @@ def test_c_abi_status_codes_and_messages(dev):
         ops.stft_mag(torch.zeros((1, 100), device=dev), N=100, hop=25)   # N not a power of two
     torch.cuda.synchronize()
     assert fwd(desc) == 0                                             # the handle is still usable
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, T=5, F=21, r=6, K=4),
+    dict(B=17, T=4, F=257, r=100, K=5, ragged=True),                 # one tail bin
+    dict(B=5, T=3, F=64, r=16, K=3, untied=()),                      # whole tiles only, tied
+    dict(B=2, T=2, F=1025, r=4000, K=3, alph=1600.0),                # BASELINE config 5 width
+    dict(B=250, T=2, F=513, r=1000, K=2, alph=400.0),                # row-blocked kernels
+])
+def test_cell_forward_fp16_operands(dev, cfg):
+    """BASELINE config 5: fp16 MFMA operands, fp32 accumulate.  Against the oracle's emulation of
+    the same rounding points (tight), and against the exact fp64 oracle through the mask (the
+    north-star bar: mask MSE < 1e-5; SURVEY.md 8c expects <= 1e-6 for fp16 operands)."""
+    cfg = dict(cfg)
+    K = cfg.pop("K")
+    P, alt, labels, N = _problem(K=K, **cfg)
+    h, _, _ = _run_cell(dev, P, alt, labels, N, K, operand_f16=True)
+    lay, u = O.maps_factored(alt, labels, K), O.u_scalars(alt)
+    emu = O.cell_forward_factored(P["X"], lay, u, P["log_h0"], operand_dtype=np.float16)
+    exact = O.cell_forward_factored(P["X"], lay, u, P["log_h0"])
+    assert np.all(np.isfinite(h))
+    scale = max(np.max(np.abs(emu)), 1e-30)
+    # fp32 accumulation order + activations that sit on an fp16 rounding boundary
+    assert np.max(np.abs(h - emu)) / scale <= 2e-3
+    assert np.sqrt(np.mean((h - emu) ** 2)) / scale <= 1e-4
+    r = N // 2
+    kc = np.log(1e-7 + P["W"][:, :r]).T
+    kn = np.log(1e-7 + P["W"][:, r:]).T
+    m16 = O.head_forward(h, kc, kn)[0]
+    m64 = O.head_forward(exact, kc, kn)[0]
+    valid = (P["X"] != -1.0).any(-1)
+    assert np.mean((m16 - m64)[valid] ** 2) <= 1e-6
+    # the mode is forward only
+    with pytest.raises(ValueError):
+        _run_cell(dev, P, alt, labels, N, K, return_all_hidden=True, operand_f16=True)
