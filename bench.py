@@ -39,6 +39,11 @@ def parse():
     ap.add_argument("--tied", action="store_true", help="tie log_D/log_alph across layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ista", action="store_true", help="skip the frame-parallel ISTA line")
+    ap.add_argument("--operand-f16", action="store_true",
+                    help="fp16 MFMA operands, fp32 accumulate (BASELINE config 5 mode; the headline "
+                         "metric is quoted in fp32)")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the config-5 shape lines (F=1025, N=8000, K=50)")
     ap.add_argument("--no-slab", action="store_true",
                     help="skip the 250-utterance inference slab line")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step lines")
@@ -172,6 +177,47 @@ def slab_bench(torch, dev, F, r, K, T, slab=250):
     return out
 
 
+def config5_bench(torch, dev, frames=64, B=64):
+    """BASELINE configs[4] shape on ONE GPU (the config itself is an 8-GPU stress line): W 1025 x
+    8000, K=50 untied, forward (cell + head) with fp32 and with fp16 MFMA operands (fp32
+    accumulate).  Flop fractions against the fp32 / fp16 dense MFMA peaks respectively."""
+    from drnmf_amd import layers, ops
+    F, r, K = 1025, 4000, 50
+    N = 2 * r
+    W, log_h0, X = synth_on_device(torch, dev, B, frames, F, r, seed=5)
+    out = {"shape": "F=%d N=%d K=%d B=%d T=%d untied" % (F, N, K, B, frames)}
+    h_buf = torch.empty((B, frames, N), dtype=torch.float32, device=dev)
+    m_buf = torch.empty((B, frames, F), dtype=torch.float32, device=dev)
+    masks = {}
+    for name, od, peak in (("f32", "float32", PEAK_F32_MFMA_TFLOPS), ("f16", "float16", 2500.0)):
+        p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=frames,
+                 K_layers=K, W=W, alph=0.4 * r, lam1=1.0, params_trainable=["log_D", "log_alph"],
+                 params_untied=["log_D", "log_alph"], operand_dtype=od)
+        model = layers.build_unfolded_snmf(p, device=dev)
+        model.cell.log_h0.copy_(torch.from_numpy(log_h0))
+
+        def step():
+            h = model.cell.call(X, mask_value=-1., out=h_buf)
+            ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
+        step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3
+        tf = B * frames * 4.0 * F * N * K / sec / 1e12
+        out[name] = {"frames_per_s": B * frames / sec, "tflops": tf, "frac_of_mfma_peak": tf / peak,
+                     "launch_us": sec / (frames * (2 * K - 1)) * 1e6}
+        masks[name] = m_buf.clone()
+        del model
+    out["mask_mse_f16_vs_f32"] = float(((masks["f16"] - masks["f32"]) ** 2).mean())
+    del X, h_buf, m_buf, masks
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic():
     """HBM-side bytes per cell launch from the newest committed PMC summary (separate rocprofv3
     --pmc passes over this same command, profiles/collect.sh; FETCH_SIZE KB x 1024 x 2 -- the
@@ -260,6 +306,8 @@ def main():
              alph=400.0 if r >= 1000 else 50.0, lam1=1.0, params_trainable=["log_D", "log_alph"])
     if not a.tied:
         p["params_untied"] = ["log_D", "log_alph"]
+    if a.operand_f16:
+        p["operand_dtype"] = "float16"
     model = layers.build_unfolded_snmf(p, device=dev)
     model.cell.log_h0.copy_(torch.from_numpy(log_h0))
     h_buf = torch.empty((B, T, N), dtype=torch.float32, device=dev)
@@ -335,6 +383,8 @@ def main():
             extra["ista_frame_parallel"] = ista_bench(torch, dev, F, N, K, W)
         if not a.no_slab and world == 1:
             extra["inference_slab_250"] = slab_bench(torch, dev, F, r, K, T)
+        if not a.no_config5 and world == 1:
+            extra["config5_shape"] = config5_bench(torch, dev)
         if not a.no_train and world == 1:
             del X
             torch.cuda.empty_cache()
@@ -347,7 +397,8 @@ def main():
                   "%d-frame, K=%d unrolls" % (F, T, K),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 operands, f32 accumulate" if a.operand_f16 else "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: K=%d unrolled SNMF forward (recurrent cell + "
                                "mask head), W %dx%d, %s log_D/log_alph, batch %d x %d frames per "
                                "GPU" % (K, F, N, "tied" if a.tied else "untied", B, T),

@@ -146,6 +146,19 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // that chunk.  Loads run PF chunks ahead of the MFMAs (enough to cover the L2/fabric latency)
     // and the two streams overlap instead of adding up.
     constexpr int PF = G - 1;   // prefetch distance 2..4 measured equivalent, 6 slower (C2 shape)
+    // Slots past a wave's last chunk are never loaded but still multiplied (by a zeroed residual,
+    // branch-free): their dictionary registers must not hold Inf/NaN garbage (one fp16 bit
+    // pattern in 32 does).
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bv[g][s] = f32x2{0.f, 0.f};
+        bh[g][0] = bh[g][1] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < NP; ++ks) av[g][rb][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(g, g);
 
@@ -222,9 +235,6 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // ---- GEMM:  g[16*RB x 32] = r[16*RB x F] . Dn[F x 32] ---------------------------------------
     auto compute_chunk = [&](int base, int g) {
         const bool ok = base + g < per_wave;
-        // (wave-uniform) past the last chunk the slot's registers were never loaded: skip, do not
-        // multiply garbage by zero (an fp16 bit pattern is Inf/NaN one time in 32)
-        if (!ok) return;
         f32x4 r4[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -237,6 +247,7 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
                 const int c = w + NW_A * (base + g);
                 *(f32x4*)(a.xcur + (size_t)(mb0 + rb) * nft * 256 + 256 * c + j * 16 + q * 4) = r4[rb];
             }
+            if (!ok) r4[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (HALF) {
 #pragma unroll

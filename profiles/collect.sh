@@ -18,7 +18,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats"
 cp "$OUT"/stats/*/stats_kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null || \
     cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 # 3. PMC passes, 20 frames of the headline workload (cell + head only)
-SMALL="--frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-ista --no-train --no-slab"
+SMALL="--frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-ista --no-train --no-slab --no-config5"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch" -o p -- python3 "$B" $SMALL \
     > /dev/null 2> "$OUT/pmc_fetch.err"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d "$OUT/pmc_write" -o p -- python3 "$B" $SMALL \
