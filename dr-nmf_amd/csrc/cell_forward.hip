@@ -123,7 +123,6 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     f32x2 bv[G][4];
     f16x4 bh[G][2];
     auto load_chunk = [&](int i, int g) {      // chunk i of this wave -> slot g
-        if (i >= per_wave && i > 0) return;    // wave-uniform: nothing past the last chunk
         int c = w + NW_A * i;
         c = c > clast ? clast : c;
 #pragma unroll
@@ -272,10 +271,25 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     // slots rotate: chunk i lives in slot i mod G and its loads are issued PF = G-1 chunks ahead,
     // so the register footprint does not grow with the number of chunks and the pipeline never
     // drains between groups.
-    for (int base = 0; base < per_wave; base += G) {
+    // Loads past a wave's last chunk are clamped (they re-read the last chunk: an L1/L2 hit, no
+    // branch -- a wave-uniform branch around them or around the MFMAs costs 1-7 %).  When every
+    // wave owns a whole number of groups (all 2^k+1 STFT sizes from 512 up: nchunks % 16 == 0)
+    // the last group is peeled and issues only the one load that is still needed.
+    const bool exact = (a.nchunks % (NW_A * G)) == 0;
+    int base = 0;
+    for (; base + (exact ? G : 0) < per_wave; base += G) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             load_chunk(base + g + PF, (g + PF) % G);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_chunk(base, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (exact) {
+        load_chunk(base + PF, PF % G);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
             __builtin_amdgcn_sched_barrier(0);
             compute_chunk(base, g);
             __builtin_amdgcn_sched_barrier(0);
