@@ -141,8 +141,14 @@ struct BwdAArgs {
     int k, B, T, N, K, Bp, Fp, Np, numA, nchunks;
 };
 
+// (leading scalar arguments: preloaded into SGPRs, see cell_b_kernel)
 template <int G, int KS>
-__global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
+__global__ void __launch_bounds__(256)
+bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, int Fp_, int Np_,
+             int numA_, int nchunks_, const BwdAArgs a_in) {
+    BwdAArgs a = a_in;
+    a.drpart = drpart_; a.Dn = Dn_; a.c_rd = c_rd_; a.Bp = Bp_; a.Fp = Fp_; a.Np = Np_;
+    a.numA = numA_; a.nchunks = nchunks_;
     __shared__ __attribute__((aligned(16))) float red[4 * ROWS * ATOMS];
     const int m = blockIdx.x >> 3;                          // grid layout: see cell_a_kernel
     const int ab_raw = blockIdx.y * 8 + (blockIdx.x & 7);
@@ -179,6 +185,7 @@ __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
     constexpr int PF = G < 3 ? G : 3;
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
+    __builtin_amdgcn_sched_barrier(0);   // struct-dependent code stays behind the first operand loads
 
     const int cnt = *a.c_rd;
     if (a.c_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.c_wr = cnt + 1;
@@ -269,6 +276,12 @@ __global__ void __launch_bounds__(256) bwd_a_kernel(const BwdAArgs a) {
         if (a.k == 1) a.dz0s_part[po] = s0;
     }
 }
+
+struct BwdAParams {
+    void* p[9];
+    explicit BwdAParams(BwdAArgs& a)
+        : p{&a.drpart, &a.Dn, &a.c_rd, &a.Bp, &a.Fp, &a.Np, &a.numA, &a.nchunks, &a} {}
+};
 
 template <int KS>
 void* bwd_a_func(int per_wave) {
@@ -629,10 +642,9 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         ge.key = gkey;
         DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
         hipGraphNode_t last = nullptr;
-        auto add = [&](void* func, dim3 grid, unsigned block, void* argp) -> hipError_t {
+        auto add = [&](void* func, dim3 grid, unsigned block, void** kp) -> hipError_t {
             hipKernelNodeParams p;
             memset(&p, 0, sizeof(p));
-            void* kp[1] = {argp};
             p.func = func; p.gridDim = grid; p.blockDim = dim3(block);
             p.sharedMemBytes = 0; p.kernelParams = kp; p.extra = nullptr;
             hipGraphNode_t node;
@@ -642,16 +654,18 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
             return e;
         };
         for (int rep = 0; rep < fpg; ++rep) {
-            DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, &ea));
+            void* ke[1] = {&ea};
+            DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, ke));
             for (int k = K - 1; k >= 1; --k) {
                 CellBArgs b = make_b(k);
-                DRNMF_HIP(h, add(pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, &b));
+                DRNMF_HIP(h, add(pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, CellBParams(b).p));
                 BwdAArgs a = make_a(k);
-                DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, &a));
+                DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, BwdAParams(a).p));
             }
             if (K == 1) {
                 int* cp = cA;
-                DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, &cp));
+                void* kc[1] = {&cp};
+                DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, kc));
             }
         }
         DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));

@@ -67,8 +67,16 @@ struct CellAArgs {
 // workgroup (see cell_b_kernel): every dictionary operand feeds RB row blocks.
 // HALF: residual and dictionary enter the matrix cores as fp16 (v_mfma_f32_16x16x16_f16: two MFMAs
 // per 16-bin chunk instead of eight), fp32 accumulation; everything else stays fp32.
+// What the operand addresses need is passed as leading scalar arguments (preloaded into SGPRs by
+// the command processor, see cell_b_kernel); the rest of the struct is fetched by scalar loads that
+// are not on the path to the first operand load.
 template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN, bool HALF = false>
-__global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
+__global__ void __launch_bounds__(64 * NW_A)
+cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, int Fp_, int Np_,
+              int numA_, int nchunks_, const CellAArgs a_in) {
+    CellAArgs a = a_in;
+    a.rsrc = rsrc_; a.Dn = Dn_; a.t_rd = t_rd_; a.Bp = Bp_; a.Fp = Fp_; a.Np = Np_;
+    a.numA = numA_; a.nchunks = nchunks_;
     constexpr bool WRITE_OUT = IS_LAST || ALL_HIDDEN;
     __shared__ __attribute__((aligned(16))) float red[NW_A * RB * ROWS * ATOMS];   // [NW][RB][16][32]
 
@@ -160,6 +168,9 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
     }
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(g, g);
+    // everything below depends on struct fields that are still being fetched by scalar loads:
+    // keep it (and the wait for those loads) behind the first operand loads
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue operands (tiny, needed last; issued behind the GEMM operands) --------------
     const int erow = (tid & 255) >> 4, ec = (tid & 15) * 2;
@@ -394,6 +405,13 @@ __global__ void __launch_bounds__(64 * NW_A) cell_a_kernel(const CellAArgs a) {
         }
     }
 }
+
+// kernelParams array of cell_a_kernel
+struct CellAParams {
+    void* p[9];
+    explicit CellAParams(CellAArgs& a)
+        : p{&a.rsrc, &a.Dn, &a.t_rd, &a.Bp, &a.Fp, &a.Np, &a.numA, &a.nchunks, &a} {}
+};
 
 __global__ void noop_kernel() {}
 
@@ -698,16 +716,17 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         for (int t = 0; t < T_run; ++t) {
             for (int k = 0; k < K; ++k) {
                 CellAArgs a = make_a(k);
-                void* kp[1] = {&a};
+                CellAParams kpa(a);
+                void** kp = kpa.p;
                 DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
                 DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1,
                                                          d->return_all_hidden != 0, half),
                                              grid_a, dim3(64 * NW_A), kp, 0, stream));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
-                    void* kb[1] = {&b};
+                    CellBParams kb(b);
                     DRNMF_HIP(h, mark(1));
-                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks, W.RB, half), grid_b, dim3(64 * NW_B), kb, 0,
+                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks, W.RB, half), grid_b, dim3(64 * NW_B), kb.p, 0,
                                                  stream));
                 }
             }
@@ -757,10 +776,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         ge.key = gkey;
         DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
         hipGraphNode_t last = nullptr;
-        auto add = [&](void* func, dim3 grid, unsigned block, void* argp) -> hipError_t {
+        auto add = [&](void* func, dim3 grid, unsigned block, void** kp) -> hipError_t {
             hipKernelNodeParams p;
             memset(&p, 0, sizeof(p));
-            void* kp[1] = {argp};
             p.func = func;
             p.gridDim = grid;
             p.blockDim = dim3(block);
@@ -776,15 +794,18 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         for (int rep = 0; rep < fpg; ++rep) {
             for (int k = 0; k < K; ++k) {
                 CellAArgs a = make_a(k);
-                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1, d->return_all_hidden != 0, half), grid_a, 64 * NW_A, &a));
+                CellAParams ka_(a);
+                void** ka = ka_.p;
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1, d->return_all_hidden != 0, half), grid_a, 64 * NW_A, ka));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
-                    DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB, half), grid_b, 64 * NW_B, &b));
+                    DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB, half), grid_b, 64 * NW_B, CellBParams(b).p));
                 }
             }
             if (K == 1) {
                 int* tp = tA;
-                DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, &tp));
+                void* kt[1] = {&tp};
+                DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, kt));
             }
         }
         DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));

@@ -29,8 +29,15 @@ struct CellBArgs {
 // operand for RB row blocks, which divides the operand traffic per flop by up to (1 + RB) / 2RB.
 // HALF: both operands enter the matrix cores as fp16 (v_mfma_f32_16x16x16_f16: one MFMA per
 // 16-atom chunk instead of four), fp32 accumulation.
+// The arguments are passed as individual scalars (not as one struct) so that the command
+// processor can preload them into SGPRs (-amdgpu-kernarg-preload-count, build.py): the kernel
+// then starts without a dependent scalar load from the kernarg segment.
 template <int GB, int RB = 1, int NW = 8, bool HALF = false>
-__global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
+__global__ void __launch_bounds__(64 * NW)
+cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rpart, int Fp_,
+              int Np_, int nft_, int KS_, int nch_ks_, int Bp_) {   // 14 dwords: all preloaded
+    const CellBArgs a{Dn_next, h_in, xp, rpart, nullptr, Bp_, Fp_, Np_, nft_, KS_,
+                      __builtin_ctz((unsigned)KS_), nch_ks_};
     __shared__ __attribute__((aligned(16))) float red[NW * RB * 16 * 16];
     // 2-D grid (x = 8 * row tile group + XCD slot, y = octet of (bin tile, atom range)): see
     // cell_a_kernel.  KS is a power of two.  Padded blocks redo the last tile with the store
@@ -143,6 +150,13 @@ __global__ void __launch_bounds__(64 * NW) cell_b_kernel(const CellBArgs a) {
             a.rpart[(size_t)ks * a.Bp * Fp + eoff + rb * estep] = (a.xp != nullptr) ? xv[rb] - s : s;
     }
 }
+
+// kernelParams array of cell_b_kernel for hipLaunchKernel / hipGraphAddKernelNode
+struct CellBParams {
+    void* p[10];
+    explicit CellBParams(CellBArgs& b)
+        : p{&b.Dn_next, &b.h, &b.xp, &b.rpart, &b.Fp, &b.Np, &b.nft, &b.KS, &b.nch_ks, &b.Bp} {}
+};
 
 __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
 
