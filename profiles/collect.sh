@@ -12,9 +12,10 @@ cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
 # 1. the default bench line
 python3 "$B" > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"
-# 2. kernel trace + stats of the same command (1 step)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$B" --steps 1 --warmup 0 \
-    --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+# 2. kernel trace + stats of the headline workload alone (1 step; the extra lines of the default
+#    command reuse the same kernel templates at other shapes and would blur the per-kernel means)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$B" --steps 1 --warmup 1 \
+    --no-cpu-baseline --no-ista --no-train --no-slab --no-config5 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 cp "$OUT"/stats/*/stats_kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null || \
     cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 # 3. PMC passes, 20 frames of the headline workload (cell + head only)
