@@ -90,6 +90,10 @@ def lib():
             raise ImportError(
                 "libdrnmf.so not found at %s -- build it with `python dr-nmf_amd/build.py` "
                 "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+        # torch first: it ships its own libamdhip64, and the process must hold ONE HIP runtime.
+        # Loaded before torch, libdrnmf.so would pull in /opt/rocm's copy and the second runtime
+        # to initialise reports "no ROCm-capable device".
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
