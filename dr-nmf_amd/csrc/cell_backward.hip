@@ -634,6 +634,8 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         if (g.key == gkey) { entry = &g; break; }
     if (!entry) {
         if (h->graphs.size() >= 24) {   // bounded cache shared with the forward: drop the oldest
+            // (rare) the evicted graph may still be replaying on some stream
+            DRNMF_HIP(h, hipDeviceSynchronize());
             (void)hipGraphExecDestroy(h->graphs.front().exec);
             (void)hipGraphDestroy(h->graphs.front().graph);
             h->graphs.erase(h->graphs.begin());

@@ -768,6 +768,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         if (g.key == gkey) { entry = &g; break; }
     if (!entry) {
         if (h->graphs.size() >= 24) {   // bounded cache: drop the oldest
+            // (rare) the evicted graph may still be replaying on some stream
+            DRNMF_HIP(h, hipDeviceSynchronize());
             (void)hipGraphExecDestroy(h->graphs.front().exec);
             (void)hipGraphDestroy(h->graphs.front().graph);
             h->graphs.erase(h->graphs.begin());
