@@ -58,7 +58,8 @@ def main():
                   ['kl_div', 'beta_div', 'ista_ed', 'ista_kl', 'ista_beta'])
     utl = extract(os.path.join(REF, 'util.py'),
                   ['masked_seqs_to_frames', 'pad_axis_toN_with_constant'])
-    ads = extract(os.path.join(REF, 'audio_dataset.py'), ['reshape_and_pad_stacks'])
+    ads = extract(os.path.join(REF, 'audio_dataset.py'),
+                  ['reshape_and_pad_stacks', 'clip_x_to_y', 'get_mask_value'])
 
     rng = np.random.Generator(np.random.PCG64(20171))
     out = {}
@@ -119,6 +120,20 @@ def main():
     x, y, m = ads['reshape_and_pad_stacks'](xstk, ystk, fidx, transform_x=mag, transform_y=mag,
                                             pad_value=-1., maxlen=10)
     out['rps_mag10_x'], out['rps_mag10_y'], out['rps_mag10_mask'] = x, y, m
+
+    # ---- clip_x_to_y (audio_dataset.py:90-104) and get_mask_value (11-17) ---------------------
+    # (appended after every other draw so that the earlier vectors keep their values)
+    xf = np.array([[0, 9], [9, 20], [20, 26]], dtype=np.int32)
+    yf = np.array([[0, 7], [7, 17], [17, 23]], dtype=np.int32)
+    cx = rng.random((4, 26)).astype(np.float32)
+    cy = rng.random((4, 23)).astype(np.float32)
+    out['clip_x'], out['clip_y'], out['clip_xfidx'], out['clip_yfidx'] = cx.copy(), cy, xf, yf
+    out['clip_out'] = ads['clip_x_to_y'](cx.copy(), cy, xf, yf)
+    out['maskval_cases'] = np.array([ads['get_mask_value'](c) for c in (
+        {'transform_x': 'mag', 'transform_y': 'mag'},
+        {'transform_x': 'none', 'transform_y': 'logmag'},
+        {'transform_x': 'logmag', 'transform_y': 'none'},
+        {'transform_x': 'none', 'transform_y': 'none'})], dtype=np.float64)
 
     np.savez_compressed(os.path.join(HERE, 'reference_numpy_golden.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_numpy_golden.npz'), len(out), 'arrays')

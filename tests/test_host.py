@@ -169,3 +169,40 @@ def test_weight_files_follow_keras_layout(tmp_path):
     except ImportError:
         with pytest.raises(ImportError):
             m.load_weights(str(tmp_path / "model.hdf5"))
+
+
+def test_data_layout_helpers_match_reference_golden_vectors(golden):
+    """drnmf_amd.data (the layout contract either side of the hot path) against outputs of the
+    reference's own reshape_and_pad_stacks / masked_seqs_to_frames / pad_axis_toN_with_constant /
+    clip_x_to_y / get_mask_value (tests/golden/make_golden.py)."""
+    from drnmf_amd import data as D
+    g = golden
+    np.testing.assert_array_equal(D.masked_seqs_to_frames(g["m2f_x"], g["m2f_mask"]), g["m2f_out"])
+    np.testing.assert_array_equal(D.pad_axis_toN_with_constant(g["m2f_x"], 1, 15, -1.),
+                                  g["pad_out"])
+    for ml in (None, 10, 25):
+        x, y, m = D.reshape_and_pad_stacks(g["rps_x_stack"], g["rps_y_stack"], g["rps_fidx"],
+                                           pad_value=-1., maxlen=ml)
+        for got, key in ((x, "x"), (y, "y"), (m, "mask")):
+            want = g["rps_%s_%s" % (ml, key)]
+            assert got.dtype == want.dtype
+            np.testing.assert_array_equal(got, want)
+        # and back: crop every sequence to its true length (enhance.py:1200-1203)
+        np.testing.assert_array_equal(D.sequences_to_stack(x, g["rps_fidx"], maxlen=ml),
+                                      g["rps_x_stack"])
+    mag = D.get_transform("mag")
+    x, y, m = D.reshape_and_pad_stacks(g["rps_x_stack"], g["rps_y_stack"], g["rps_fidx"],
+                                       transform_x=mag, transform_y=mag, pad_value=-1., maxlen=10)
+    np.testing.assert_array_equal(x, g["rps_mag10_x"])
+    np.testing.assert_array_equal(y, g["rps_mag10_y"])
+    np.testing.assert_array_equal(m, g["rps_mag10_mask"])
+    np.testing.assert_array_equal(
+        D.clip_x_to_y(g["clip_x"].copy(), g["clip_y"], g["clip_xfidx"], g["clip_yfidx"]),
+        g["clip_out"])
+    cases = ({"transform_x": "mag", "transform_y": "mag"},
+             {"transform_x": "none", "transform_y": "logmag"},
+             {"transform_x": "logmag", "transform_y": "none"},
+             {"transform_x": "none", "transform_y": "none"})
+    np.testing.assert_array_equal([D.get_mask_value(c) for c in cases], g["maskval_cases"])
+    with pytest.raises(ValueError):
+        D.pad_axis_toN_with_constant(g["m2f_x"], 1, 3, 0.)
