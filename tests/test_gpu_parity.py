@@ -560,3 +560,67 @@ def test_cell_forward_fp16_operands(dev, cfg):
     # the mode is forward only
     with pytest.raises(ValueError):
         _run_cell(dev, P, alt, labels, N, K, return_all_hidden=True, operand_f16=True)
+
+
+def test_end_to_end_enhancement_pipeline(dev):
+    """enhance.py's inference flow end to end on the device -- wav -> STFT stacks ->
+    reshape_and_pad_stacks -> predict_on_batch in slabs -> crop -> masked iSTFT -> SNR / SDR
+    (enhance.py:1185-1203, audio_dataset.py:267-278, score_audio.m:206-209) -- against the same flow
+    through the oracle."""
+    from drnmf_amd import data as D, layers, ops
+    rng = np.random.default_rng(12)
+    N_fft, hop, maxlen = 64, 16, 20
+    F = N_fft // 2 + 1
+    lens = [700, 433, 900]
+    clean = [(0.3 * np.sin(0.05 * (i + 1) * np.arange(n)) * rng.random(n)).astype(np.float32)
+             for i, n in enumerate(lens)]
+    noisy = [c + 0.1 * rng.standard_normal(c.shape[0]).astype(np.float32) for c in clean]
+    pcm = [np.clip(np.round(v * 32768.0), -32768, 32767).astype(np.int16) for v in noisy]
+    win = O.sqrt_hann(N_fft)
+
+    # ---- device: STFT of every utterance, concatenated [re; im] stack + frame index table ----
+    re_d, im_d, nfr = [], [], []
+    for p in pcm:
+        re, im = ops.stft(torch.from_numpy(p).to(dev), N=N_fft, hop=hop)
+        re_d.append(re[0]); im_d.append(im[0]); nfr.append(re.shape[1])
+    fidx = np.stack([np.cumsum([0] + nfr[:-1]), np.cumsum(nfr)], 1)
+    stack = np.concatenate([torch.cat(re_d).cpu().numpy().T, torch.cat(im_d).cpu().numpy().T], 0)
+    mag = D.get_transform("mag")
+    x, _, m = D.reshape_and_pad_stacks(stack, stack, fidx, transform_x=mag, transform_y=mag,
+                                       pad_value=D.get_mask_value({"transform_x": "mag"}),
+                                       maxlen=maxlen)
+    r, K = 8, 3
+    P = O.synth_problem(1, 1, F, r, seed=4)
+    params = dict(input_dim=F, hidden_dim=2 * r, output_dim=F, mask_value=-1., maxseq=maxlen,
+                  K_layers=K, W=P["W"], alph=4.0, lam1=0.1, params_untied=["log_D", "log_alph"],
+                  params_trainable=["log_D", "log_alph"])
+    model = layers.build_unfolded_snmf(params, device=dev)
+    irm = np.concatenate([model.predict_on_batch(x[s:s + 2]) for s in range(0, x.shape[0], 2)])
+    irm_stack = D.sequences_to_stack(irm, fidx, maxlen=maxlen)               # (F, total frames)
+    snr_d, sdr_d, wav_d = [], [], []
+    for u, n in enumerate(lens):
+        mk = torch.from_numpy(np.ascontiguousarray(irm_stack[:, fidx[u, 0]:fidx[u, 1]].T)).to(dev)
+        y = ops.istft_masked(re_d[u][None], im_d[u][None], mk[None], n, N_fft, hop)
+        c = torch.from_numpy(clean[u]).to(dev)[None]
+        snr_d.append(float(ops.snr_db(y, c)[0])); sdr_d.append(float(ops.sdr_db(y, c, flen=32)[0]))
+        wav_d.append(y[0].cpu().numpy())
+
+    # ---- the same flow through the oracle ---------------------------------------------------
+    w = model.get_weights()
+    names = ["log_h0"] + list(model.cell._alt.keys()) + ["kc", "kn"]
+    wd = dict(zip(names, w))
+    alt = {k: wd[k] for k in model.cell._alt.keys()}
+    for u, n in enumerate(lens):
+        S = O.stft_mc(O.wav_int16_to_float(pcm[u]), N_fft, hop, win)
+        xm = np.sqrt(S.real ** 2 + S.imag ** 2).T                             # (frames, F)
+        np.testing.assert_allclose(stack[:F, fidx[u, 0]:fidx[u, 1]], S.real, atol=2e-5)
+        # the model sees the utterance in maxlen-frame pieces, state restarting in every piece
+        pieces = [xm[t:t + maxlen] for t in range(0, xm.shape[0], maxlen)]
+        mk = np.concatenate([O.model_forward(pc[None], alt, model.cell.maps_from_alt.labels_per_k,
+                                             K, wd["log_h0"], wd["kc"], wd["kn"],
+                                             mask_value=-1.)[0][0] for pc in pieces])
+        y = O.reconstruct(S.real, S.imag, mk.T, hop, win, nsampl=n)
+        assert np.max(np.abs(wav_d[u] - y)) <= 1e-4 * max(np.max(np.abs(y)), 1e-3)
+        assert abs(snr_d[u] - O.snr_db(y, clean[u].astype(np.float64))) <= 1e-2
+        assert abs(sdr_d[u] - O.sdr_db(y, clean[u].astype(np.float64), 32)) <= 1e-2
+    assert m.sum() == sum(nfr) and x.shape[0] == sum(-(-f // maxlen) for f in nfr)
