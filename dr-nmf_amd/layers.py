@@ -717,28 +717,56 @@ class UnfoldedSNMFModel(object):
         return float(s[0]) / max(float(s[1]), 1.0)
 
     def fit(self, x, y, sample_weight=None, batch_size=32, epochs=1, validation_data=None,
-            shuffle=True, seed=7654, verbose=0):
+            shuffle=True, seed=7654, verbose=0, callbacks=None):
         """Minimal keras.Model.fit: shuffled mini-batches (np.random.seed(7654), enhance.py:7),
-        returns {'loss': [...], 'val_loss': [...]} per epoch.  Under torch.distributed every rank
-        passes ITS shard of the data; batches are all-reduced per step."""
+        Keras-style callbacks (callbacks.py: on_train_begin / on_batch_end / on_epoch_end with
+        logs {'loss', 'val_loss'}; a callback may set model.stop_training), returns {'loss': [...],
+        'val_loss': [...]} per epoch.  Under torch.distributed every rank passes ITS shard of the
+        data; batches are all-reduced per step."""
         n = x.shape[0]
         rng = np.random.RandomState(seed)
         hist = {'loss': [], 'val_loss': []}
+        callbacks = list(callbacks or [])
+        self.stop_training = False
+        for cb in callbacks:
+            if hasattr(cb, 'set_model'):
+                cb.set_model(self)
+            else:
+                cb.model = self
+            if hasattr(cb, 'on_train_begin'):
+                cb.on_train_begin({})
         for ep in range(epochs):
+            for cb in callbacks:
+                if hasattr(cb, 'on_epoch_begin'):
+                    cb.on_epoch_begin(ep, {})
             idx = rng.permutation(n) if shuffle else np.arange(n)
             tot, cnt = 0.0, 0
             for s0 in range(0, n, batch_size):
                 b = idx[s0:s0 + batch_size]
                 sw = None if sample_weight is None else sample_weight[b]
-                tot += self.train_on_batch(x[b], y[b], sw)
+                loss = self.train_on_batch(x[b], y[b], sw)
+                tot += loss
+                for cb in callbacks:
+                    if hasattr(cb, 'on_batch_end'):
+                        cb.on_batch_end(cnt, {'batch': cnt, 'size': len(b), 'loss': loss})
                 cnt += 1
-            hist['loss'].append(tot / max(cnt, 1))
+            logs = {'loss': tot / max(cnt, 1)}
+            hist['loss'].append(logs['loss'])
             if validation_data is not None:
                 xv, yv, wv = validation_data
-                hist['val_loss'].append(self.test_on_batch(xv, yv, wv))
+                logs['val_loss'] = self.test_on_batch(xv, yv, wv)
+                hist['val_loss'].append(logs['val_loss'])
             if verbose:
-                print('epoch %d loss %.6f%s' % (ep + 1, hist['loss'][-1],
-                      (' val_loss %.6f' % hist['val_loss'][-1]) if validation_data else ''))
+                print('epoch %d loss %.6f%s' % (ep + 1, logs['loss'],
+                      (' val_loss %.6f' % logs['val_loss']) if validation_data else ''))
+            for cb in callbacks:
+                if hasattr(cb, 'on_epoch_end'):
+                    cb.on_epoch_end(ep, logs)
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            if hasattr(cb, 'on_train_end'):
+                cb.on_train_end({})
         return hist
 
 

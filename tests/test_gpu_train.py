@@ -176,3 +176,37 @@ def test_snmf_cost_pretraining_gradients_and_fit(dev, cfg):
     # the DR-NMF model shares the pretrained weights (enhance.py:1119 reloads them from disk)
     for a, b in zip(model.get_weights(), pre.get_weights()):
         np.testing.assert_array_equal(a, b)
+
+
+def test_fit_with_reference_callbacks(dev, tmp_path):
+    """enhance.py:1134-1166: fit(..., callbacks=[LossHistory, ModelCheckpoint(save_best_only,
+    save_weights_only), EarlyStopping('val_loss', patience)]) then model.load_weights(savefile)."""
+    import pickle
+    from drnmf_amd import callbacks as C
+    K = 2
+    model, P, wmask = _setup(4, 6, 33, 8, K, ("log_D", "log_alph"))
+    model.compile(lr=1e-2)
+    hist_file, save_file = str(tmp_path / "hist.pkl"), str(tmp_path / "best.npz")
+    history = C.LossHistory(hist_file)
+    ckpt = C.ModelCheckpoint(filepath=save_file, save_best_only=True, save_weights_only=True)
+    stop = C.EarlyStopping(monitor="val_loss", patience=2)
+    val = (P["X"], P["Y"], wmask)
+    hist = model.fit(P["X"], P["Y"], sample_weight=wmask, batch_size=2, epochs=6,
+                     validation_data=val, callbacks=[history, ckpt, stop])
+    assert len(hist["val_loss"]) >= 3 and hist["val_loss"][-1] < hist["val_loss"][0]
+    rec = pickle.load(open(hist_file, "rb"))
+    assert rec["on_epoch_end"]["val_loss"] == hist["val_loss"]
+    assert len(rec["on_batch_end"]["loss"]) == 2 * len(hist["loss"])
+    best = min(hist["val_loss"])
+    assert ckpt.best == best
+    # the checkpoint holds the best epoch's weights: loading them reproduces its val_loss
+    w_last = model.get_weights()
+    model.set_weights([a * 0 for a in w_last][:1] + w_last[1:])       # disturb log_h0
+    model.load_weights(save_file)
+    assert abs(model.test_on_batch(*val) - best) <= 1e-6 * best + 1e-9
+    # early stopping: a learning rate of zero never improves -> stops after patience + 1 epochs
+    model.compile(lr=0.0)
+    stop2 = C.EarlyStopping(monitor="val_loss", patience=1)
+    h2 = model.fit(P["X"], P["Y"], sample_weight=wmask, batch_size=4, epochs=10,
+                   validation_data=val, callbacks=[stop2])
+    assert len(h2["val_loss"]) == 3 and model.stop_training
