@@ -114,6 +114,20 @@ def test_cell_forward_matches_oracle(dev, cfg):
     _check_h(h, _oracle_cell(P, alt, labels, K))
 
 
+def test_cell_forward_long_sequence_does_not_drift(dev):
+    """The state is carried over every frame: fp32 rounding must not accumulate along a long
+    utterance (T = 600 frames x K = 5 layers = 3000 dependent layer-steps; the ISTA map is
+    contractive, so the error stays at the single-step level)."""
+    K = 5
+    P, alt, labels, N = _problem(2, 600, 65, 16, K, density=0.05)
+    h, _, _ = _run_cell(dev, P, alt, labels, N, K)
+    ref = _oracle_cell(P, alt, labels, K)
+    scale = np.max(np.abs(ref))
+    err_t = np.max(np.abs(h - ref), axis=(0, 2)) / scale
+    assert err_t.max() <= H_TOL
+    assert err_t[-100:].max() <= 4 * max(err_t[:100].max(), 1e-7)      # no growth with t
+
+
 def test_cell_forward_masking_semantics(dev):
     """ragged lengths + a masked HEAD (outside the reference's layout contract, but defined by
     K.rnn): repeat previous output, zeros before the first valid frame, state held."""
