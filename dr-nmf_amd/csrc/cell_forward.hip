@@ -316,6 +316,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             *(f32x2*)(red + ((w * RB + rb) * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
         }
     __syncthreads();
+    if (NW_A > 4 && tid >= 256) return;   // the elementwise epilogue is 256 threads wide
 
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {

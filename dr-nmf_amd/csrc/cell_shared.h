@@ -10,7 +10,7 @@ constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
 constexpr int ATOMS = 32;   // atoms per cell_a workgroup
 constexpr int MAX_KS = 8;
 constexpr int NW_B = 8;    // waves per cell_b workgroup (more requests in flight per CU)
-constexpr int NW_A = 4;    // waves per cell_a workgroup (8 measured slower: 224k vs 232k frames/s)
+constexpr int NW_A = 4;    // waves per cell_a workgroup (8 measured slower, twice: 224k vs 232k, later 259k vs 277k frames/s)
 
 struct CellBArgs {
     const void* Dn_next;     // packed dictionary of the next layer (fp32 Dp, or the fp16 DpB packing)
