@@ -52,15 +52,58 @@ struct EpiResidual {   // R = g(X, X^): enhance.py:412 / 431 / 450
     }
 };
 
+// NT = odd bins kept out of the GEMMs (0..2, see drnmf_ista_forward): their contribution to
+// G = R W is the rank-NT term sum_i R[row][Fm+i] * W[Fm+i][col], added here.
+template <int NT>
 struct EpiIstaUpdate {   // H <- max(0, -lam1/alph + H + (1/alph) G): enhance.py:412
     float* H;
     int N;
     float neg_lam_over_alph, inv_alph;
-    __device__ f32x2 pre(int64_t row, int col) const { return f32x2{H[row * N + col], 0.f}; }
+    const float* Rt;     // R + Fm   (row stride ldr)
+    const float* Wtt;    // Wt + Fm  (row stride ldr): Wtt[col * ldr + i] = W[Fm+i][col]
+    int ldr;
+    __device__ f32x2 pre(int64_t row, int col) const {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) t = fmaf(Rt[row * ldr + i], Wtt[(int64_t)col * ldr + i], t);
+        return f32x2{H[row * N + col], t};
+    }
     __device__ void operator()(int64_t row, int col, float gacc, f32x2 pv) const {
-        H[row * N + col] = fmaxf(0.f, neg_lam_over_alph + pv[0] + inv_alph * gacc);
+        H[row * N + col] = fmaxf(0.f, neg_lam_over_alph + pv[0] + inv_alph * (gacc + pv[1]));
     }
 };
+
+// Odd bins of a 2^k+1 STFT (F = 16 j + 1 or 2): X^[row][Fm+i] = H[row,:] . W[Fm+i,:] and its
+// residual, one wave per row -- instead of a fifth, almost empty 128-column tile in the X^ GEMM
+// (F = 513: 1280 -> 1024 workgroups, 2.5 -> 2 rounds of the chip) and a 17th k-tile in the G GEMM.
+template <int DIV>
+__global__ void __launch_bounds__(256)
+ista_tail_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                 const float* __restrict__ H, float* __restrict__ R, int64_t n, int F, int N,
+                 int Fm, int nt, int ldr, float beta) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (row >= n) return;
+    float s[2] = {0.f, 0.f};
+    const float* hrow = H + row * N;
+    for (int c = l; c < N; c += 64) {
+        const float hv = hrow[c];
+        s[0] = fmaf(hv, W[(size_t)Fm * N + c], s[0]);
+        if (nt > 1) s[1] = fmaf(hv, W[(size_t)(Fm + 1) * N + c], s[1]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s[0] += __shfl_xor(s[0], o, 64);
+        s[1] += __shfl_xor(s[1], o, 64);
+    }
+    if (l < nt) {
+        const float xh = s[l], x = X[row * F + Fm + l];
+        float r;
+        if (DIV == DRNMF_DIV_ED) r = x - xh;
+        else if (DIV == DRNMF_DIV_KL) r = x / xh - 1.f;
+        else r = x * powf(xh, beta - 2.f) - powf(xh, beta - 1.f);
+        R[row * ldr + Fm + l] = r;
+    }
+}
 
 // ---------------- MU epilogues ------------------------------------------------------------------
 struct EpiStore {
@@ -232,18 +275,37 @@ extern "C" int32_t drnmf_ista_forward(drnmf_handle_t h, int64_t n, int32_t F, in
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((Fp4 + 31) / 32, (N + 31) / 32), dim3(256), 0,
                        stream, W, Wt, F, N, Fp4);
     if (Fp4 != F) DRNMF_HIP(h, hipMemsetAsync(R, 0, (size_t)n * Fp4 * 4, stream));
-    gemm::Operands g1{H, W, n, F, N, N, N};          // X^ = H . W^T   (contract atoms)
-    gemm::Operands g2{R, Wt, n, N, Fp4, Fp4, Fp4};   // G  = R . W     (contract bins)
-    EpiIstaUpdate e2{H, N, -lam1 / alph, 1.f / alph};
+    // odd bins (F = 16 j + 1 | 2, the 2^k + 1 STFT sizes) stay out of the GEMM tiles
+    const int nt = (F % 16 != 0 && F % 16 <= 2 && F > 16) ? F % 16 : 0;
+    const int Fm = F - nt;
+    gemm::Operands g1{H, W, n, Fm, N, N, N};                     // X^ = H . W^T  (contract atoms)
+    gemm::Operands g2{R, Wt, n, N, nt ? Fm : Fp4, Fp4, Fp4};     // G  = R . W    (contract bins)
+    const dim3 tgrid((unsigned)((n + 3) / 4));
     for (int k = 0; k < K; ++k) {
-        if (divergence == DRNMF_DIV_ED)
+        if (divergence == DRNMF_DIV_ED) {
             DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_ED>{X, R, F, Fp4, beta}, stream));
-        else if (divergence == DRNMF_DIV_KL)
+            if (nt) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_ED>, tgrid, dim3(256), 0, stream,
+                                       X, W, H, R, n, F, N, Fm, nt, Fp4, beta);
+        } else if (divergence == DRNMF_DIV_KL) {
             DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_KL>{X, R, F, Fp4, beta}, stream));
-        else
+            if (nt) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_KL>, tgrid, dim3(256), 0, stream,
+                                       X, W, H, R, n, F, N, Fm, nt, Fp4, beta);
+        } else {
             DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_BETA>{X, R, F, Fp4, beta}, stream));
-        DRNMF_HIP(h, gemm::launch(g2, e2, stream));
+            if (nt) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_BETA>, tgrid, dim3(256), 0,
+                                       stream, X, W, H, R, n, F, N, Fm, nt, Fp4, beta);
+        }
+        const float c0 = -lam1 / alph, c1 = 1.f / alph;
+        if (nt == 0)
+            DRNMF_HIP(h, gemm::launch(g2, EpiIstaUpdate<0>{H, N, c0, c1, R, Wt, Fp4}, stream));
+        else if (nt == 1)
+            DRNMF_HIP(h, gemm::launch(g2, EpiIstaUpdate<1>{H, N, c0, c1, R + Fm, Wt + Fm, Fp4},
+                                      stream));
+        else
+            DRNMF_HIP(h, gemm::launch(g2, EpiIstaUpdate<2>{H, N, c0, c1, R + Fm, Wt + Fm, Fp4},
+                                      stream));
     }
+    DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }
 

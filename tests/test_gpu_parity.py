@@ -286,6 +286,30 @@ def test_ista_large_ragged_shape_vs_oracle(dev):
     assert err <= 2e-5, err
 
 
+@pytest.mark.parametrize("F", [64, 34, 48, 130])
+@pytest.mark.parametrize("name", ["ed", "kl", "beta"])
+def test_ista_bin_counts_around_the_tile_size(dev, F, name):
+    """The X^ / G GEMMs run on whole 16-bin tiles and the 1-2 odd bins of a 2^k+1 STFT go through
+    a separate rank-1 path: F = 64, 48 (no odd bins), 34, 130 (two), with the goldens covering one."""
+    from drnmf_amd import ops
+    rng = np.random.default_rng(F)
+    N, n, K = 24, 37, 6
+    W = rng.random((F, N)) ** 2
+    W = (W / np.sqrt((W * W).sum(0, keepdims=True))).astype(np.float32)
+    x = (W @ ((rng.random((N, n)) < 0.3) * rng.random((N, n))) + 0.05).astype(np.float32)
+    H0 = (0.1 + 0.1 * rng.random((N, n))).astype(np.float32)
+    alph = 40.0 * N if name != "ed" else 4.0
+    fn = dict(ed=O.ista_ed, kl=O.ista_kl, beta=lambda *a, **k: O.ista_beta(*a, beta=1.5, **k))[name]
+    want = fn(x.astype(np.float64), W.astype(np.float64), H0.astype(np.float64), 0.1, alph, K)
+    want = want[0] if isinstance(want, tuple) else want
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    H = t(H0.T)
+    ops.ista_forward(t(x.T), t(W), H, 0.1, alph, K, divergence=name, beta=1.5)
+    torch.cuda.synchronize()
+    got = H.cpu().numpy().T
+    assert np.max(np.abs(got - want)) <= 2e-5 * max(np.max(np.abs(want)), 1e-6)
+
+
 @pytest.mark.parametrize("beta", [2.0, 1.0, 1.5])
 def test_mu_inference_and_irm_vs_oracle(dev, beta):
     from drnmf_amd import ops
