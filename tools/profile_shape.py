@@ -1,9 +1,9 @@
 import sys, os, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as G; G.build()
 from drnmf_amd import layers, ops
 import importlib.util
-sp = importlib.util.spec_from_file_location('b', '/root/repo/bench.py'); bm = importlib.util.module_from_spec(sp); sp.loader.exec_module(bm)
+sp = importlib.util.spec_from_file_location('b', os.path.join(ROOT, 'bench.py')); bm = importlib.util.module_from_spec(sp); sp.loader.exec_module(bm)
 dev = torch.device('cuda:0')
 B, T, F, r, K = [int(v) for v in sys.argv[1:6]]
 N = 2 * r
