@@ -1,5 +1,9 @@
+"""Per-kernel HIP-event times of the cell at an arbitrary shape (measurement aid):
+    python tools/profile_shape.py B T F r K        # e.g. 64 8 1025 4000 6
+"""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import __graft_entry__ as G; G.build()
 from drnmf_amd import layers, ops
 import importlib.util
