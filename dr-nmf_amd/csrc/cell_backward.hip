@@ -214,11 +214,6 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
         for (int ks = 1; ks < KS; ++ks) r4 += av[g][ks];
         const bool ok = base + g < per_wave;
         if (!ok) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int c = w + 4 * (base + g);
-        if (live && ok && (c % a.numA) == ab && dr_lane) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) dr_row[16 * c + 4 * s] = r4[s];
-        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             acc0 = mfma16(r4[s], bv[g][s][0], acc0);
@@ -236,6 +231,21 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
             __builtin_amdgcn_sched_barrier(0);
             compute_chunk(base, g);
             __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // the d r copy, outside the MFMA loop (a wave-uniform branch inside it costs several %): the
+    // chunks c = ab (mod numA) are re-read (cache hits) and stored by the wave that owns them
+    if (live) {
+        for (int c = ab; c < a.nchunks; c += a.numA) {
+            if ((c & 3) != w) continue;
+            f32x4 r4 = *(const f32x4*)(arow + 256 * c);
+#pragma unroll
+            for (int ks = 1; ks < KS; ++ks) r4 += *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
+            if (dr_lane) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dr_row[16 * c + 4 * s] = r4[s];
+            }
         }
     }
 
