@@ -529,6 +529,7 @@ template <int KS, int RB, bool AH, bool HALF>
 void* a_func_g(int per_wave, bool first, bool last) {
     // G operand slots; operand registers G * (4*KS*RB + 8)
     if (per_wave <= 2) return a_func<2, KS, RB, AH, HALF>(first, last);
+    // (8 slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch)
     return a_func<4, KS, RB, AH, HALF>(first, last);
 }
 
