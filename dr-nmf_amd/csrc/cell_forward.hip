@@ -111,7 +111,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     const float* arow = rsrc + (size_t)mb0 * nft * 256 + j * 16 + q * 4;          // + 256*c
     const size_t astep = (size_t)nft * 256;                                        // per row block
     // B: blocks (c, ac0 | ac0+1) of Dp, rows 4s+q, atoms 2j, 2j+1 of the 32
-    const float* brow = (const float*)a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + q * 16 + (j & 7) * 2;
+    // fp32: the cell_a packing (common.h): block (c, ab) of 512 floats, lane l reads 2 x 16 bytes
+    const float* brow = (const float*)a.Dn + (size_t)ab * 512 + l * 4;
     // fp16: DpA block (c, ac0 + j/8), lane's 8 halves = atoms 2(j%8), 2(j%8)+1 x k = 4q..4q+3
     const f16* brow16 = (const f16*)a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + ((j & 7) * 4 + q) * 8;
     const size_t bstep = (size_t)NAC * 256;                                        // per chunk c
@@ -128,7 +129,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     constexpr int NP = IS_FIRST ? 1 : KS;
 
     f32x4 av[G][RB][NP];
-    f32x2 bv[G][4];
+    f32x4 bv[G][2];      // {s = 2i: atoms a0 a1, s = 2i+1: a0 a1} for i = 0, 1
     f16x4 bh[G][2];
     auto load_chunk = [&](int i, int g) {      // chunk i of this wave -> slot g
         int c = w + NW_A * i;
@@ -143,9 +144,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             bh[g][0] = bp[0];
             bh[g][1] = bp[1];
         } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
+            bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
+            bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
         }
     };
     // Software pipeline: the texture path of a CU moves 64 B/clk and is shared by the 4 waves, so
@@ -158,8 +158,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // pattern in 32 does).
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bv[g][s] = f32x2{0.f, 0.f};
+        bv[g][0] = bv[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         bh[g][0] = bh[g][1] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -272,8 +271,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                acc[rb][0] = mfma16(r4[rb][s], bv[g][s][0], acc[rb][0]);
-                acc[rb][1] = mfma16(r4[rb][s], bv[g][s][1], acc[rb][1]);
+                acc[rb][0] = mfma16(r4[rb][s], bv[g][s >> 1][(s & 1) * 2], acc[rb][0]);
+                acc[rb][1] = mfma16(r4[rb][s], bv[g][s >> 1][(s & 1) * 2 + 1], acc[rb][1]);
             }
         }
     };
@@ -645,13 +644,16 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     const size_t dstride = (size_t)L.Fp * L.Np * 4;
     auto Dn_of = [&](int k) { return Dn_base + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
     auto DnB_of = [&](int k) { return Dn_of(k) + (half ? dstride / 2 : 0); };
+    auto DnA_of = [&](int k) {      // cell_a's operand: fp16 DpA, or the fp32 cell_a packing
+        return half ? Dn_of(k) : pb + L.off_dnA + (d->n_D == 1 ? 0 : (size_t)k * dstride);
+    };
     auto tail_of = [&](int k) {
         return (const float*)(pb + L.off_tail) + (d->n_D == 1 ? 0 : (size_t)k * MAX_TAIL * L.Np);
     };
 
     auto make_a = [&](int k) {
         CellAArgs a;
-        a.Dn = Dn_of(k);
+        a.Dn = DnA_of(k);
         a.inv_alpha = (const float*)(pb + L.off_inv_alpha) + (size_t)k * L.Np;
         a.bias = (const float*)(pb + L.off_bias) + (size_t)k * L.Np;
         a.rsrc = (k == 0) ? xp : rpart;

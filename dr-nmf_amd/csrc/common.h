@@ -65,10 +65,14 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 // params block layout (see drnmf_prepare_params).  off_dn: per stored layer either the fp32
 // tile-packed dictionary Dp[ft][ac][f%16][n%16] or, with operand_f16, two fp16 packings of the same
 // bytes in total (cell_a's, then cell_b's; params.hip).  off_tail: fp32 rows of the tail bins
-// [n_D][MAX_TAIL][Np] (fp16-rounded values in operand_f16 mode).
+// [n_D][MAX_TAIL][Np] (fp16-rounded values in operand_f16 mode).  off_dnA (fp32 mode only): a
+// second packing of the dictionary for cell_a / bwd_a, whose lanes need 2 atoms x 4 bins per chunk:
+// DpA[ft][n/32][s/2][q][j][s%2][a] = Dn[16 ft + 4s + q][32 (n/32) + 2j + a], so that the operand
+// comes in two 16-byte loads per lane over contiguous 1 KB (8-byte loads run at half the
+// texture-path rate).
 struct ParamsLayout {
     int Fp, Np;
-    size_t off_dn, off_colnorm, off_inv_alpha, off_bias, off_tail, total;
+    size_t off_dn, off_colnorm, off_inv_alpha, off_bias, off_tail, off_dnA, total;
 };
 static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     ParamsLayout L;
@@ -80,6 +84,8 @@ static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     L.off_inv_alpha = o; o += round_up_sz((size_t)d->K * L.Np * sizeof(float), 256);
     L.off_bias = o;      o += round_up_sz((size_t)d->K * L.Np * sizeof(float), 256);
     L.off_tail = o;      o += round_up_sz((size_t)d->n_D * MAX_TAIL * L.Np * sizeof(float), 256);
+    L.off_dnA = o;
+    if (!d->operand_f16) o += (size_t)d->n_D * L.Fp * L.Np * sizeof(float);
     L.total = o;
     return L;
 }

@@ -90,8 +90,8 @@ extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
 template <bool HALF>
 __global__ void __launch_bounds__(256)
 prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
-                 float* __restrict__ colnorm, float* __restrict__ tail, int F, int N, int Fp,
-                 int Np) {
+                 float* __restrict__ colnorm, float* __restrict__ tail, float* __restrict__ DnA_,
+                 int F, int N, int Fp, int Np) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int layer = blockIdx.y;
     if (n >= Np) return;
@@ -100,9 +100,14 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
     float* dn = (float*)Dn_ + (size_t)layer * lstride + (size_t)(n >> 4) * 256 + (n & 15);
     f16* dA = (f16*)Dn_ + (size_t)layer * 2 * lstride;
     f16* dB = dA + lstride;
+    float* dnA = HALF ? nullptr : DnA_ + (size_t)layer * lstride;
     auto put = [&](int f, float v) {
         if (!HALF) {
             dn[(size_t)(f >> 4) * NAC * 256 + (f & 15) * 16] = v;
+            // cell_a packing (common.h): block (ft, n/32), s = fi/4, q = fi%4, j = (n%32)/2, a = n%2
+            const int fi = f & 15, n32 = n & 31;
+            dnA[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + (fi >> 3) * 256 +
+                ((fi & 3) * 16 + (n32 >> 1)) * 4 + ((fi >> 2) & 1) * 2 + (n32 & 1)] = v;
         } else {
             const size_t blk = ((size_t)(f >> 4) * NAC + (n >> 4)) * 256;
             const int fi = f & 15;
@@ -174,11 +179,12 @@ extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_
     if (d->operand_f16)
         hipLaunchKernelGGL(prep_dict_kernel<true>, g1, dim3(256), 0, stream, log_D,
                            (void*)(base + L.off_dn), (float*)(base + L.off_colnorm),
-                           (float*)(base + L.off_tail), d->F, d->N, L.Fp, L.Np);
+                           (float*)(base + L.off_tail), (float*)nullptr, d->F, d->N, L.Fp, L.Np);
     else
         hipLaunchKernelGGL(prep_dict_kernel<false>, g1, dim3(256), 0, stream, log_D,
                            (void*)(base + L.off_dn), (float*)(base + L.off_colnorm),
-                           (float*)(base + L.off_tail), d->F, d->N, L.Fp, L.Np);
+                           (float*)(base + L.off_tail), (float*)(base + L.off_dnA), d->F, d->N,
+                           L.Fp, L.Np);
     dim3 g2((L.Np + 255) / 256, d->K);
     hipLaunchKernelGGL(prep_scalars_kernel, g2, dim3(256), 0, stream, log_alph, log_lam1,
                        (float*)(base + L.off_inv_alpha), (float*)(base + L.off_bias), d->N, L.Np,
