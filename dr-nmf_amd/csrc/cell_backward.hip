@@ -162,23 +162,22 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     const size_t pstride = (size_t)a.Bp * Fp;
     const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
     const float* arow = a.drpart + (size_t)m * nft * 256 + j * 16 + q * 4;
-    const float* brow = a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + q * 16 + (j & 7) * 2;
+    const float* brow = a.Dn + (size_t)ab * 512 + l * 4;     // the cell_a packing (common.h)
     const size_t bstep = (size_t)NAC * 256;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int per_wave = (a.nchunks - w + 3) >> 2;
     const int clast = a.nchunks - 1;
     f32x4 av[G][KS];
-    f32x2 bv[G][4];
+    f32x4 bv[G][2];
     auto load_chunk = [&](int base, int g) {
         int c = w + 4 * (base + g);
         c = c > clast ? clast : c;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             av[g][ks] = *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            bv[g][s] = *(const f32x2*)(brow + (size_t)c * bstep + 64 * s);
+        bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
+        bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
     };
     // same software pipeline as the forward's cell_a_kernel: operand loads run PF chunks ahead
     // of the MFMAs
@@ -216,8 +215,8 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
         if (!ok) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            acc0 = mfma16(r4[s], bv[g][s][0], acc0);
-            acc1 = mfma16(r4[s], bv[g][s][1], acc1);
+            acc0 = mfma16(r4[s], bv[g][s >> 1][(s & 1) * 2], acc0);
+            acc1 = mfma16(r4[s], bv[g][s >> 1][(s & 1) * 2 + 1], acc1);
         }
     };
     for (int base = 0; base < per_wave; base += G) {
@@ -605,7 +604,7 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     };
     auto make_a = [&](int k) {
         BwdAArgs a;
-        a.Dn = Dp_of(k);
+        a.Dn = (const float*)(pb + PL.off_dnA) + (d->n_D == 1 ? 0 : (size_t)k * dstride);
         a.ia_prev = ia_of(k - 1);
         a.drpart = drpart;
         a.dzp_in = dzp[k & 1];
