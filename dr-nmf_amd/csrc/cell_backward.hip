@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
     const int NAC = a.Np / 16, ac0 = ab * 2;
     const int erow = tid >> 4, ec = (tid & 15) * 2;
     const int rg = m * ROWS + erow, n = ab * ATOMS + ec;
-    const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
+    const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + hp_pos(erow, ec & 15);
     const int KN = a.K * a.N;
     const size_t pstride = (size_t)a.numA * a.Bp;
 
@@ -161,7 +161,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     const int row0 = m * ROWS, n0 = ab * ATOMS;
     const size_t pstride = (size_t)a.Bp * Fp;
     const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
-    const float* arow = a.drpart + (size_t)m * nft * 256 + j * 16 + q * 4;
+    const float* arow = a.drpart + (size_t)m * nft * 256 + l * 4;
     const float* brow = a.Dn + (size_t)ab * 512 + l * 4;     // the cell_a packing (common.h)
     const size_t bstep = (size_t)NAC * 256;
 
@@ -191,7 +191,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     const int t = a.T - 1 - cnt;
     const int erow = tid >> 4, ec = (tid & 15) * 2;
     const int rg = row0 + erow, n = n0 + ec;
-    const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
+    const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + hp_pos(erow, ec & 15);
     const int KN = a.K * a.N;
     const f32x2 dzk = *(const f32x2*)(a.dzp_in + hoff);
     const f32x2 ia = *(const f32x2*)(a.ia_prev + n);
@@ -314,7 +314,8 @@ unpack_dn_kernel(const float* __restrict__ Dp, float* __restrict__ Dn, int Fp, i
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)Fp * Np) return;
     const int f = (int)(i / Np), n = (int)(i % Np);
-    Dn[i] = Dp[((size_t)(f >> 4) * (Np / 16) + (n >> 4)) * 256 + (f & 15) * 16 + (n & 15)];
+    Dn[i] = Dp[((size_t)(f >> 4) * (Np / 16) + (n >> 4)) * 256 + (((n & 15) >> 2) * 16 + (f & 15)) * 4 +
+               (n & 3)];
 }
 
 struct EpiResid {   // R = X - H Dn^T

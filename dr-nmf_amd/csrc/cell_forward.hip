@@ -24,9 +24,11 @@
 // residual partials, packed input) is stored as 1 KB blocks of 16 x 16 floats, so that each MFMA
 // operand load instruction of a wave covers contiguous full cache lines (a row-major layout makes
 // every load touch 16 half-used lines and the kernels stall on VMEM issue):
-//     Dp[ft][ac][f%16][n%16]   Hp[m][ac][row%16][n%16]   Rp[m][ft][row%16][perm(f%16)]
-// with ft = f/16, ac = n/16, m = row/16 and perm(e) = (e%4)*4 + e/4 (cell_a contracts bins in
-// the slot order f = 16c + 4s + q so that its dictionary loads cover whole lines).
+//     Dp[ft][ac][q][f%16][e]   Hp[m][ac][hp_pos(row%16, n%16)]   Rp[m][ft][rp_pos(row%16, f%16)]
+// with ft = f/16, ac = n/16, m = row/16; hp_pos / rp_pos (common.h) order a block so that lane
+// q*16 + row finds its four operand values at lane*16 bytes (cell_a contracts bin 16c + 4s + q in
+// its s-th MFMA, cell_b atom 16c + 4q + s); cell_a / bwd_a read the dictionary from a second
+// packing, DpA (common.h).
 //
 // A frame is 2K-1 launches, built once as a hipGraph and replayed T times; kernels read the frame
 // index from device memory.  Dictionary operands are read straight into MFMA operand registers:
@@ -108,7 +110,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     const float* rsrc = IS_FIRST ? a.rsrc + (size_t)t * pstride : a.rsrc;
     const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
     // A: block (mb, c) of Rp, lane (row j, slot q) reads the float4 {s = 0..3} <-> f = 16c+4s+q
-    const float* arow = rsrc + (size_t)mb0 * nft * 256 + j * 16 + q * 4;          // + 256*c
+    const float* arow = rsrc + (size_t)mb0 * nft * 256 + l * 4;                   // + 256*c
     const size_t astep = (size_t)nft * 256;                                        // per row block
     // B: blocks (c, ac0 | ac0+1) of Dp, rows 4s+q, atoms 2j, 2j+1 of the 32
     // fp32: the cell_a packing (common.h): block (c, ab) of 512 floats, lane l reads 2 x 16 bytes
@@ -174,7 +176,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // ---- epilogue operands (tiny, needed last; issued behind the GEMM operands) --------------
     const int erow = (tid & 255) >> 4, ec = (tid & 15) * 2;
     const int n = n0 + ec;
-    const size_t hoff0 = ((size_t)mb0 * NAC + ac0 + (ec >> 4)) * 256 + erow * 16 + (ec & 15);
+    const size_t hoff0 = ((size_t)mb0 * NAC + ac0 + (ec >> 4)) * 256 + hp_pos(erow, ec & 15);
     const size_t hstep = (size_t)NAC * 256;                                        // per row block
     const f32x2 ia = *(const f32x2*)(a.inv_alpha + n);
     const f32x2 bs = *(const f32x2*)(a.bias + n);
@@ -227,8 +229,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             for (int u = 0; u < 4; ++u) qv[rb][i][u] = 0.f;
             if (i >= a.ntail) continue;
             if (IS_FIRST) {
-                // packed input: bin 16*nchunks + i sits at tile nchunks, position perm(i) = 4*i
-                xt[rb][i] = rsrc[((size_t)(mb0 + rb) * nft + a.nchunks) * 256 + erow * 16 + 4 * i];
+                // packed input: bin 16*nchunks + i sits in tile nchunks
+                xt[rb][i] = rsrc[((size_t)(mb0 + rb) * nft + a.nchunks) * 256 + rp_pos(erow, i)];
             } else {
                 xt[rb][i] = a.xtail[(size_t)i * a.Bp + rg];
                 const float* qp = a.q_in + (size_t)i * a.Bp + rg;
@@ -254,7 +256,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 // republish this row tile's x_t chunk at a frame-independent address (cell_b
                 // reads it without a dependent frame-index load)
                 const int c = w + NW_A * (base + g);
-                *(f32x4*)(a.xcur + (size_t)(mb0 + rb) * nft * 256 + 256 * c + j * 16 + q * 4) = r4[rb];
+                *(f32x4*)(a.xcur + (size_t)(mb0 + rb) * nft * 256 + 256 * c + l * 4) = r4[rb];
             }
             if (!ok) r4[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -429,7 +431,7 @@ load_state_kernel(const float* __restrict__ init, float* __restrict__ state,
     for (int n = l; n < Np; n += 64) {
         const float v = (b < B && n < N) ? init[(size_t)b * N + n] : 0.f;
         s += v;
-        state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + (b & 15) * 16 + (n & 15)] = v;
+        state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + hp_pos(b & 15, n & 15)] = v;
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (l == 0) {
@@ -442,7 +444,7 @@ store_state_kernel(const float* __restrict__ state, float* __restrict__ out, int
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * N) return;
     const int b = (int)(i / N), n = (int)(i % N);
-    out[i] = state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + (b & 15) * 16 + (n & 15)];
+    out[i] = state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + hp_pos(b & 15, n & 15)];
 }
 
 // Masking + relayout: x [B][T][F] -> xp [T][Bp][Fp] (masked frames and all padding zero) and
@@ -456,21 +458,19 @@ pack_input_kernel(const float* __restrict__ x, float* __restrict__ xp,
     if (rowid >= (size_t)T * Bp) return;
     const int t = (int)(rowid / Bp), b = (int)(rowid % Bp);
     const int nft = Fp / 16;
-    // tile-packed destination: Rp[t][b/16][f/16][b%16][perm(f%16)]
-    float* dst = xp + (size_t)t * Bp * Fp + (size_t)(b >> 4) * nft * 256 + (b & 15) * 16;
+    // tile-packed destination: Rp[t][b/16][f/16][rp_pos(b%16, f%16)]
+    float* dst = xp + (size_t)t * Bp * Fp + (size_t)(b >> 4) * nft * 256;
     bool any = false;
     if (b < B) {
         const float* src = x + ((size_t)b * T + t) * F;
         for (int f = l; f < F; f += 64) any |= (src[f] != mask_value);
         any = __any(any);
         for (int f = l; f < Fp; f += 64) {
-            const int e = f & 15;
-            dst[(size_t)(f >> 4) * 256 + ((e & 3) * 4 + (e >> 2))] = (any && f < F) ? src[f] : 0.f;
+            dst[(size_t)(f >> 4) * 256 + rp_pos(b & 15, f & 15)] = (any && f < F) ? src[f] : 0.f;
         }
     } else {
         for (int f = l; f < Fp; f += 64) {
-            const int e = f & 15;
-            dst[(size_t)(f >> 4) * 256 + ((e & 3) * 4 + (e >> 2))] = 0.f;
+            dst[(size_t)(f >> 4) * 256 + rp_pos(b & 15, f & 15)] = 0.f;
         }
     }
     if (l == 0) valid[rowid] = any ? 1 : 0;
@@ -506,7 +506,7 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
             s += v;
         }
         for (int b = 0; b < Bp; ++b)   // tile-packed Hp[b/16][n/16][b%16][n%16]
-            state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + (b & 15) * 16 + (n & 15)] = v;
+            state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + hp_pos(b & 15, n & 15)] = v;
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((tid & 63) == 0) wsum[tid >> 6] = s;

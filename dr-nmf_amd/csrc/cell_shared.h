@@ -60,11 +60,12 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
     const int clast = nch - 1;
 
     const int NAC = Np / 16;
-    // blocks (mb, cbase+c) of Hp and (ft, cbase+c) of Dp: lane (j, q) reads the float4 of atoms
-    // 16c + 4q + {0..3} in row j -> one contiguous 1 KB block per wave instruction
-    const float* arow = a.h + ((size_t)m * RB * NAC + cbase) * 256 + j * 16 + q * 4;     // + 256*c
+    // blocks (mb, cbase+c) of Hp and (ft, cbase+c) of Dp: lane (j, q) = lane q*16 + j reads the
+    // float4 of atoms 16c + 4q + {0..3} of row / bin j at lane*16 bytes -> one contiguous 1 KB
+    // block per wave instruction, consecutive lanes on consecutive addresses
+    const float* arow = a.h + ((size_t)m * RB * NAC + cbase) * 256 + l * 4;              // + 256*c
     const size_t astep = (size_t)NAC * 256;                                              // per row block
-    const float* brow = (const float*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;
+    const float* brow = (const float*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + l * 4;   // [q][bin][e]
     const f16* brow16 = (const f16*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;
 
     // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
@@ -85,9 +86,12 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
     // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
-    const int erow = (tid & 255) >> 4, ecol = tid & 15;
+    // thread p of the first 256 owns the element at position p of the output block (rp_pos order:
+    // p = (q*16 + row)*4 + s <-> bin 4s + q), so that the x_t load and the store are contiguous
+    const int ep = tid & 255;
+    const int erow = (ep >> 2) & 15, ecol = 4 * (ep & 3) + (ep >> 6);
     // (buffers keep Fp/16 tiles per row tile even when only a.nft of them are MFMA tiles)
-    const size_t eoff = ((size_t)m * RB * (Fp / 16) + ft) * 256 + erow * 16 + ((ecol & 3) * 4 + (ecol >> 2));
+    const size_t eoff = ((size_t)m * RB * (Fp / 16) + ft) * 256 + ep;
     const size_t estep = (size_t)(Fp / 16) * 256;                                        // per row block
     float xv[RB];
 #pragma unroll

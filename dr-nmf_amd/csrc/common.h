@@ -57,6 +57,15 @@ extern char g_create_err[512];
         }                                                                                \
     } while (0)
 
+// Position of element (row r, column c), r, c in 0..15, inside a 1 KB block of a tile-packed
+// activation / residual buffer.  Both orders put the four values one MFMA lane (row r, k-group q)
+// needs in one 16-byte piece at lane * 16 bytes (lane = q*16 + r): consecutive lanes read
+// consecutive memory (lane order matters to the texture path: +1.3 % per operand on the headline).
+//   hp_pos: lane's values = atoms 4q..4q+3 (cell_b contracts consecutive atoms per MFMA)
+//   rp_pos: lane's values = bins q, 4+q, 8+q, 12+q (cell_a contracts bin 4s+q in its s-th MFMA)
+__host__ __device__ static inline int hp_pos(int r, int c) { return ((c >> 2) * 16 + r) * 4 + (c & 3); }
+__host__ __device__ static inline int rp_pos(int r, int c) { return ((c & 3) * 16 + r) * 4 + (c >> 2); }
+
 constexpr int MAX_TAIL = 2;   // STFT sizes are 2^k + 1: the odd bin(s) must not cost a whole 16-bin tile
 
 using f16 = _Float16;

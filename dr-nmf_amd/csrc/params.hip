@@ -97,13 +97,16 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
     if (n >= Np) return;
     const int NAC = Np / 16;
     const size_t lstride = (size_t)Fp * Np;
-    float* dn = (float*)Dn_ + (size_t)layer * lstride + (size_t)(n >> 4) * 256 + (n & 15);
+    // fp32 Dp block (ft, ac): [(q*16 + f%16)*4 + e] = Dn[f][16 ac + 4q + e] -- lane l = q*16 + f%16 of
+    // cell_b reads its four atoms at l*16 bytes: consecutive lanes, consecutive 16 bytes
+    float* dn = (float*)Dn_ + (size_t)layer * lstride + (size_t)(n >> 4) * 256 +
+                ((n & 15) >> 2) * 64 + (n & 3);
     f16* dA = (f16*)Dn_ + (size_t)layer * 2 * lstride;
     f16* dB = dA + lstride;
     float* dnA = HALF ? nullptr : DnA_ + (size_t)layer * lstride;
     auto put = [&](int f, float v) {
         if (!HALF) {
-            dn[(size_t)(f >> 4) * NAC * 256 + (f & 15) * 16] = v;
+            dn[(size_t)(f >> 4) * NAC * 256 + (f & 15) * 4] = v;
             // cell_a packing (common.h): block (ft, n/32), s = fi/4, q = fi%4, j = (n%32)/2, a = n%2
             const int fi = f & 15, n32 = n & 31;
             dnA[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + (fi >> 3) * 256 +

@@ -63,8 +63,8 @@ def unpack_params(block, desc):
     f = block.view(torch.float32) if block.dtype != torch.float32 else block
     o = 0
     n = desc.n_D * Fp * Np
-    # tile-packed Dp[ft][ac][f%16][n%16] -> logical [Fp][Np]
-    Dn = f[o:o + n].view(desc.n_D, Fp // 16, Np // 16, 16, 16).permute(0, 1, 3, 2, 4) \
+    # tile-packed Dp[ft][ac][q][f%16][e] (n%16 = 4q + e) -> logical [Fp][Np]
+    Dn = f[o:o + n].view(desc.n_D, Fp // 16, Np // 16, 4, 16, 4).permute(0, 1, 4, 2, 3, 5) \
         .reshape(desc.n_D, Fp, Np); o += n
     n = desc.n_D * Np
     colnorm = f[o:o + n].view(desc.n_D, Np); o += r256(n * 4) // 4
