@@ -115,8 +115,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // B: blocks (c, ac0 | ac0+1) of Dp, rows 4s+q, atoms 2j, 2j+1 of the 32
     // fp32: the cell_a packing (common.h): block (c, ab) of 512 floats, lane l reads 2 x 16 bytes
     const float* brow = (const float*)a.Dn + (size_t)ab * 512 + l * 4;
-    // fp16: DpA block (c, ac0 + j/8), lane's 8 halves = atoms 2(j%8), 2(j%8)+1 x k = 4q..4q+3
-    const f16* brow16 = (const f16*)a.Dn + (size_t)(ac0 + (j >> 3)) * 256 + ((j & 7) * 4 + q) * 8;
+    // fp16: DpA block (c, ab) of 512 halves, lane's 8 halves = atoms 2j, 2j+1 x k = 4q..4q+3
+    const f16* brow16 = (const f16*)a.Dn + (size_t)ab * 512 + l * 8;
     const size_t bstep = (size_t)NAC * 256;                                        // per chunk c
 
     // ---- GEMM operands first (critical path), wave w takes chunks c = w (mod 4) -------------

@@ -66,7 +66,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
     const float* arow = a.h + ((size_t)m * RB * NAC + cbase) * 256 + l * 4;              // + 256*c
     const size_t astep = (size_t)NAC * 256;                                              // per row block
     const float* brow = (const float*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + l * 4;   // [q][bin][e]
-    const f16* brow16 = (const f16*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + j * 16 + q * 4;
+    const f16* brow16 = (const f16*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + l * 4;
 
     // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
     f32x4 av[GB][RB], bv[GB];

@@ -82,10 +82,10 @@ extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
 // pass 2 writes exp(log_D)/sqrt(sum) -- enhance.py:177-178 / 190-191 -- into the TILE-PACKED
 // dictionary (1 KB blocks of 16 bins x 16 atoms; see cell_forward.hip).  Padded rows/columns are
 // written as zeros.  HALF = false: fp32 Dp[ft][ac][f%16][n%16].  HALF = true: two fp16 packings,
-//   A (cell_a, contracts bins):  DpA[ft][ac][p][q][a][e] = Dn[16 ft + 4e + q][16 ac + 2p + a]
-//                                (MFMA k = 4q+e; a lane's two atoms 2p, 2p+1 are one 16-byte load)
-//   B (cell_b, contracts atoms): DpB[ft][ac][f%16][n%16] = Dn[f][n]
-// each Fp*Np halves; a wave's operand load covers contiguous 512-byte blocks.
+//   A (cell_a, contracts bins):  DpA[ft][n/32][q][j][a][e] = Dn[16 ft + 4e + q][32 (n/32) + 2j + a]
+//                                (MFMA k = 4q+e; a lane's two atoms are one 16-byte load)
+//   B (cell_b, contracts atoms): DpB[ft][ac][q][f%16][e] = Dn[f][16 ac + 4q + e]
+// each Fp*Np halves; lane l = q*16 + (j | f%16) reads at l * (16 | 8) bytes of its block.
 // tail[layer][i][n] = Dn[16*(F/16) + i][n] for the (at most MAX_TAIL) bins past the last full tile.
 template <bool HALF>
 __global__ void __launch_bounds__(256)
@@ -112,11 +112,14 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
             dnA[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + (fi >> 3) * 256 +
                 ((fi & 3) * 16 + (n32 >> 1)) * 4 + ((fi >> 2) & 1) * 2 + (n32 & 1)] = v;
         } else {
-            const size_t blk = ((size_t)(f >> 4) * NAC + (n >> 4)) * 256;
-            const int fi = f & 15;
-            const int n16 = n & 15;                                      // q = fi%4, e = fi/4
-            dA[blk + (((n16 >> 1) * 4 + (fi & 3)) * 2 + (n16 & 1)) * 4 + (fi >> 2)] = (f16)v;
-            dB[blk + fi * 16 + (n & 15)] = (f16)v;
+            const int fi = f & 15, n32 = n & 31;
+            // A: block (ft, n/32) of 512 halves, lane l = q*16 + j (q = fi%4, j = (n%32)/2) holds
+            //    its 8 halves {a = 0: e = 0..3, a = 1: e = 0..3} (e = fi/4) at l*16 bytes
+            dA[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + ((fi & 3) * 16 + (n32 >> 1)) * 8 +
+               (n32 & 1) * 4 + (fi >> 2)] = (f16)v;
+            // B: block (ft, ac) of 256 halves, lane l = q*16 + f%16 holds atoms 4q..4q+3 at l*8 bytes
+            dB[((size_t)(f >> 4) * NAC + (n >> 4)) * 256 + (((n & 15) >> 2) * 16 + fi) * 4 + (n & 3)] =
+                (f16)v;
         }
     };
     const int t0 = (F / 16) * 16;
