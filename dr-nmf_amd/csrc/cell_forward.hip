@@ -57,7 +57,8 @@ struct CellAArgs {
     float u0d, u0o, uko;
     const float* Dtail;      // [MAX_TAIL][Np] tail-bin rows of this layer's dictionary
     const float* Dtail_next; // the same of layer k+1 (for the next x^ tail partials)
-    const float* q_in;       // [numA][MAX_TAIL][Bp] tail-bin x^ partials of the previous layer
+    const float* q_in;       // [MAX_TAIL][Bp][numA] tail-bin x^ partials of the previous layer (one
+                             // row's partials are contiguous: the 16 lanes that add them load 64 B)
     float* q_out;            // same, produced for the next layer
     float* xtail;            // [MAX_TAIL][Bp] tail bins of x_t (published by the first layer)
     float* xcur;             // [Bp][Fp] packed x_t, republished by the first layer for cell_b
@@ -233,11 +234,11 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 xt[rb][i] = rsrc[((size_t)(mb0 + rb) * nft + a.nchunks) * 256 + rp_pos(erow, i)];
             } else {
                 xt[rb][i] = a.xtail[(size_t)i * a.Bp + rg];
-                const float* qp = a.q_in + (size_t)i * a.Bp + rg;
+                const float* qp = a.q_in + ((size_t)i * a.Bp + rg) * a.numA;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {   // atom blocks (tid&15) + 16u: covers numA <= 64 here
                     const int b2 = (tid & 15) + 16 * u;
-                    if (b2 < a.numA) qv[rb][i][u] = qp[(size_t)b2 * MAX_TAIL * a.Bp];
+                    if (b2 < a.numA) qv[rb][i][u] = qp[b2];
                 }
             }
         }
@@ -339,9 +340,9 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 if (ab_raw == 0 && (tid & 15) == 0) a.xtail[(size_t)i * a.Bp + rg] = xt[rb][i];
             } else {
                 float sq = (qv[rb][i][0] + qv[rb][i][1]) + (qv[rb][i][2] + qv[rb][i][3]);
-                const float* qp = a.q_in + (size_t)i * a.Bp + rg;
+                const float* qp = a.q_in + ((size_t)i * a.Bp + rg) * a.numA;
                 for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16)      // numA > 64 only
-                    sq += qp[(size_t)b2 * MAX_TAIL * a.Bp];
+                    sq += qp[b2];
                 sq += __shfl_xor(sq, 8, 16);
                 sq += __shfl_xor(sq, 4, 16);
                 sq += __shfl_xor(sq, 2, 16);
@@ -402,7 +403,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 sq += __shfl_xor(sq, 4, 16);
                 sq += __shfl_xor(sq, 2, 16);
                 sq += __shfl_xor(sq, 1, 16);
-                if ((tid & 15) == 0) a.q_out[((size_t)ab * MAX_TAIL + i) * a.Bp + rg] = sq;
+                if ((tid & 15) == 0) a.q_out[((size_t)i * a.Bp + rg) * a.numA + ab] = sq;
             }
         }
     }
