@@ -200,6 +200,10 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     const int nchN = W.Np / 16;
     int KS = 1;
     while (KS < (W.RB > 1 ? 2 : MAX_KS) && tiles * KS < 224 && nchN / (KS * 2) >= 4) KS *= 2;
+    if (const char* e = getenv("DRNMF_KS")) {   // tuning aid: force the number of atom ranges
+        const int v = atoi(e);
+        if ((v == 1 || v == 2 || v == 4 || v == 8) && (W.RB == 1 || v <= 2) && nchN / v >= 1) KS = v;
+    }
     W.KS = KS;
     W.nch_ks = (nchN + KS - 1) / KS;
     size_t o = 0;
