@@ -218,6 +218,24 @@ def config5_bench(torch, dev, frames=64, B=64):
     return out
 
 
+def run_guarded(fn, timeout_s, on_timeout):
+    """fn() with a watchdog thread: exceptions become {'error': ...}; if fn has not returned after
+    timeout_s the watchdog calls on_timeout() (which is expected to end the process)."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(timeout_s):
+            on_timeout()
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        res = fn()
+    except Exception as e:           # noqa: BLE001 -- reported in the JSON line instead
+        res = {"error": repr(e)[:300]}
+    done.set()
+    return res
+
+
 def pmc_traffic():
     """HBM-side bytes per cell launch from the newest committed PMC summary (separate rocprofv3
     --pmc passes over this same command, profiles/collect.sh; FETCH_SIZE KB x 1024 x 2 -- the
@@ -288,8 +306,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        # (test aids: DRNMF_BENCH_BACKEND=gloo and DRNMF_BENCH_DEVICE=<i> let the N > 1 path run with
+        # several ranks on ONE GPU, where RCCL refuses duplicate devices)
+        if "DRNMF_BENCH_DEVICE" in os.environ:
+            local = int(os.environ["DRNMF_BENCH_DEVICE"])
+        backend = os.environ.get("DRNMF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(local)
@@ -409,6 +435,22 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(F, r, K, B, a.cpu_frames, a.tied)
+    if world > 1 and not a.no_train:
+        # BASELINE configs[3]: data-parallel training, 32 utterances per GPU, one RCCL all-reduce of
+        # the flat gradient per step (every rank takes part).  Guarded: a collective that does not
+        # come back must not cost the headline line -- after 180 s rank 0 prints what it has and
+        # every rank leaves.
+        def on_timeout():
+            if rank == 0:
+                out["extra"]["train_step_configs3_dp"] = {"error": "timed out after 180 s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        res = run_guarded(lambda: train_bench(torch, dev, steps=3), 180.0, on_timeout)
+        if rank == 0:
+            if "error" not in res:
+                res.update({"n_gpus": world, "global_batch": 32 * world,
+                            "frames_per_s_all_gpus": res["frames_per_s"] * world})
+            out["extra"]["train_step_configs3_dp"] = res
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
