@@ -196,9 +196,13 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     float qv[RB][MAX_TAIL][4];
     // (unconditional loads: a guarded load here makes hipcc wait for EVERY outstanding load
     // before the GEMM loop; without tail bins the values are never used)
-    f32x2 dt[MAX_TAIL];
+    f32x2 dt[MAX_TAIL], dtn[MAX_TAIL];   // tail rows of this layer's and the next layer's dictionary
 #pragma unroll
-    for (int i = 0; i < MAX_TAIL; ++i) dt[i] = *(const f32x2*)(a.Dtail + (size_t)i * Np + n);
+    for (int i = 0; i < MAX_TAIL; ++i) {
+        dt[i] = *(const f32x2*)(a.Dtail + (size_t)i * Np + n);
+        dtn[i] = *(const f32x2*)(a.Dtail_next + (size_t)i * Np + n);   // (used at the very end: a
+                                            // load issued there would sit on the critical path)
+    }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int rg = (mb0 + rb) * ROWS + erow;
@@ -397,8 +401,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
 #pragma unroll
             for (int i = 0; i < MAX_TAIL; ++i) {
                 if (i >= a.ntail) continue;
-                const f32x2 dn = *(const f32x2*)(a.Dtail_next + (size_t)i * Np + n);
-                float sq = hn[0] * dn[0] + hn[1] * dn[1];
+                float sq = hn[0] * dtn[i][0] + hn[1] * dtn[i][1];
                 sq += __shfl_xor(sq, 8, 16);
                 sq += __shfl_xor(sq, 4, 16);
                 sq += __shfl_xor(sq, 2, 16);
