@@ -69,10 +69,8 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
             s0 += z0[(size_t)b2 * a.Bp];
             sp += dp_[(size_t)b2 * a.Bp];
         }
-        for (int o = 8; o > 0; o >>= 1) {
-            s0 += __shfl_xor(s0, o, 16);
-            sp += __shfl_xor(sp, o, 16);
-        }
+        s0 = row16_sum(s0);
+        sp = row16_sum(sp);
         const f32x2 dz0 = *(const f32x2*)(a.dzp0 + hoff);
         if (a.valid[(size_t)(t + 1) * a.Bp + rg]) {
             ds[0] = a.u0d * dz0[0] + a.u0o * (s0 - dz0[0]) + sp;
@@ -104,7 +102,7 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
         *(f32x2*)(a.dGp_top + hoff) = dG;
         const int par = c & 1;
         float s = dz[0] + dz[1];
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        s = row16_sum(s);
         if ((tid & 15) == 0) {
             a.dps_part[par * pstride + (size_t)ab * a.Bp + rg] = 0.f;
             if (a.K == 1) a.dz0s_part[par * pstride + (size_t)ab * a.Bp + rg] = s;
@@ -275,10 +273,8 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     f32x2 dG = {dzn[0] * ia[0], dzn[1] * ia[1]};
     *(f32x2*)(a.dGp_out + hoff) = dG;
     float s = dzk[0] + dzk[1], s0 = dzn[0] + dzn[1];
-    for (int o = 8; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 16);
-        s0 += __shfl_xor(s0, o, 16);
-    }
+    s = row16_sum(s);
+    s0 = row16_sum(s0);
     if ((tid & 15) == 0) {
         const size_t po = (size_t)(cnt & 1) * a.numA * a.Bp + (size_t)ab * a.Bp + rg;
         a.dps_part[po] += a.uko * s;

@@ -213,10 +213,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             const float* rp = a.rs_part + (size_t)(t & 1) * a.numA * a.Bp + rg;
             float s = 0.f;
             for (int b2 = (tid & 15); b2 < a.numA; b2 += 16) s += rp[(size_t)b2 * a.Bp];
-            s += __shfl_xor(s, 8, 16);
-            s += __shfl_xor(s, 4, 16);
-            s += __shfl_xor(s, 2, 16);
-            s += __shfl_xor(s, 1, 16);
+            s = row16_sum(s);
             ps[rb] = s;
             if (ab_raw == 0 && (tid & 15) == 0) {
                 a.psum[rg] = s;
@@ -347,10 +344,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 const float* qp = a.q_in + ((size_t)i * a.Bp + rg) * a.numA;
                 for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16)      // numA > 64 only
                     sq += qp[b2];
-                sq += __shfl_xor(sq, 8, 16);
-                sq += __shfl_xor(sq, 4, 16);
-                sq += __shfl_xor(sq, 2, 16);
-                sq += __shfl_xor(sq, 1, 16);
+                sq = row16_sum(sq);
                 rt -= sq;
             }
             gsum[0] = fmaf(rt, dt[i][0], gsum[0]);
@@ -389,10 +383,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             if (!vld[rb]) st = IS_FIRST ? hp[rb] : *(const f32x2*)(a.state + hoff);
             *(f32x2*)(a.state + hoff) = st;
             float s = st[0] + st[1];
-            s += __shfl_xor(s, 8, 16);
-            s += __shfl_xor(s, 4, 16);
-            s += __shfl_xor(s, 2, 16);
-            s += __shfl_xor(s, 1, 16);
+            s = row16_sum(s);
             if ((tid & 15) == 0)
                 a.rs_part[((size_t)((t + 1) & 1) * a.numA + ab) * a.Bp + rg] = s;
         } else {
@@ -402,10 +393,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             for (int i = 0; i < MAX_TAIL; ++i) {
                 if (i >= a.ntail) continue;
                 float sq = hn[0] * dtn[i][0] + hn[1] * dtn[i][1];
-                sq += __shfl_xor(sq, 8, 16);
-                sq += __shfl_xor(sq, 4, 16);
-                sq += __shfl_xor(sq, 2, 16);
-                sq += __shfl_xor(sq, 1, 16);
+                sq = row16_sum(sq);
                 if ((tid & 15) == 0) a.q_out[((size_t)i * a.Bp + rg) * a.numA + ab] = sq;
             }
         }

@@ -19,6 +19,22 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16i .. 16i+15), result in every lane, by four row
+// rotations on the VALU (v_add_f32 ... row_ror:8/4/2/1).  __shfl_xor(x, o, 16) compiles to
+// ds_bpermute_b32 -- an LDS round trip per step: eight of them in a row were ~0.2 us on the tail of
+// every cell_a launch.  Every lane adds the same operand pairs (only commuted), so all 16 results
+// are bit-identical.
+__device__ __forceinline__ float row16_sum(float v) {
+#define DRNMF_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(                 \
+        0, __builtin_bit_cast(int, (x)), 0x120 + (n), 0xf, 0xf, false))
+    v += DRNMF_ROR(v, 8);
+    v += DRNMF_ROR(v, 4);
+    v += DRNMF_ROR(v, 2);
+    v += DRNMF_ROR(v, 1);
+#undef DRNMF_ROR
+    return v;
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
