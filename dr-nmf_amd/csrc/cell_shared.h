@@ -38,7 +38,8 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
               int Np_, int nft_, int KS_, int nch_ks_, int Bp_) {   // 14 dwords: all preloaded
     const CellBArgs a{Dn_next, h_in, xp, rpart, nullptr, Bp_, Fp_, Np_, nft_, KS_,
                       __builtin_ctz((unsigned)KS_), nch_ks_};
-    __shared__ __attribute__((aligned(16))) float red[NW * RB * 16 * 16];
+    __shared__ __attribute__((aligned(16))) float red[NW * RB * 16 * 17];   // row stride 17: the
+    // epilogue threads read (row, bin 4s+q) with row fastest -- stride 16 would be an 8-way bank conflict
     // 2-D grid (x = 8 * row tile group + XCD slot, y = octet of (bin tile, atom range)): see
     // cell_a_kernel.  KS is a power of two.  Padded blocks redo the last tile with the store
     // predicated off.
@@ -142,14 +143,14 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-            red[((w * RB + rb) * 16 + 4 * q + v) * 16 + j] = acc[rb][0][v] + acc[rb][1][v];
+            red[((w * RB + rb) * 16 + 4 * q + v) * 17 + j] = acc[rb][0][v] + acc[rb][1][v];
     __syncthreads();
     if (tid >= 256) return;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         float s = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) s += red[((ww * RB + rb) * 16 + erow) * 16 + ecol];
+        for (int ww = 0; ww < NW; ++ww) s += red[((ww * RB + rb) * 16 + erow) * 17 + ecol];
         if (live)
             a.rpart[(size_t)ks * a.Bp * Fp + eoff + rb * estep] = (a.xp != nullptr) ? xv[rb] - s : s;
     }
