@@ -81,7 +81,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
         else bv[g] = *(const f32x4*)(brow + 256 * c);
     };
     // software pipeline: loads run PF chunks ahead of the MFMAs (see cell_a_kernel)
-    constexpr int PF0 = RB > 1 ? 3 : 6;
+    constexpr int PF0 = RB > 1 ? 3 : 6;   // (8 = every chunk of the C2 shape up front: no gain)
     constexpr int PF = GB < PF0 ? GB : PF0;
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
