@@ -409,22 +409,38 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const ColRedArgs a) {
     }
     float sb = 0.f, sg = 0.f;
     int b = (int)(r0 / a.T), t = (int)(r0 % a.T) - 1;
-    for (int64_t bt = r0; bt < r1; ++bt) {
-        if (++t == a.T) { t = 0; ++b; }
-        const float dz = a.dz_all[bt * KN + (size_t)a.k * a.N + n];
-        if (dz == 0.f) continue;
-        const float ps = a.psum_all[(size_t)t * a.Bp + b];
-        const float hk = a.hall[bt * KN + (size_t)a.k * a.N + n];
-        float base;
-        if (a.k == 0) {
-            const float p = a.seen[(size_t)t * a.Bp + b]
-                                ? a.hall[(bt - 1) * KN + (size_t)(a.K - 1) * a.N + n] : h0v;
-            base = a.u0d * p + a.u0o * (ps - p) + bk;
-        } else {
-            base = a.hall[bt * KN + (size_t)(a.k - 1) * a.N + n] + bk + a.uko * ps;
+    // dz is sparse (it inherits the zeros of h): its loads decide everything else, so eight of
+    // them are in flight at a time (one dependent load per row made this kernel latency-bound:
+    // 1.7 ms per layer at the C2 shape)
+    constexpr int U = 8;
+    const float* dzp = a.dz_all + (size_t)a.k * a.N + n;
+    for (int64_t bt0 = r0; bt0 < r1; bt0 += U) {
+        float dzv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t bt = bt0 + u < r1 ? bt0 + u : r1 - 1;
+            dzv[u] = dzp[bt * KN];
         }
-        sb += dz;
-        sg = fmaf(dz, hk - base, sg);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t bt = bt0 + u;
+            if (bt >= r1) break;
+            if (++t == a.T) { t = 0; ++b; }
+            const float dz = dzv[u];
+            if (dz == 0.f) continue;
+            const float ps = a.psum_all[(size_t)t * a.Bp + b];
+            const float hk = a.hall[bt * KN + (size_t)a.k * a.N + n];
+            float base;
+            if (a.k == 0) {
+                const float p = a.seen[(size_t)t * a.Bp + b]
+                                    ? a.hall[(bt - 1) * KN + (size_t)(a.K - 1) * a.N + n] : h0v;
+                base = a.u0d * p + a.u0o * (ps - p) + bk;
+            } else {
+                base = a.hall[bt * KN + (size_t)(a.k - 1) * a.N + n] + bk + a.uko * ps;
+            }
+            sb += dz;
+            sg = fmaf(dz, hk - base, sg);
+        }
     }
     a.part[((size_t)sp * 2 + 0) * a.Np + n] = sb;
     a.part[((size_t)sp * 2 + 1) * a.Np + n] = sg;
