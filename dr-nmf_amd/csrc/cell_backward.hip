@@ -19,7 +19,22 @@
 
 namespace {
 
-constexpr int TN_SPLITS = 8;
+constexpr int TN_SPLITS = 16;   // upper bound (partial buffers); the count per shape: tn_splits()
+
+// Split-K count of the time-batched weight-gradient GEMMs: tiles x splits workgroups run in rounds
+// of 512 (2 per CU); pick the count that minimises rounds / splits (8 splits at the C2 shape made
+// 640 workgroups = 2 rounds, 6 make 480 = 1 round: 3.8 -> 2.6 ms per GEMM).
+static int tn_splits(int M, int N, int64_t Kdim) {
+    const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= TN_SPLITS; ++s) {
+        if (Kdim / s < 256) break;                      // keep the k loop of a split long
+        const double cost = (double)((tiles * s + 511) / 512) / s;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
+}
 constexpr int CR_SPLITS = 64;
 
 struct EdgeArgs {
@@ -735,15 +750,16 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         }
         // M = Fp: the padded bins of R / X / dR are zero, and whole 4-column groups keep the loads vectorised
         gemm_tn::Operands t1{Aop, dz_all + (size_t)k * N, BT, W.Fp, N, W.Fp, KN};
-        DRNMF_HIP(h, gemm_tn::launch(t1, EpiP1{P, ia_of(k), W.Np, pstr}, TN_SPLITS, stream));
+        const int nsplit = tn_splits(W.Fp, N, BT);
+        DRNMF_HIP(h, gemm_tn::launch(t1, EpiP1{P, ia_of(k), W.Np, pstr}, nsplit, stream));
         if (k >= 1) {
             gemm_tn::Operands t2{dR_all + (size_t)k * BT * W.Fp, hall + (size_t)(k - 1) * N, BT,
                                  W.Fp, N, W.Fp, KN};
-            DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, TN_SPLITS, stream));
+            DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, nsplit, stream));
         }
         const int kd = d->n_D == 1 ? 0 : k;
         hipLaunchKernelGGL(dlogd_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, P, Dn_rm,
-                           d_log_D + (size_t)kd * F * N, F, N, W.Np, TN_SPLITS, pstr,
+                           d_log_D + (size_t)kd * F * N, F, N, W.Np, nsplit, pstr,
                            (d->n_D == 1 && k > 0) ? 1 : 0);
         ColRedArgs ca;
         ca.hall = hall; ca.dz_all = dz_all; ca.bias = b_of(k); ca.psum_all = psum_all;
