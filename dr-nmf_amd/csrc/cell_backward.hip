@@ -55,6 +55,11 @@ struct EdgeArgs {
     int* c_wr;
     float u0d, u0o;
     int B, T, N, K, Bp, Np, numA;
+    // odd bins (kept out of the MFMA tiles as in the forward): d r_tail of layer K-1 is the sum over
+    // atom blocks of these partial dots of dG with the tail rows of the dictionary
+    const float* Dtail_top;  // [MAX_TAIL][Np] of layer K-1
+    float* dq_out;           // [MAX_TAIL][Bp][numA]
+    int ntail;
 };
 
 __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
@@ -115,6 +120,13 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
         const f32x2 ia = *(const f32x2*)(a.ia_last + n);
         f32x2 dG = {dz[0] * ia[0], dz[1] * ia[1]};
         *(f32x2*)(a.dGp_top + hoff) = dG;
+#pragma unroll
+        for (int i = 0; i < MAX_TAIL; ++i) {
+            if (i >= a.ntail) continue;
+            const f32x2 dt = *(const f32x2*)(a.Dtail_top + (size_t)i * a.Np + n);
+            const float sq = row16_sum(dG[0] * dt[0] + dG[1] * dt[1]);
+            if ((tid & 15) == 0) a.dq_out[((size_t)i * a.Bp + rg) * a.numA + ab] = sq;
+        }
         const int par = c & 1;
         float s = dz[0] + dz[1];
         s = row16_sum(s);
@@ -152,6 +164,13 @@ struct BwdAArgs {
     int* c_wr;
     float uko;
     int k, B, T, N, K, Bp, Fp, Np, numA, nchunks;
+    // odd bins: d r_tail = sum of dq_in over atom blocks; its rank-1 term is added to the MFMA
+    // result, it is copied into dR, and the partials of layer k-1 are produced for the next launch
+    const float* Dtail;      // [MAX_TAIL][Np] of layer k
+    const float* Dtail_prev; // of layer k-1
+    const float* dq_in;      // [MAX_TAIL][Bp][numA]
+    float* dq_out;
+    int ntail;
 };
 
 // (leading scalar arguments: preloaded into SGPRs, see cell_b_kernel)
@@ -213,6 +232,23 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     for (int e = 0; e < 2; ++e)
         if (rg < a.B && n + e < a.N)
             hprev[e] = a.hall[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n + e];
+
+    f32x2 dt[MAX_TAIL], dtp[MAX_TAIL];
+    float qv[MAX_TAIL][4];
+#pragma unroll
+    for (int i = 0; i < MAX_TAIL; ++i) {
+        dt[i] = *(const f32x2*)(a.Dtail + (size_t)i * Np + n);
+        dtp[i] = *(const f32x2*)(a.Dtail_prev + (size_t)i * Np + n);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qv[i][u] = 0.f;
+        if (i >= a.ntail) continue;
+        const float* qp = a.dq_in + ((size_t)i * a.Bp + rg) * a.numA;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b2 = (tid & 15) + 16 * u;
+            if (b2 < a.numA) qv[i][u] = qp[b2];
+        }
+    }
 
     // The summed d r_k of this row tile goes out row-major for the weight gradients.  Every
     // workgroup of the row tile holds all of it; chunk c is stored by atom block c mod numA so
@@ -276,6 +312,22 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     }
 
     if (!live) return;
+#pragma unroll
+    for (int i = 0; i < MAX_TAIL; ++i) {
+        if (i >= a.ntail) continue;
+        float sq = (qv[i][0] + qv[i][1]) + (qv[i][2] + qv[i][3]);
+        const float* qp = a.dq_in + ((size_t)i * a.Bp + rg) * a.numA;
+        for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16) sq += qp[b2];      // numA > 64 only
+        sq = row16_sum(sq);                                   // d r_tail[row] of layer k
+        gsum[0] = fmaf(sq, dt[i][0], gsum[0]);
+        gsum[1] = fmaf(sq, dt[i][1], gsum[1]);
+        if (ab_raw == 0 && (tid & 15) == 0 && rg < a.B)
+            a.dR[((size_t)rg * a.T + t) * Fp + 16 * a.nchunks + i] = sq;
+    }
+    if (a.ntail > 0 && ab_raw == 0 && rg < a.B) {             // the rest of the tail tile is padding
+        const int c0 = a.ntail + (tid & 15);
+        if (c0 < 16) a.dR[((size_t)rg * a.T + t) * Fp + 16 * a.nchunks + c0] = 0.f;
+    }
     f32x2 dzn;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -287,6 +339,14 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     *(f32x2*)(a.dzp_out + hoff) = dzn;
     f32x2 dG = {dzn[0] * ia[0], dzn[1] * ia[1]};
     *(f32x2*)(a.dGp_out + hoff) = dG;
+    if (a.k >= 2) {
+#pragma unroll
+        for (int i = 0; i < MAX_TAIL; ++i) {
+            if (i >= a.ntail) continue;
+            const float sq = row16_sum(dG[0] * dtp[i][0] + dG[1] * dtp[i][1]);
+            if ((tid & 15) == 0) a.dq_out[((size_t)i * a.Bp + rg) * a.numA + ab] = sq;
+        }
+    }
     float s = dzk[0] + dzk[1], s0 = dzn[0] + dzn[1];
     s = row16_sum(s);
     s0 = row16_sum(s0);
@@ -509,7 +569,7 @@ dlogh0_kernel(const float* __restrict__ dh0_part, const float* __restrict__ log_
 
 struct BwdWs {
     size_t off_dstate, off_gq, off_dzp0, off_dzp1, off_dGp0, off_dGp1, off_drpart, off_z0s, off_dps,
-        off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_P, off_cr, total;
+        off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_P, off_cr, off_dq, total;
 };
 BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     BwdWs L;
@@ -531,6 +591,7 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     L.off_dn = take((size_t)W.Fp * W.Np * 4);
     L.off_P = take((size_t)TN_SPLITS * W.Fp * W.Np * 4);
     L.off_cr = take((size_t)CR_SPLITS * 2 * W.Np * 4);
+    L.off_dq = take((size_t)2 * MAX_TAIL * W.Bp * W.numA * 4);
     L.total = o;
     return L;
 }
@@ -575,7 +636,8 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     char* bw = (char*)bwd_workspace;
     const int K = d->K, N = d->N, F = d->F, T = d->T, B = d->B;
     const int64_t BT = (int64_t)B * T;
-    const int numM = W.Bp / ROWS, nft = W.Fp / 16;
+    // MFMA bin tiles: the odd bins of a 2^k+1 STFT are handled by rank-1 terms, as in the forward
+    const int numM = W.Bp / ROWS, nft = W.nft_main;
     const float* Dp_base = (const float*)(pb + PL.off_dn);
     const size_t dstride = (size_t)PL.Fp * PL.Np;
     auto Dp_of = [&](int k) { return Dp_base + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
@@ -617,6 +679,14 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     ea.c_wr = (K == 1) ? nullptr : cA;
     ea.u0d = u0_diag; ea.u0o = u0_off;
     ea.B = B; ea.T = T; ea.N = N; ea.K = K; ea.Bp = W.Bp; ea.Np = W.Np; ea.numA = W.numA;
+    auto tail_of = [&](int k) {
+        return (const float*)(pb + PL.off_tail) + (d->n_D == 1 ? 0 : (size_t)k * MAX_TAIL * PL.Np);
+    };
+    float* dq = (float*)(bw + L.off_dq);
+    const size_t dqstride = (size_t)MAX_TAIL * W.Bp * W.numA;
+    ea.Dtail_top = tail_of(K - 1);
+    ea.dq_out = dq + (size_t)((K - 1) & 1) * dqstride;   // partials of layer k live in buffer k & 1
+    ea.ntail = W.ntail;
 
     auto make_b = [&](int k) {
         CellBArgs b;
@@ -646,6 +716,11 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         a.uko = uk_off;
         a.k = k; a.B = B; a.T = T; a.N = N; a.K = K; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
         a.numA = W.numA; a.nchunks = nft;
+        a.Dtail = tail_of(k);
+        a.Dtail_prev = tail_of(k - 1);
+        a.dq_in = dq + (size_t)(k & 1) * dqstride;
+        a.dq_out = dq + (size_t)((k - 1) & 1) * dqstride;
+        a.ntail = W.ntail;
         return a;
     };
 

@@ -71,6 +71,7 @@ def _autograd(model, P, wmask, K, square, snmf_cost_l1_weight=None):
          trainable=("log_D", "log_alph", "log_lam1")),
     dict(B=3, T=6, F=21, r=6, K=3, untied=("log_D",), masked_head=True),
     dict(B=17, T=3, F=257, r=20, K=2, untied=("log_D", "log_alph")),
+    dict(B=3, T=4, F=34, r=6, K=3, untied=("log_D", "log_alph")),          # two odd bins
     dict(B=250, T=2, F=513, r=1000, K=2, untied=("log_D", "log_alph")),   # row-blocked kernels
 ])
 def test_gradients_match_autograd(dev, cfg):
