@@ -202,8 +202,8 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     const int clast = a.nchunks - 1;
     f32x4 av[G][KS];
     f32x4 bv[G][2];
-    auto load_chunk = [&](int base, int g) {
-        int c = w + 4 * (base + g);
+    auto load_chunk = [&](int i, int g) {      // chunk i of this wave -> slot g
+        int c = w + 4 * i;
         c = c > clast ? clast : c;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -211,11 +211,18 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
         bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
         bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
     };
-    // same software pipeline as the forward's cell_a_kernel: operand loads run PF chunks ahead
-    // of the MFMAs
-    constexpr int PF = G < 3 ? G : 3;
+    // same software pipeline as the forward's cell_a_kernel: G rotating operand slots, loads PF =
+    // G-1 chunks ahead of the MFMAs, clamped (never-loaded slots zeroed), last group peeled when
+    // every wave owns whole groups
+    constexpr int PF = G - 1;
 #pragma unroll
-    for (int g = 0; g < PF; ++g) load_chunk(0, g);
+    for (int g = 0; g < G; ++g) {
+        bv[g][0] = bv[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) av[g][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int g = 0; g < PF; ++g) load_chunk(g, g);
     __builtin_amdgcn_sched_barrier(0);   // struct-dependent code stays behind the first operand loads
 
     const int cnt = *a.c_rd;
@@ -268,14 +275,21 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
             acc1 = mfma16(r4[s], bv[g][s >> 1][(s & 1) * 2 + 1], acc1);
         }
     };
-    for (int base = 0; base < per_wave; base += G) {
-        if (base > 0) {
-#pragma unroll
-            for (int g = 0; g < PF; ++g) load_chunk(base, g);
-        }
+    const bool exact = (a.nchunks % (4 * G)) == 0;
+    int base = 0;
+    for (; base + (exact ? G : 0) < per_wave; base += G) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (g + PF < G) load_chunk(base, g + PF);
+            load_chunk(base + g + PF, (g + PF) % G);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_chunk(base, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (exact) {
+        load_chunk(base + PF, PF % G);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
             __builtin_amdgcn_sched_barrier(0);
             compute_chunk(base, g);
             __builtin_amdgcn_sched_barrier(0);
@@ -365,9 +379,8 @@ struct BwdAParams {
 
 template <int KS>
 void* bwd_a_func(int per_wave) {
-    if (per_wave <= 3) return (void*)&bwd_a_kernel<3, KS>;
-    if (per_wave <= 5 || KS >= 4) return (void*)&bwd_a_kernel<5, KS>;
-    return (void*)&bwd_a_kernel<9, KS>;
+    if (per_wave <= 2) return (void*)&bwd_a_kernel<2, KS>;
+    return (void*)&bwd_a_kernel<4, KS>;
 }
 void* pick_bwd_a(int nchunks, int KS) {
     const int per_wave = (nchunks + 3) / 4;
