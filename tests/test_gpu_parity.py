@@ -102,6 +102,7 @@ def test_prepare_params_matches_oracle(dev):
     dict(B=2, T=2, F=1025, r=4000, K=3, alph=1600.0),                # BASELINE config 5 width
     dict(B=33, T=2, F=514, r=17, K=2),                               # two tail bins, odd r, 3 row tiles
     dict(B=2, T=3, F=16, r=1, K=2),                                  # N = 2: a single atom pair
+    dict(B=1, T=1, F=5, r=3, K=2),                                   # fewer bins than one tile, one frame
     dict(B=130, T=2, F=513, r=1000, K=3, alph=400.0, ragged=True),   # 9 row tiles
     dict(B=250, T=3, F=513, r=1000, K=2, alph=400.0, ragged=True),   # inference slab (enhance.py:1189): 2 row blocks per workgroup
     dict(B=250, T=2, F=512, r=1000, K=2, alph=400.0, untied=()),     # 2 row blocks, no tail bin, tied
