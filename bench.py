@@ -104,6 +104,32 @@ def ista_bench(torch, dev, F, N, K, W, n=32768):
             "gemm_launch_us": sec / (2 * K) * 1e6}
 
 
+def mu_bench(torch, dev, F, N, W, n=32768, iters=20):
+    """SNMF inference by multiplicative updates with W fixed -- the classical baseline branch of
+    enhance.py:838-852 that replaces the Matlab process (200 iterations there) -- on n frames,
+    beta = 2.  Flops counted as the Matlab loop spends them: 6*F*N per frame per iteration."""
+    from drnmf_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    Wt = torch.from_numpy(W).to(dev)
+    Ht = (torch.rand((n, N), generator=g, device=dev) < 0.02) * \
+        torch.rand((n, N), generator=g, device=dev) * 5.0
+    V = Ht @ Wt.t() + 0.01 * torch.rand((n, F), generator=g, device=dev)
+    H = torch.rand((n, N), generator=g, device=dev)
+    ops.mu_forward(V, Wt, H, 5.0, 2, beta=2.0)            # warm-up
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.mu_forward(V, Wt, H, 5.0, iters, beta=2.0)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3
+    tf = n * 6.0 * F * N * iters / sec / 1e12
+    return {"frames": n, "iterations": iters, "frame_iterations_per_s": n * iters / sec,
+            "tflops_as_counted_by_the_reference_loop": tf,
+            "ms_per_iteration": sec / iters * 1e3}
+
+
 def train_bench(torch, dev, steps=3, shape=(32, 500, 257, 1000, 5), ragged=True):
     """Forward + BPTT + Adam per step on a synthetic batch.  Default shape = BASELINE configs[2],
     the shipped training configuration (downsample1: F=257, maxlen=500, batch 32, K=5, r=1000,
@@ -407,6 +433,7 @@ def main():
                  "whole_forward_frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS}
         if not a.no_ista:
             extra["ista_frame_parallel"] = ista_bench(torch, dev, F, N, K, W)
+            extra["mu_inference"] = mu_bench(torch, dev, F, N, W)
         if not a.no_slab and world == 1:
             extra["inference_slab_250"] = slab_bench(torch, dev, F, r, K, T)
         if not a.no_config5 and world == 1:

@@ -155,6 +155,49 @@ struct EpiMuUpdate {   // H <- H * dmh / max(dph + sparsity, flr): sparse_nmf_gp
     }
 };
 
+// beta == 2 inference with the odd bins kept out of the GEMM tiles (see ista_tail_kernel): the
+// rank-NT term sum_i lambda[row][Fm+i] * W[Fm+i][col] completes dph = lambda W.
+template <int NT>
+struct EpiMuUpdateTail {
+    float* H;
+    const float* DMH;      // [n][N]
+    int N;
+    float sparsity, flr;
+    const float* Lt;       // lambda + Fm (row stride ld)
+    const float* Wtt;      // Wt + Fm     (row stride ld)
+    int ld;
+    __device__ f32x2 pre(int64_t row, int col) const {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) t = fmaf(Lt[row * ld + i], Wtt[(int64_t)col * ld + i], t);
+        return f32x2{H[row * N + col] * DMH[row * N + col], t};
+    }
+    __device__ void operator()(int64_t row, int col, float acc, f32x2 pv) const {
+        H[row * N + col] = pv[0] / fmaxf(acc + pv[1] + sparsity, flr);
+    }
+};
+
+// lambda of the odd bins: max(H[row,:] . W[Fm+i,:], flr), one wave per row
+__global__ void __launch_bounds__(256)
+mu_tail_kernel(const float* __restrict__ W, const float* __restrict__ H, float* __restrict__ P1,
+               int64_t n, int N, int Fm, int nt, int ld, float flr) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (row >= n) return;
+    float s[2] = {0.f, 0.f};
+    const float* hrow = H + row * N;
+    for (int c = l; c < N; c += 64) {
+        const float hv = hrow[c];
+        s[0] = fmaf(hv, W[(size_t)Fm * N + c], s[0]);
+        if (nt > 1) s[1] = fmaf(hv, W[(size_t)(Fm + 1) * N + c], s[1]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s[0] += __shfl_xor(s[0], o, 64);
+        s[1] += __shfl_xor(s[1], o, 64);
+    }
+    if (l < nt) P1[row * ld + Fm + l] = fmaxf(s[l], flr);
+}
+
 // column norms of W and sums of the normalised columns: sparse_nmf_gpu.m:163-166
 __global__ void __launch_bounds__(256)
 mu_colnorm_kernel(const float* __restrict__ W, float* __restrict__ Wn, float* __restrict__ norm,
@@ -366,9 +409,18 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
         DRNMF_HIP(h, hipMemsetAsync(P1, 0, (size_t)n * Fp4 * 4, stream));
         DRNMF_HIP(h, hipMemsetAsync(P2, 0, (size_t)n * Fp4 * 4, stream));
     }
-    gemm::Operands gl{H, Wn, n, F, N, N, N};            // W H  (row layout: H . Wn^T)
+    // beta == 2: odd bins (F = 16 j + 1 | 2) stay out of the GEMM tiles, as in drnmf_ista_forward
+    const int nt = (beta == 2.f && F % 16 != 0 && F % 16 <= 2 && F > 16) ? F % 16 : 0;
+    const int Fm = F - nt;
+    gemm::Operands gl{H, Wn, n, Fm, N, N, N};           // W H  (row layout: H . Wn^T)
     auto launch_lambda = [&]() -> hipError_t {
-        if (beta == 2.f) return gemm::launch(gl, EpiLambda<2>{Vuse, P1, P2, nullptr, F, Fp4, beta, flr}, stream);
+        if (beta == 2.f) {
+            hipError_t e = gemm::launch(gl, EpiLambda<2>{Vuse, P1, P2, nullptr, F, Fp4, beta, flr}, stream);
+            if (e == hipSuccess && nt)
+                hipLaunchKernelGGL(mu_tail_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
+                                   stream, Wn, H, P1, n, N, Fm, nt, Fp4, flr);
+            return e;
+        }
         if (beta == 1.f) return gemm::launch(gl, EpiLambda<1>{Vuse, P1, P2, nullptr, F, Fp4, beta, flr}, stream);
         return gemm::launch(gl, EpiLambda<0>{Vuse, P1, P2, nullptr, F, Fp4, beta, flr}, stream);
     };
@@ -386,9 +438,15 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
             gemm::Operands gd{P2, Wt, n, N, Fp4, Fp4, Fp4};
             DRNMF_HIP(h, gemm::launch(gd, EpiStore{DMH, N}, stream));
         }
-        gemm::Operands gu{P1, Wt, n, N, Fp4, Fp4, Fp4};
+        gemm::Operands gu{P1, Wt, n, N, nt ? Fm : Fp4, Fp4, Fp4};
         if (beta == 1.f)
             DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<1>{H, DMH, colsum, N, sparsity, flr}, stream));
+        else if (nt == 1)
+            DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdateTail<1>{H, DMH, N, sparsity, flr, P1 + Fm,
+                                                             Wt + Fm, Fp4}, stream));
+        else if (nt == 2)
+            DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdateTail<2>{H, DMH, N, sparsity, flr, P1 + Fm,
+                                                             Wt + Fm, Fp4}, stream));
         else
             DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<2>{H, DMH, colsum, N, sparsity, flr}, stream));
         DRNMF_HIP(h, launch_lambda());                  // lambda = max(w*h, flr)  (:228)
