@@ -5,7 +5,9 @@
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
 repo snapshot.
 """
+import fcntl
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -28,37 +30,76 @@ def _deps():
         [os.path.join(os.path.dirname(HERE), "include", "drnmf.h"), os.path.abspath(__file__)]
 
 
+STAMP = LIB + ".srchash"
+
+
+def _src_hash():
+    """Content hash of everything the library is built from (mtimes do not survive the copy to the
+    GPU box in any particular order)."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in sorted(_deps()):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in _deps())
+    with open(STAMP) as f:
+        return f.read().strip() != _src_hash()
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
+    # one builder at a time: `bench.py --gpus N` starts N processes that all call build()
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():     # another process built it meanwhile
+                return LIB
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if (not force and os.path.exists(obj) and
-                os.path.getmtime(obj) > max(os.path.getmtime(p) for p in _deps()
-                                            if not p.endswith(".hip") or p == src)):
-            continue
+        # per-object stamp: this source + every header + the flags
+        hh = hashlib.sha256(" ".join(FLAGS).encode())
+        for p in sorted(q for q in _deps() if not q.endswith(".hip") or q == src):
+            with open(p, "rb") as f:
+                hh.update(f.read())
+        want = hh.hexdigest()
+        stamp = obj + ".srchash"
+        if not force and os.path.exists(obj) and os.path.exists(stamp):
+            with open(stamp) as f:
+                if f.read().strip() == want:
+                    continue
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+        procs.append((src, stamp, want, subprocess.Popen(cmd)))
+    for src, stamp, want, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)            # a process that already mapped the old file keeps it
+    with open(STAMP, "w") as f:
+        f.write(_src_hash() + "\n")
     return LIB
 
 
