@@ -19,8 +19,16 @@ class CellDesc(C.Structure):
                  "return_all_hidden", "operand_f16")]
 
 
+class DenseDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "T", "F", "N", "K", "connect_input", "activation", "return_all_hidden")]
+
+
+ACTIVATIONS = {"linear": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "softplus": 4, "hard_sigmoid": 5}
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _DP = C.POINTER(CellDesc)
+_DDP = C.POINTER(DenseDesc)
 
 # name -> (restype, argtypes); mirrors include/drnmf.h one to one
 SIGNATURES = {
@@ -37,6 +45,11 @@ SIGNATURES = {
                                            _vp, _vp, _sz, _vp]),
     "drnmf_cell_profile": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _sz,
                                   _vp, _i32, C.POINTER(C.c_float)]),
+    "drnmf_dense_params_bytes": (_sz, [_DDP]),
+    "drnmf_dense_prepare_params": (_i32, [_vp, _DDP, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "drnmf_dense_workspace_bytes": (_sz, [_DDP]),
+    "drnmf_dense_cell_forward": (_i32, [_vp, _DDP, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                        _vp]),
     "drnmf_padded_f": (_i32, [_i32]),
     "drnmf_head_forward": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp,
                                   _vp, _vp, _vp, _vp]),

@@ -1,0 +1,474 @@
+// General (dense-matrix) SimpleDeepRNN cell forward on gfx950.
+//
+// Reference semantics: SimpleDeepRNN.step (custom_layers.py:343-375) as written, for ANY per-layer
+// matrices -- the ones a caller's own maps_from_alt produce, directly trainable W/U/b/S weights
+// (custom_layers.py:234-287), or build_alt's maps once log_U1 / log_Uk have been trained away from
+// their rank-structured initialisation:
+//     h_k = act( p U_k + [k > 0] h_{k-1} S_{k-1} + [connect] x_t Wk_k + b_k ),   p = h_{K-1} of frame t-1
+// (the factored kernels of cell_forward.hip cover the build_alt form with untrained U only).
+// Masking follows K.rnn as in cell_forward.hip; `flag_connect_input_to_layers = False` drops the
+// input from EVERY layer, layer 0 included (custom_layers.py:366-368).
+//
+// One layer-step is ONE launch: the three products are a single contraction of the row block
+// [p | h_{k-1} | x_t] (16 rows x L, L = Np + Np + Fp) with the stacked matrix [U_k; S_{k-1}; Wk_k]
+// (L x N), which `drnmf_dense_prepare_params` stores once in the cell_a operand packing (common.h:
+// 512-float blocks of 16 contraction rows x 32 atoms, two 16-byte loads per lane).  Activations
+// (state, hidden ping-pong, packed input) are kept in the A-operand order (rp_pos) so that every
+// operand load is one contiguous 1 KB per wave.  Workgroup = 16 rows x 32 atoms, the contraction
+// split over 4 waves and reduced through LDS, as cell_a_kernel; 2*B*(2N+F)*N flops per launch.
+// K launches per frame, several frames per cached hipGraph.
+#include "cell_shared.h"
+
+namespace {
+
+struct DenseArgs {
+    const float* M;          // stacked matrix of this layer, cell_a packing: block (c, ab) of 512 floats
+    const float* bias;       // [Np]
+    const float* xp;         // [T][Bp][Fp] packed input (pack_input_kernel)
+    const float* h_in;       // [Bp][Np] packed h of layer k-1 (unused for layer 0)
+    float* h_out;            // [Bp][Np] packed h of this layer (unused for the last layer)
+    float* state;            // [2][Bp][Np] packed recurrent state, by frame parity
+    const unsigned char* valid;   // [T][Bp]
+    float* out;              // [B][T][out_width]
+    const int* t_rd;
+    int* t_wr;
+    int t_wr_add;
+    int B, T, N, Bp, Fp, Np, numA;
+    int nP, nH, nX;          // 16-wide chunks of the contraction per segment (nH = 0: layer 0)
+    int act;                 // DRNMF_ACT_*
+    int out_width, out_off;
+};
+
+__device__ __forceinline__ float activate(float v, int act) {
+    switch (act) {
+        case DRNMF_ACT_RELU: return fmaxf(v, 0.f);
+        case DRNMF_ACT_TANH: return tanhf(v);
+        case DRNMF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case DRNMF_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+        case DRNMF_ACT_HARD_SIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
+        default: return v;
+    }
+}
+
+// G operand slots per wave, prefetch distance G-1 (same rotation as cell_a_kernel); NW waves split
+// the contraction (the stacked matrices do not fit the Infinity Cache at the large shapes -- 36 MB
+// per layer at F=513, N=2000 -- so the operand stream comes from HBM and needs many loads in flight)
+template <int G, int NW, bool IS_LAST, bool WRITE_OUT>
+__global__ void __launch_bounds__(64 * NW) dense_step_kernel(const DenseArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[NW * ROWS * ATOMS];
+    const int mb = blockIdx.x >> 3;                           // grid layout: see cell_a_kernel
+    const int ab_raw = blockIdx.y * 8 + (blockIdx.x & 7);
+    const bool live = ab_raw < a.numA;
+    const int ab = live ? ab_raw : a.numA - 1;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63, j = l & 15, q = l >> 4;
+    const int Np = a.Np, Fp = a.Fp;
+
+    const int t = *a.t_rd;
+    if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
+
+    const size_t sstride = (size_t)a.Bp * Np;
+    const float* pseg = a.state + (size_t)(t & 1) * sstride + (size_t)mb * (Np / 16) * 256 + l * 4;
+    const float* hseg = a.h_in + (size_t)mb * (Np / 16) * 256 + l * 4;
+    const float* xseg = a.xp + (size_t)t * a.Bp * Fp + (size_t)mb * (Fp / 16) * 256 + l * 4;
+    const float* brow = a.M + (size_t)ab * 512 + l * 4;
+    const size_t bstep = (size_t)a.numA * 512;
+    const int nPH = a.nP + a.nH, nch = nPH + a.nX;
+    const int per_wave = (nch - w + NW - 1) / NW, clast = nch - 1;
+
+    f32x4 av[G], bv[G][2];
+    auto load_chunk = [&](int i, int g) {
+        int c = w + NW * i;
+        c = c > clast ? clast : c;
+        const float* ap = c < a.nP ? pseg + 256 * c
+                                   : (c < nPH ? hseg + 256 * (c - a.nP) : xseg + 256 * (c - nPH));
+        av[g] = *(const f32x4*)ap;
+        bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
+        bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
+    };
+    constexpr int PF = G - 1;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        av[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[g][0] = bv[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int g = 0; g < PF; ++g) load_chunk(g, g);
+
+    // epilogue operands, issued behind the first GEMM operands
+    const int erow = (tid & 255) >> 4, ec = (tid & 15) * 2;
+    const int n = ab * ATOMS + ec;
+    const int rg = mb * ROWS + erow;
+    const f32x2 bs = *(const f32x2*)(a.bias + n);
+    const bool vld = a.valid[(size_t)t * a.Bp + rg] != 0;
+    const size_t hblk = ((size_t)mb * (Np / 16) + (n >> 4)) * 256;
+    const int pos0 = rp_pos(erow, n & 15), pos1 = rp_pos(erow, (n & 15) + 1);
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < per_wave; base += G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            load_chunk(base + g + PF, (g + PF) % G);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool ok = base + g < per_wave;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float r = ok ? av[g][s] : 0.f;
+                acc0 = mfma16(r, bv[g][s >> 1][(s & 1) * 2], acc0);
+                acc1 = mfma16(r, bv[g][s >> 1][(s & 1) * 2 + 1], acc1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const f32x2 pr = {acc0[v], acc1[v]};
+        *(f32x2*)(red + (w * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
+    }
+    __syncthreads();
+    if (NW > 4 && tid >= 256) return;     // the elementwise epilogue is 256 threads wide
+
+    f32x2 gsum = *(const f32x2*)(red + erow * ATOMS + ec);
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+        const f32x2 p2 = *(const f32x2*)(red + (ww * ROWS + erow) * ATOMS + ec);
+        gsum[0] += p2[0];
+        gsum[1] += p2[1];
+    }
+    f32x2 hn;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) hn[e] = (n + e < a.N) ? activate(gsum[e] + bs[e], a.act) : 0.f;
+
+    if (WRITE_OUT && live && rg < a.B) {
+        // K.rnn masking: a masked step repeats the previous output (zeros before the first valid
+        // step) and keeps the state
+        float* orow = a.out + ((size_t)rg * a.T + t) * a.out_width + a.out_off;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (n + e < a.N) {
+                float o = hn[e];
+                if (!vld) o = (t > 0) ? orow[n + e - (ptrdiff_t)a.out_width] : 0.f;
+                orow[n + e] = o;
+            }
+        }
+    }
+    if (!live) return;
+    if (IS_LAST) {
+        const float* so = a.state + (size_t)(t & 1) * sstride + hblk;
+        float* sn = a.state + (size_t)((t + 1) & 1) * sstride + hblk;
+        sn[pos0] = vld ? hn[0] : so[pos0];
+        sn[pos1] = vld ? hn[1] : so[pos1];
+    } else {
+        a.h_out[hblk + pos0] = hn[0];
+        a.h_out[hblk + pos1] = hn[1];
+    }
+}
+
+// state[0] = h0 tiled over the rows (custom_layers.py:336-341) or the caller's initial state
+// (stateful mode, custom_layers.py:296-318), in the packed A-operand order; frame counters = 0.
+__global__ void __launch_bounds__(256)
+dense_init_state_kernel(const float* __restrict__ h0, const float* __restrict__ init,
+                        float* __restrict__ state, int* tptr, int B, int N, int Np, int Bp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { tptr[0] = 0; tptr[16] = 0; }
+    if (i >= (size_t)Bp * Np) return;
+    const int b = (int)(i / Np), n = (int)(i % Np);
+    float v = 0.f;
+    if (b < B && n < N) v = init ? init[(size_t)b * N + n] : h0[n];
+    state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + rp_pos(b & 15, n & 15)] = v;
+}
+
+__global__ void __launch_bounds__(256)
+dense_store_state_kernel(const float* __restrict__ state, float* __restrict__ out, int B, int N,
+                         int Np) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    const int b = (int)(i / N), n = (int)(i % N);
+    out[i] = state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + rp_pos(b & 15, n & 15)];
+}
+
+// Stacked matrix [U; S; W] of one layer -> cell_a operand packing.  Row i of the stack is
+// contraction index i: [0, Np) = p (U rows), then Np rows of h (S rows) when nS, then Fp rows of x
+// (W rows) when nW; padded rows / columns are zero.
+__global__ void __launch_bounds__(256)
+pack_dense_kernel(const float* __restrict__ U, const float* __restrict__ S,
+                  const float* __restrict__ W, float* __restrict__ M, int N, int F, int Np, int Fp,
+                  int L) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)L * Np) return;
+    const int i = (int)(idx / Np), n = (int)(idx % Np);
+    float v = 0.f;
+    if (n < N) {
+        if (i < Np) {
+            if (i < N) v = U[(size_t)i * N + n];
+        } else if (S && i < 2 * Np) {
+            if (i - Np < N) v = S[(size_t)(i - Np) * N + n];
+        } else if (W) {
+            const int f = i - (S ? 2 * Np : Np);
+            if (f < F) v = W[(size_t)f * N + n];
+        }
+    }
+    const int c = i >> 4, fi = i & 15, n32 = n & 31;
+    M[((size_t)c * (Np / 32) + (n >> 5)) * 512 + (fi >> 3) * 256 + ((fi & 3) * 16 + (n32 >> 1)) * 4 +
+      ((fi >> 2) & 1) * 2 + (n32 & 1)] = v;
+}
+
+__global__ void __launch_bounds__(256)
+pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int N, int Np, int K) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K * Np) return;
+    const int k = i / Np, n = i % Np;
+    out[i] = n < N ? b[(size_t)k * N + n] : 0.f;
+}
+
+struct DenseLayout {
+    int Bp, Fp, Np, numA, nX;
+    size_t L0, L1;           // stacked rows of layer 0 / of layers k > 0
+    size_t off_bias, params_total;
+    size_t off_xp, off_valid, off_h0, off_h1, off_state, off_t, ws_total;
+    size_t m_off(int k) const { return k == 0 ? 0 : (L0 + (size_t)(k - 1) * L1) * Np * 4; }
+};
+
+DenseLayout dense_layout(const drnmf_dense_desc_t* d) {
+    DenseLayout D;
+    D.Bp = pad_b(d->B);
+    D.Fp = pad_f(d->F);
+    D.Np = pad_n(d->N);
+    D.numA = D.Np / ATOMS;
+    D.nX = d->connect_input ? D.Fp / 16 : 0;
+    D.L0 = (size_t)D.Np + (d->connect_input ? D.Fp : 0);
+    D.L1 = D.L0 + D.Np;
+    D.off_bias = round_up_sz(D.m_off(d->K), 256);
+    D.params_total = D.off_bias + round_up_sz((size_t)d->K * D.Np * 4, 256);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += round_up_sz(bytes, 256); return at; };
+    D.off_xp = take((size_t)d->T * D.Bp * D.Fp * 4);
+    D.off_valid = take((size_t)d->T * D.Bp);
+    D.off_h0 = take((size_t)D.Bp * D.Np * 4);
+    D.off_h1 = take((size_t)D.Bp * D.Np * 4);
+    D.off_state = take((size_t)2 * D.Bp * D.Np * 4);
+    D.off_t = take(256);
+    D.ws_total = o;
+    return D;
+}
+
+int validate_dense_desc(drnmf_handle_t h, const drnmf_dense_desc_t* d) {
+    if (!d) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense desc is NULL");
+    if (d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0 || d->K <= 0)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "B,T,F,N,K must be positive (got %d,%d,%d,%d,%d)",
+                   d->B, d->T, d->F, d->N, d->K);
+    if (d->activation < DRNMF_ACT_LINEAR || d->activation > DRNMF_ACT_HARD_SIGMOID)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "unknown activation id %d", d->activation);
+    if ((int64_t)d->B * d->T * (int64_t)d->N * (d->return_all_hidden ? d->K : 1) >= (1ll << 40))
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "output tensor too large");
+    return DRNMF_OK;
+}
+
+template <int G, int NW>
+void* dense_func(bool last, bool write_out) {
+    if (last) return (void*)&dense_step_kernel<G, NW, true, true>;
+    return write_out ? (void*)&dense_step_kernel<G, NW, false, true>
+                     : (void*)&dense_step_kernel<G, NW, false, false>;
+}
+
+}  // namespace
+
+extern "C" size_t drnmf_dense_params_bytes(const drnmf_dense_desc_t* d) {
+    if (!d || d->F <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    return dense_layout(d).params_total;
+}
+
+extern "C" size_t drnmf_dense_workspace_bytes(const drnmf_dense_desc_t* d) {
+    if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    return dense_layout(d).ws_total;
+}
+
+extern "C" int32_t drnmf_dense_prepare_params(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                              const float* U, const float* S, const float* W,
+                                              const float* b, void* params, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    int rc = validate_dense_desc(h, d);
+    if (rc) return rc;
+    if (!U || !b || !params || (d->K > 1 && !S) || (d->connect_input && !W))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_prepare_params: NULL pointer argument");
+    if ((uintptr_t)params & 255)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "params must be 256-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const DenseLayout D = dense_layout(d);
+    char* base = (char*)params;
+    const size_t NN = (size_t)d->N * d->N, FN = (size_t)d->F * d->N;
+    for (int k = 0; k < d->K; ++k) {
+        const int L = (int)(k == 0 ? D.L0 : D.L1);
+        const size_t tot = (size_t)L * D.Np;
+        hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                           stream, U + (size_t)k * NN, k > 0 ? S + (size_t)(k - 1) * NN : nullptr,
+                           d->connect_input ? W + (size_t)k * FN : nullptr,
+                           (float*)(base + D.m_off(k)), d->N, d->F, D.Np, D.Fp, L);
+    }
+    hipLaunchKernelGGL(pack_bias_kernel, dim3((unsigned)((d->K * D.Np + 255) / 256)), dim3(256), 0,
+                       stream, b, (float*)(base + D.off_bias), d->N, D.Np, d->K);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                            const float* x, float mask_value, const void* params,
+                                            const float* h0, const float* initial_state,
+                                            float* final_state, float* h_out, void* workspace,
+                                            size_t workspace_bytes, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    int rc = validate_dense_desc(h, d);
+    if (rc) return rc;
+    if (!x || !params || !h_out || !workspace || (!h0 && !initial_state))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_forward: NULL pointer argument");
+    const DenseLayout D = dense_layout(d);
+    if (workspace_bytes < D.ws_total)
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "dense_cell_forward: workspace %zu < required %zu",
+                   workspace_bytes, D.ws_total);
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 255))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "workspace/params must be 256-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    const char* pb = (const char*)params;
+    float* xp = (float*)(ws + D.off_xp);
+    unsigned char* valid = (unsigned char*)(ws + D.off_valid);
+    float* hb[2] = {(float*)(ws + D.off_h0), (float*)(ws + D.off_h1)};
+    float* state = (float*)(ws + D.off_state);
+    int* tA = (int*)(ws + D.off_t);
+    int* tB = tA + 16;
+    const int K = d->K;
+
+    {
+        const size_t rows = (size_t)d->T * D.Bp;
+        hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                           stream, x, xp, valid, mask_value, d->B, d->T, d->F, D.Bp, D.Fp);
+        const size_t tot = (size_t)D.Bp * D.Np;
+        hipLaunchKernelGGL(dense_init_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256),
+                           0, stream, h0, initial_state, state, tA, d->B, d->N, D.Np, D.Bp);
+        DRNMF_HIP(h, hipGetLastError());
+    }
+
+    const dim3 grid(8u * (unsigned)(D.Bp / ROWS), (unsigned)(round_up(D.numA, 8) / 8));
+    auto make = [&](int k) {
+        DenseArgs a;
+        a.M = (const float*)(pb + D.m_off(k));
+        a.bias = (const float*)(pb + D.off_bias) + (size_t)k * D.Np;
+        a.xp = xp;
+        a.h_in = hb[(k + 1) & 1];
+        a.h_out = hb[k & 1];
+        a.state = state;
+        a.valid = valid;
+        a.out = h_out;
+        // frame counters as in cell_forward.hip: nobody reads a counter in the kernel that writes it
+        if (K == 1) { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
+        else if (k == 0) { a.t_rd = tB; a.t_wr = tA; a.t_wr_add = 0; }
+        else if (k == K - 1) { a.t_rd = tA; a.t_wr = tB; a.t_wr_add = 1; }
+        else { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
+        a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = D.Bp; a.Fp = D.Fp; a.Np = D.Np;
+        a.numA = D.numA;
+        a.nP = D.Np / 16;
+        a.nH = k > 0 ? D.Np / 16 : 0;
+        a.nX = D.nX;
+        a.act = d->activation;
+        a.out_width = d->return_all_hidden ? d->N * K : d->N;
+        a.out_off = d->return_all_hidden ? k * d->N : 0;
+        return a;
+    };
+    // waves per workgroup by contraction length (16-wide chunks).  Measured on MI355X, us per
+    // layer-step with 4 / 8 / 16 waves: F=513 N=2000 B=64: 17.6 / 17.2 / 19.3; F=257 N=2000 B=32:
+    // 14.9 / 13.8 / 16.8; F=257 N=200 B=32: 4.8 / 5.2 / 6.0
+    int nw = (D.Np / 16) * 2 + D.nX >= 128 ? 8 : 4;
+    if (const char* e = getenv("DRNMF_DENSE_NW")) {   // tuning aid
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) nw = v;
+    }
+    auto func = [&](int k) {
+        const bool last = k == K - 1, wo = d->return_all_hidden != 0;
+        return nw == 16 ? dense_func<4, 16>(last, wo)
+                        : (nw == 8 ? dense_func<4, 8>(last, wo) : dense_func<4, 4>(last, wo));
+    };
+
+    int fpg = 400 / K;
+    fpg = fpg < 1 ? 1 : (fpg > 64 ? 64 : fpg);
+    if (fpg > d->T) fpg = d->T;
+    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr;
+    if (!use_graph) {
+        for (int t = 0; t < d->T; ++t) {
+            for (int k = 0; k < K; ++k) {
+                DenseArgs a = make(k);
+                void* kp[1] = {&a};
+                DRNMF_HIP(h, hipLaunchKernel(func(k), grid, dim3(64 * nw), kp, 0, stream));
+            }
+            if (K == 1) hipLaunchKernelGGL(advance_frame_kernel, dim3(1), dim3(1), 0, stream, tA);
+        }
+        DRNMF_HIP(h, hipGetLastError());
+    } else {
+        auto get_graph = [&](int frames, hipGraphExec_t* out) -> int32_t {
+            std::vector<uint64_t> key = {
+                0xDE05Eull, (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N,
+                (uint64_t)d->K, (uint64_t)d->connect_input, (uint64_t)d->activation,
+                (uint64_t)d->return_all_hidden, (uint64_t)(uintptr_t)params,
+                (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)frames, (uint64_t)nw};
+            for (auto& g : h->graphs)
+                if (g.key == key) { *out = g.exec; return DRNMF_OK; }
+            if (h->graphs.size() >= 24) {
+                DRNMF_HIP(h, hipDeviceSynchronize());
+                (void)hipGraphExecDestroy(h->graphs.front().exec);
+                (void)hipGraphDestroy(h->graphs.front().graph);
+                h->graphs.erase(h->graphs.begin());
+            }
+            GraphEntry ge;
+            ge.key = key;
+            DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
+            hipGraphNode_t last = nullptr;
+            auto add = [&](void* f, dim3 g, unsigned block, void** kp) -> hipError_t {
+                hipKernelNodeParams p;
+                memset(&p, 0, sizeof(p));
+                p.func = f;
+                p.gridDim = g;
+                p.blockDim = dim3(block);
+                p.kernelParams = kp;
+                hipGraphNode_t node;
+                hipError_t e = hipGraphAddKernelNode(&node, ge.graph, last ? &last : nullptr,
+                                                     last ? 1 : 0, &p);
+                last = node;
+                return e;
+            };
+            for (int rep = 0; rep < frames; ++rep) {
+                for (int k = 0; k < K; ++k) {
+                    DenseArgs a = make(k);
+                    void* kp[1] = {&a};
+                    DRNMF_HIP(h, add(func(k), grid, 64 * nw, kp));
+                }
+                if (K == 1) {
+                    int* tp = tA;
+                    void* kt[1] = {&tp};
+                    DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, kt));
+                }
+            }
+            DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+            h->graphs.push_back(ge);
+            *out = ge.exec;
+            return DRNMF_OK;
+        };
+        hipGraphExec_t ex = nullptr;
+        rc = get_graph(fpg, &ex);
+        if (rc) return rc;
+        int t = 0;
+        for (; t + fpg <= d->T; t += fpg) DRNMF_HIP(h, hipGraphLaunch(ex, stream));
+        if (t < d->T) {
+            rc = get_graph(1, &ex);
+            if (rc) return rc;
+            for (; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(ex, stream));
+        }
+    }
+    if (final_state) {
+        const size_t tot = (size_t)d->B * d->N;
+        hipLaunchKernelGGL(dense_store_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256),
+                           0, stream, state + (size_t)(d->T & 1) * D.Bp * D.Np, final_state, d->B,
+                           d->N, D.Np);
+        DRNMF_HIP(h, hipGetLastError());
+    }
+    return DRNMF_OK;
+}

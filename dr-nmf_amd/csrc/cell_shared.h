@@ -165,6 +165,36 @@ struct CellBParams {
 
 __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
 
+// Masking + relayout: x [B][T][F] -> xp [T][Bp][Fp] (masked frames and all padding zero) and
+// valid [T][Bp].  One wave per (t, row).  [K2.0.4-memory: keras.layers.Masking]
+__global__ void __launch_bounds__(256)
+pack_input_kernel(const float* __restrict__ x, float* __restrict__ xp,
+                  unsigned char* __restrict__ valid, float mask_value, int B, int T, int F, int Bp,
+                  int Fp) {
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const size_t rowid = (size_t)blockIdx.x * 4 + wv;   // = t*Bp + b
+    if (rowid >= (size_t)T * Bp) return;
+    const int t = (int)(rowid / Bp), b = (int)(rowid % Bp);
+    const int nft = Fp / 16;
+    // tile-packed destination: Rp[t][b/16][f/16][rp_pos(b%16, f%16)]
+    float* dst = xp + (size_t)t * Bp * Fp + (size_t)(b >> 4) * nft * 256;
+    bool any = false;
+    if (b < B) {
+        const float* src = x + ((size_t)b * T + t) * F;
+        for (int f = l; f < F; f += 64) any |= (src[f] != mask_value);
+        any = __any(any);
+        for (int f = l; f < Fp; f += 64) {
+            dst[(size_t)(f >> 4) * 256 + rp_pos(b & 15, f & 15)] = (any && f < F) ? src[f] : 0.f;
+        }
+    } else {
+        for (int f = l; f < Fp; f += 64) {
+            dst[(size_t)(f >> 4) * 256 + rp_pos(b & 15, f & 15)] = 0.f;
+        }
+    }
+    if (l == 0) valid[rowid] = any ? 1 : 0;
+}
+
+
 struct Workspace {
     size_t off_xp, off_valid, off_seen, off_psum_all, off_rpart, off_h0, off_h1, off_state, off_rs,
         off_psum, off_t, total;

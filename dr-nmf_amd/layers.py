@@ -7,8 +7,10 @@ Same names, constructor arguments and protocol as the reference (custom_layers.p
                                   divide_A_by_AplusB, build_alt, build_unfolded_snmf)
 
 Weights live in torch tensors on the GPU (containers only); every forward goes through the
-hand-written HIP kernels in libdrnmf.so.  There is no CPU/oracle fallback: configurations the
-kernels do not cover raise NotImplementedError.
+hand-written HIP kernels in libdrnmf.so: the fused factored kernels for the configuration
+build_unfolded_snmf constructs, the general dense-matrix kernel (SimpleDeepRNN.step as written) for
+every other configuration of the layer.  There is no CPU/oracle fallback: what the kernels do not
+cover (training outside the build_alt configuration) raises NotImplementedError.
 """
 from collections import OrderedDict
 
@@ -288,22 +290,27 @@ class SimpleDeepRNN(_Layer):
         self.device = torch.device(device if device is not None else 'cuda')
         self._params_block = None
         self._ws = {}
-        # what the fused HIP path covers (everything the reference's enhance.py constructs)
-        problems = []
-        if not isinstance(self.maps_from_alt, AltMaps):
-            problems.append('maps_from_alt must come from build_alt (generic maps need the dense '
-                            'U/S/W path, not built)')
-        if activation != 'relu':
-            problems.append("activation must be 'relu' (enhance.py:260)")
-        if not flag_connect_input_to_layers or not flag_nonnegative:
-            problems.append('flag_connect_input_to_layers and flag_nonnegative must be True '
-                            '(enhance.py:265-266)')
+        # The fused factored kernels cover everything the reference's enhance.py constructs
+        # (build_alt maps, relu, both flags on).  Any other configuration of the layer -- caller-
+        # supplied maps, free W/U/b/S weights, another activation, flags off -- runs the general
+        # dense-matrix kernel (csrc/cell_dense.hip: SimpleDeepRNN.step as written), forward only.
+        if activation not in ops.ACTIVATIONS:
+            raise ValueError("activation must be one of %s (got %r)" %
+                             (sorted(ops.ACTIVATIONS), activation))
+        self._generic = (not isinstance(self.maps_from_alt, AltMaps) or activation != 'relu' or
+                         not flag_connect_input_to_layers or not flag_nonnegative)
+        self._dense_now = self._generic
+        if self._generic and operand_dtype != 'float32':
+            raise NotImplementedError("operand_dtype='float16' exists for the fused build_alt "
+                                      "configuration only")
+        # dropout is the identity outside the training phase (K.in_train_phase,
+        # custom_layers.py:377-395) and regularizers only add to the training loss: inference is
+        # unaffected, training with them is not implemented
+        self._train_blockers = []
         if dropout_W or dropout_U:
-            problems.append('dropout is never enabled by the reference and is not implemented')
+            self._train_blockers.append('dropout')
         if W_regularizer or U_regularizer or b_regularizer:
-            problems.append('regularizers are not implemented')
-        if problems:
-            raise NotImplementedError('SimpleDeepRNN (HIP path): ' + '; '.join(problems))
+            self._train_blockers.append('regularizers')
 
     # -- Keras protocol --------------------------------------------------------------------
     def compute_output_shape(self, input_shape):                          # custom_layers.py:175-185
@@ -316,48 +323,152 @@ class SimpleDeepRNN(_Layer):
 
     def build(self, input_shape):                                         # custom_layers.py:187-294
         self.input_dim = int(input_shape[2])
-        N = self.output_dim
-        # 'uniform' initializer = U(-0.05, 0.05) [K2.0.4-memory]; h0 = softplus(log_h0)
-        log_h0 = np.random.uniform(-0.05, 0.05, (N,)).astype(np.float32)
-        self.log_h0 = torch.from_numpy(log_h0).to(self.device)
+        N, F = self.output_dim, self.input_dim
+        if self.flag_nonnegative:
+            # 'uniform' initializer = U(-0.05, 0.05) [K2.0.4-memory]; h0 = softplus(log_h0)
+            log_h0 = np.random.uniform(-0.05, 0.05, (N,)).astype(np.float32)
+            self.log_h0 = torch.from_numpy(log_h0).to(self.device)
+        else:
+            self.h0 = torch.zeros(N, dtype=torch.float32, device=self.device)   # :208-211
         self._alt = OrderedDict()
         for key in self.alt_params:                                       # custom_layers.py:216-228
             v = np.asarray(self.alt_params[key], np.float32)
             self._alt[key] = torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
         self.trainable_keys = [k for k in self._alt if k in self.keys_trainable]
-        lab = self.maps_from_alt.labels_per_k
-        F = self.input_dim
-        d0 = self._alt[lab['log_D'][0]]
-        if tuple(d0.shape) != (F, N):
-            raise ValueError('log_D has shape %s, expected (input_dim=%d, output_dim=%d)' %
-                             (tuple(d0.shape), F, N))
+        # matrices without a map are free weights of the layer (custom_layers.py:241-281)
+        self._free = OrderedDict()
+        for k in range(self.K_layers):
+            if 'W' not in self.maps_from_alt:
+                self._free['W_%d' % k] = self._initializer(self.init, (F, N))
+            if 'U' not in self.maps_from_alt:
+                self._free['U_%d' % k] = self._initializer(self.inner_init, (N, N))
+            if 'b' not in self.maps_from_alt:
+                self._free['b_%d' % k] = self._initializer('zero', (N,))
+            if k > 0 and 'S' not in self.maps_from_alt:
+                self._free['S_%dto%d' % (k - 1, k)] = self._initializer(self.inner_init, (N, N))
+        if not self._generic:
+            lab = self.maps_from_alt.labels_per_k
+            d0 = self._alt[lab['log_D'][0]]
+            if tuple(d0.shape) != (F, N):
+                raise ValueError('log_D has shape %s, expected (input_dim=%d, output_dim=%d)' %
+                                 (tuple(d0.shape), F, N))
         self.built = True
         self._weights_changed()
 
+    def _initializer(self, name, shape):
+        """Keras initializers by name [K2.0.4-memory]: glorot_uniform U(+-sqrt(6/(fan_in+fan_out))),
+        orthogonal (QR of a Gaussian, gain 1), uniform U(+-0.05), zero, one, identity."""
+        name = getattr(name, '__name__', name)
+        if name in ('zero', 'zeros'):
+            v = np.zeros(shape, np.float32)
+        elif name in ('one', 'ones'):
+            v = np.ones(shape, np.float32)
+        elif name == 'identity':
+            v = np.eye(shape[0], shape[1], dtype=np.float32)
+        elif name == 'uniform':
+            v = np.random.uniform(-0.05, 0.05, shape)
+        elif name == 'glorot_uniform':
+            lim = np.sqrt(6.0 / (shape[0] + shape[-1]))
+            v = np.random.uniform(-lim, lim, shape)
+        elif name == 'orthogonal':
+            q, r = np.linalg.qr(np.random.normal(0.0, 1.0, (max(shape), max(shape))))
+            v = (q * np.sign(np.diag(r)))[:shape[0], :shape[1]]
+        else:
+            raise ValueError('unknown initializer %r' % (name,))
+        return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.device)
+
     @property
     def weights(self):
-        """Order: log_h0, then the alt params in build_alt's insertion order (the reference's order
-        is Python-2 dict order, custom_layers.py:203-228)."""
-        return [self.log_h0] + list(self._alt.values())
+        """Order: log_h0 (or h0), the alt params in build_alt's insertion order (the reference's
+        order is Python-2 dict order, custom_layers.py:203-228), then the free W/U/b/S weights
+        layer by layer (custom_layers.py:234-287)."""
+        first = self.log_h0 if self.flag_nonnegative else self.h0
+        return [first] + list(self._alt.values()) + list(self._free.values())
 
     @property
     def weight_names(self):
-        return ['%s_log_h0' % self.name] + ['%s_%s' % (self.name, k) for k in self._alt]
+        first = '%s_log_h0' if self.flag_nonnegative else '%s_h0'
+        return [first % self.name] + ['%s_%s' % (self.name, k) for k in self._alt] + \
+            ['%s_%s' % (self.name, k) for k in self._free]
 
     def _weights_changed(self):
         self._params_block_valid = False
+        self._dense_block_valid = False
+        if self._generic:
+            return
         a = {k: v.detach().cpu().numpy() for k, v in self._alt.items()
              if k in ('log_U1', 'log_Uk')}
         U1, Uk = np.exp(a['log_U1']), np.exp(a['log_Uk'])                 # enhance.py:163-167
         N = U1.shape[0]
         d = np.diag(U1)
         off = U1[~np.eye(N, dtype=bool)] if N > 1 else np.zeros((1,), np.float32)
-        if not (np.all(d == d[0]) and np.all(off == off[0]) and np.all(Uk == Uk.flat[0])):
-            raise NotImplementedError(
-                'log_U1/log_Uk no longer have the rank-structured form (diagonal + constant); a '
-                'trained dense U needs the dense-U kernel path, which is not built. No shipped '
-                'config trains them (params_unfolded_snmf_*.yaml:10).')
+        # the factored kernels rely on the rank-structured U of build_alt's initialisation
+        # (diagonal + constant); once log_U1/log_Uk are trained away from it the layer runs on the
+        # dense-matrix kernel.  No shipped config trains them (params_unfolded_snmf_*.yaml:10).
+        self._dense_now = not (np.all(d == d[0]) and np.all(off == off[0]) and
+                               np.all(Uk == Uk.flat[0]))
         self._u = (float(d[0]), float(off[0]) if N > 1 else 0.0, float(Uk.flat[0]))
+
+    # -- general dense-matrix path -------------------------------------------------------------
+    def dense_matrices(self):
+        """Uk, Sk, Wk, bk of SimpleDeepRNN.build (custom_layers.py:234-287) as float32 numpy
+        stacks: the maps are called on a dict of the alt params (host numpy arrays) exactly as the
+        reference calls its Theano lambdas; a missing map means the free weight."""
+        K = self.K_layers
+        a = OrderedDict((k, v.detach().cpu().numpy()) for k, v in self._alt.items())
+
+        def get(kind, k, free_name):
+            if kind in self.maps_from_alt:
+                m = self.maps_from_alt[kind]
+                m = m[k] if isinstance(m, (list, tuple)) else m
+                v = m(a)
+                if isinstance(v, torch.Tensor):
+                    v = v.detach().cpu().numpy()
+                return np.asarray(v, np.float32)
+            return self._free[free_name].detach().cpu().numpy()
+        N, F = self.output_dim, self.input_dim
+        U = np.stack([get('U', k, 'U_%d' % k).reshape(N, N) for k in range(K)])
+        b = np.stack([np.broadcast_to(get('b', k, 'b_%d' % k), (N,)) for k in range(K)])
+        S = np.stack([get('S', k - 1, 'S_%dto%d' % (k - 1, k)).reshape(N, N)
+                      for k in range(1, K)]) if K > 1 else None
+        W = np.stack([get('W', k, 'W_%d' % k).reshape(F, N) for k in range(K)]) \
+            if self.flag_connect_input_to_layers else None
+        return U, S, W, b
+
+    def initial_state_vector(self):
+        """h0_last of custom_layers.py:203-211 (softplus(log_h0), or the h0 weight)."""
+        if self.flag_nonnegative:
+            z = self.log_h0.detach().cpu().numpy().astype(np.float64)
+            return np.where(z > 20, z, np.log1p(np.exp(np.minimum(z, 20)))).astype(np.float32)
+        return self.h0.detach().cpu().numpy()
+
+    def _call_dense(self, x, mask_value, out):
+        B, T, F = x.shape
+        desc = ops.make_dense_desc(B, T, F, self.output_dim, self.K_layers,
+                                   self.flag_connect_input_to_layers, self.activation,
+                                   self.flag_return_all_hidden)
+        if not self._dense_block_valid:
+            U, S, W, b = self.dense_matrices()
+            dev = x.device
+            tt = lambda v: None if v is None else torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+            self._dense_block = ops.dense_prepare_params(desc, tt(U), tt(S), tt(W), tt(b),
+                                                         out=getattr(self, '_dense_block', None))
+            self._dense_h0 = torch.from_numpy(self.initial_state_vector()).to(dev)
+            self._dense_block_valid = True
+        key = ('dense', B, T)
+        if key not in self._ws:
+            self._ws.clear()
+            self._ws[key] = ops.dense_workspace(desc, x.device)
+        init = fin = None
+        if self.stateful:
+            if getattr(self, 'states', None) is None or self.states[0] is None or \
+                    tuple(self.states[0].shape) != (B, self.output_dim):
+                self.states = [torch.zeros((B, self.output_dim), dtype=torch.float32,
+                                           device=x.device)]
+            init = fin = self.states[0]
+        h = ops.dense_cell_forward(x, mask_value, self._dense_block, desc, self._dense_h0, out=out,
+                                   workspace=self._ws[key], initial_state=init, final_state=fin)
+        return h if self.return_sequences else h[:, -1]
 
     def get_config(self):                                                 # custom_layers.py:397-412
         return {'name': self.name, 'output_dim': self.output_dim, 'init': self.init,
@@ -416,6 +527,8 @@ class SimpleDeepRNN(_Layer):
         B, T, F = x.shape
         if F != self.input_dim:
             raise ValueError('input has %d features, layer was built for %d' % (F, self.input_dim))
+        if self._dense_now:
+            return self._call_dense(x, mask_value, out)
         desc = self.prepare(B, T)
         key = (B, T)
         if key not in self._ws:
@@ -444,6 +557,12 @@ class SimpleDeepRNN(_Layer):
         if self.operand_dtype != 'float32':
             raise NotImplementedError("training runs on fp32 operands (operand_dtype='float16' is "
                                       "an inference mode)")
+        if self._dense_now or self._train_blockers:
+            raise NotImplementedError(
+                'BPTT exists for the fused build_alt configuration (relu, rank-structured U, no '
+                'dropout/regularizers); this layer %s' %
+                ('uses ' + ', '.join(self._train_blockers) if self._train_blockers
+                 else 'runs on the forward-only dense-matrix kernel'))
         if not self.built:
             self.build(tuple(x.shape))
         B, T, F = x.shape
@@ -628,6 +747,17 @@ class UnfoldedSNMFModel(object):
         self.opt = dict(lr=float(lr), clipnorm=float(clipnorm), decay=float(decay),
                         b1=float(beta_1), b2=float(beta_2), eps=float(epsilon), iterations=0)
         cell = self.cell
+        if cell._generic:
+            raise NotImplementedError('training exists for the build_alt configuration of the cell '
+                                      '(enhance.py:257-266); this one runs on the forward-only '
+                                      'dense-matrix kernel')
+        covered = set(w for w, _, _ in cell.grad_slices())
+        missing = [k for k in cell._alt if k in cell.keys_trainable and k not in covered]
+        if missing:
+            # (the reference would train them; leaving their gradient at zero would be silent)
+            raise NotImplementedError('no gradient is implemented for %s: the BPTT kernels cover '
+                                      'log_D, log_alph, log_lam1 and log_h0 (the shipped '
+                                      'params_trainable is [log_D, log_alph])' % missing)
         self._train_items = [('log_h0', cell.log_h0)]
         self._train_items += [(k, cell._alt[k]) for k in cell._alt if k in cell.keys_trainable]
         self._train_items += [('kernel_clean', self.clean.kernel), ('kernel_noise', self.noise.kernel)]

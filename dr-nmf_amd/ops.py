@@ -8,6 +8,8 @@ import torch
 
 from . import _capi
 
+ACTIVATIONS = _capi.ACTIVATIONS
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -117,6 +119,82 @@ def cell_forward(x, mask_value, params, desc, log_h0, u, out=None, workspace=Non
                               _capi.ptr(log_h0), float(u[0]), float(u[1]), float(u[2]),
                               _capi.ptr(out), _capi.ptr(workspace), workspace.numel(), _stream())
     _capi.check(rc, h, "drnmf_cell_forward")
+    return out
+
+
+def make_dense_desc(B, T, F, N, K, connect_input=True, activation="relu",
+                    return_all_hidden=False):
+    if activation not in _capi.ACTIVATIONS:
+        raise ValueError("activation %r is not one of %s" % (activation,
+                                                             sorted(_capi.ACTIVATIONS)))
+    return _capi.DenseDesc(int(B), int(T), int(F), int(N), int(K), int(bool(connect_input)),
+                           _capi.ACTIVATIONS[activation], int(bool(return_all_hidden)))
+
+
+def dense_prepare_params(desc, U, S, W, b, out=None):
+    """U [K,N,N], S [K-1,N,N] (None when K == 1), W [K,F,N] (None without the input connection),
+    b [K,N] -- the reference's Uk/Sk/Wk/bk lists stacked -> prepared block (uint8)."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(U))
+    K, N, F = desc.K, desc.N, desc.F
+    U, b = _f32c(U, "U"), _f32c(b, "b")
+    if tuple(U.shape) != (K, N, N) or tuple(b.shape) != (K, N):
+        raise ValueError("U/b must have shapes (K,N,N)/(K,N) = (%d,%d,%d)/(%d,%d)" % (K, N, N, K, N))
+    if K > 1:
+        S = _f32c(S, "S")
+        if tuple(S.shape) != (K - 1, N, N):
+            raise ValueError("S must have shape (K-1,N,N)")
+    else:
+        S = None
+    if desc.connect_input:
+        W = _f32c(W, "W")
+        if tuple(W.shape) != (K, F, N):
+            raise ValueError("W must have shape (K,F,N) = (%d,%d,%d)" % (K, F, N))
+    else:
+        W = None
+    nbytes = L.drnmf_dense_params_bytes(C.byref(desc))
+    if out is None or out.numel() < nbytes:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=U.device)
+    rc = L.drnmf_dense_prepare_params(h, C.byref(desc), _capi.ptr(U), _capi.ptr(S), _capi.ptr(W),
+                                      _capi.ptr(b), _capi.ptr(out), _stream())
+    _capi.check(rc, h, "drnmf_dense_prepare_params")
+    return out
+
+
+def dense_workspace(desc, device):
+    nbytes = _capi.lib().drnmf_dense_workspace_bytes(C.byref(desc))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def dense_cell_forward(x, mask_value, params, desc, h0, out=None, workspace=None,
+                       initial_state=None, final_state=None):
+    """General SimpleDeepRNN.step on dense per-layer matrices: x [B,T,F] -> h [B,T,N] (or
+    [B,T,K*N]).  h0 [N] is the initial state itself."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(x))
+    x, h0 = _f32c(x, "x"), _f32c(h0, "h0")
+    if tuple(x.shape) != (desc.B, desc.T, desc.F):
+        raise ValueError("x has shape %s, descriptor says (%d,%d,%d)" %
+                         (tuple(x.shape), desc.B, desc.T, desc.F))
+    if h0.numel() != desc.N:
+        raise ValueError("h0 must have N=%d elements" % desc.N)
+    width = desc.N * (desc.K if desc.return_all_hidden else 1)
+    if out is None:
+        out = torch.empty((desc.B, desc.T, width), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (desc.B, desc.T, width) or not out.is_contiguous():
+        raise ValueError("out must be a contiguous (B,T,%d) float32 tensor" % width)
+    if workspace is None:
+        workspace = dense_workspace(desc, x.device)
+    for st in (initial_state, final_state):
+        if st is not None and (tuple(st.shape) != (desc.B, desc.N) or st.dtype != torch.float32
+                               or not st.is_contiguous()):
+            raise ValueError("states must be contiguous float32 (B,N) tensors")
+    mv = float("nan") if mask_value is None else float(mask_value)
+    rc = L.drnmf_dense_cell_forward(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
+                                    _capi.ptr(h0), _capi.ptr(initial_state),
+                                    _capi.ptr(final_state), _capi.ptr(out), _capi.ptr(workspace),
+                                    workspace.numel(), _stream())
+    _capi.check(rc, h, "drnmf_dense_cell_forward")
     return out
 
 

@@ -117,6 +117,44 @@ int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t* d, const f
                            void* workspace, size_t workspace_bytes, void* stream, int32_t frames,
                            float* out_us_host);
 
+/* ---- general (dense-matrix) cell: SimpleDeepRNN.step exactly as written (custom_layers.py:
+ * 343-375) for ANY per-layer matrices -- a caller's own maps_from_alt, directly trainable
+ * W/U/b/S weights (custom_layers.py:234-287), activations other than relu, or build_alt's maps
+ * once log_U1/log_Uk have been trained away from the rank-structured form that
+ * drnmf_cell_forward exploits:
+ *     h_k = act(p U_k + [k>0] h_{k-1} S_{k-1} + [connect_input] x_t Wk_k + b_k)
+ * Forward only.  One launch per layer-step contracts [p | h_{k-1} | x_t] with the stacked
+ * [U_k; S_{k-1}; Wk_k] (2*B*(2N+F)*N flops; the factored cell needs 4*B*F*N). */
+enum {
+    DRNMF_ACT_LINEAR = 0,
+    DRNMF_ACT_RELU = 1,
+    DRNMF_ACT_TANH = 2,
+    DRNMF_ACT_SIGMOID = 3,
+    DRNMF_ACT_SOFTPLUS = 4,
+    DRNMF_ACT_HARD_SIGMOID = 5 /* clip(0.2 x + 0.5, 0, 1) [K2.0.4-memory] */
+};
+typedef struct drnmf_dense_desc {
+    int32_t B, T, F, N, K;     /* as drnmf_cell_desc_t                                          */
+    int32_t connect_input;     /* flag_connect_input_to_layers; 0 drops x from EVERY layer,
+                                * layer 0 included (custom_layers.py:366-368)                   */
+    int32_t activation;        /* DRNMF_ACT_*                                                   */
+    int32_t return_all_hidden; /* flag_return_all_hidden                                        */
+} drnmf_dense_desc_t;
+/*   U [K][N][N], S [K-1][N][N] (NULL when K == 1), W [K][F][N] (NULL without connect_input),
+ *   b [K][N]: the matrices Uk/Sk/Wk/bk of SimpleDeepRNN.build in the reference's orientation
+ *   (row vector times matrix) -> `params` (drnmf_dense_params_bytes, 256-byte aligned).
+ *   h0 [N]: the initial state itself (softplus(log_h0) or the `h0` weight,
+ *   custom_layers.py:203-211); initial_state/final_state [B][N]: stateful mode, NULL otherwise. */
+size_t drnmf_dense_params_bytes(const drnmf_dense_desc_t* d);
+int32_t drnmf_dense_prepare_params(drnmf_handle_t h, const drnmf_dense_desc_t* d, const float* U,
+                                   const float* S, const float* W, const float* b, void* params,
+                                   void* stream);
+size_t drnmf_dense_workspace_bytes(const drnmf_dense_desc_t* d);
+int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_desc_t* d, const float* x,
+                                 float mask_value, const void* params, const float* h0,
+                                 const float* initial_state, float* final_state, float* h_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- mask head: replaces the H_clean/H_noise slices, TimeDistributed(DenseNonNegW) x2
  * (custom_layers.py:23-29; enhance.py:277-292), the optional 'square' transform
  * (enhance.py:294-300) and DivideAbyAplusB (custom_layers.py:41-45).

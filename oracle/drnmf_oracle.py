@@ -132,21 +132,39 @@ def masking(x, mask_value):
     return x * valid[..., None].astype(x.dtype), valid
 
 
+ACTIVATIONS = {
+    'linear': lambda v: v,
+    'relu': lambda v: np.maximum(v, 0),
+    'tanh': np.tanh,
+    'sigmoid': lambda v: 1.0 / (1.0 + np.exp(-v)),
+    'softplus': lambda v: np.where(v > 20, v, np.log1p(np.exp(np.minimum(v, 20)))),
+    'hard_sigmoid': lambda v: np.clip(0.2 * v + 0.5, 0.0, 1.0),     # [K2.0.4-memory]
+}
+
+
 def cell_forward_dense(x, Wk, Uk, bk, Sk, log_h0, mask_value=-1.0, return_all_hidden=False,
-                       connect_input=True, dtype=np.float64):
+                       connect_input=True, dtype=np.float64, activation='relu', h0=None,
+                       initial_state=None, return_state=False):
     """The reference's op graph: per frame, K layers of relu(p U_k + h^(k-1) S_k + x Wk_k + b_k)
     (custom_layers.py:361-369), scanned over time with Keras' masked-RNN rule
     [K2.0.4-memory: theano_backend.rnn] -- a masked step repeats the previous OUTPUT (zeros before
     the first valid step) and keeps the previous STATE.  Initial state = softplus(log_h0) tiled
-    (custom_layers.py:203-206, 336-341).  Returns h:(B,T,N) (or (B,T,K*N) if return_all_hidden)."""
+    (custom_layers.py:203-206, 336-341).  Returns h:(B,T,N) (or (B,T,K*N) if return_all_hidden).
+    General form of the step (custom_layers.py:343-375): `activation` by Keras name; h0 = the
+    initial state itself when flag_nonnegative is off (the `h0` weight, custom_layers.py:208-211);
+    connect_input=False drops x from every layer; initial_state (B,N) = stateful mode."""
     x = np.asarray(x, dtype=dtype)
     B, T, F = x.shape
-    K = len(Wk)
-    N = Wk[0].shape[1]
+    K = len(Uk)
+    N = Uk[0].shape[1]
+    act = ACTIVATIONS[activation]
     xm, valid = masking(x, dtype(mask_value))
-    h0 = softplus(np.asarray(log_h0, dtype=dtype))
+    h0 = softplus(np.asarray(log_h0, dtype=dtype)) if h0 is None else np.asarray(h0, dtype=dtype)
     width = K * N if return_all_hidden else N
     state = np.tile((np.tile(h0, K) if return_all_hidden else h0)[None, :], (B, 1))
+    if initial_state is not None:
+        state = np.zeros((B, width), dtype=dtype)
+        state[:, -N:] = np.asarray(initial_state, dtype=dtype)
     out_prev = np.zeros((B, width), dtype=dtype)
     hs = np.empty((B, T, width), dtype=dtype)
     for t in range(T):
@@ -158,12 +176,14 @@ def cell_forward_dense(x, Wk, Uk, bk, Sk, log_h0, mask_value=-1.0, return_all_hi
                 pre = pre + hidden[k - 1] @ Sk[k - 1]
             if connect_input:
                 pre = pre + xm[:, t] @ Wk[k]
-            hidden.append(relu(pre + bk[k]))
+            hidden.append(act(pre + bk[k]))
         out = np.concatenate(hidden, axis=1) if return_all_hidden else hidden[-1]
         v = valid[:, t][:, None]
         out_prev = np.where(v, out, out_prev)
         state = np.where(v, out, state)
         hs[:, t] = out_prev
+    if return_state:
+        return hs, state[:, -N:]
     return hs
 
 

@@ -1,0 +1,201 @@
+"""Parity of the general dense-matrix cell (csrc/cell_dense.hip: SimpleDeepRNN.step as written,
+custom_layers.py:343-375) against the CPU oracle's restatement of the same op graph.
+
+Tolerance: max|dh| / max|h| <= 1e-4 (fp32 kernel vs fp64 oracle), as for the factored cell.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import drnmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+H_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (run with -m 'not gpu' on CPU boxes)")
+    from drnmf_amd import _capi
+    _capi.handle(0)
+    return torch.device("cuda:0")
+
+
+def _check(h, ref):
+    scale = max(np.max(np.abs(ref)), 1e-30)
+    err = np.max(np.abs(h - ref)) / scale
+    assert err <= H_TOL, "max|dh|/max|h| = %.3e" % err
+
+
+def _random_mats(rng, K, N, F, scale=0.6):
+    U = (rng.standard_normal((K, N, N)) * scale / np.sqrt(N)).astype(np.float32)
+    S = (rng.standard_normal((max(K - 1, 0), N, N)) * scale / np.sqrt(N)).astype(np.float32)
+    W = (rng.standard_normal((K, F, N)) * scale / np.sqrt(F)).astype(np.float32)
+    b = (0.1 * rng.standard_normal((K, N))).astype(np.float32)
+    return U, S, W, b
+
+
+def _run(dev, X, U, S, W, b, h0, activation="relu", connect=True, all_hidden=False,
+         mask_value=-1.0, initial_state=None, want_state=False):
+    from drnmf_amd import ops
+    B, T, F = X.shape
+    K, N = U.shape[0], U.shape[1]
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    desc = ops.make_dense_desc(B, T, F, N, K, connect, activation, all_hidden)
+    params = ops.dense_prepare_params(desc, t(U), t(S) if K > 1 else None,
+                                      t(W) if connect else None, t(b))
+    fin = torch.empty((B, N), dtype=torch.float32, device=dev) if want_state else None
+    h = ops.dense_cell_forward(t(X), mask_value, params, desc, t(h0), initial_state=t(initial_state),
+                               final_state=fin)
+    torch.cuda.synchronize()
+    if want_state:
+        return h.cpu().numpy(), fin.cpu().numpy()
+    return h.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [
+    (3, 5, 21, 12, 1),        # K = 1 (advance kernel), N below one atom block
+    (5, 7, 33, 40, 3),        # ragged over the 16-row / 32-atom padding
+    (17, 4, 65, 70, 2),       # two row tiles
+    (2, 3, 513, 200, 2),      # STFT size 2^k + 1
+])
+@pytest.mark.parametrize("activation", ["relu", "tanh"])
+def test_dense_cell_matches_oracle(dev, shape, activation):
+    B, T, F, N, K = shape
+    rng = np.random.default_rng(B * 100 + N)
+    P = O.synth_problem(B, T, F, max(N // 2, 1), seed=4, ragged=True, density=0.1)
+    X = P["X"][:, :, :F]
+    U, S, W, b = _random_mats(rng, K, N, F)
+    h0 = np.abs(rng.standard_normal(N)).astype(np.float32) * 0.3
+    h = _run(dev, X, U, S, W, b, h0, activation=activation)
+    ref = O.cell_forward_dense(X, list(W), list(U), list(b), list(S), None, h0=h0,
+                               activation=activation)
+    _check(h, ref)
+
+
+@pytest.mark.parametrize("activation", ["linear", "sigmoid", "softplus", "hard_sigmoid"])
+def test_dense_cell_activations(dev, activation):
+    B, T, F, N, K = 4, 6, 19, 24, 2
+    rng = np.random.default_rng(7)
+    X = np.abs(rng.standard_normal((B, T, F))).astype(np.float32)
+    U, S, W, b = _random_mats(rng, K, N, F, scale=0.4)
+    h0 = np.zeros(N, np.float32)
+    h = _run(dev, X, U, S, W, b, h0, activation=activation, mask_value=None)
+    ref = O.cell_forward_dense(X, list(W), list(U), list(b), list(S), None, h0=h0,
+                               activation=activation, mask_value=np.nan)
+    _check(h, ref)
+
+
+def test_dense_cell_flags_and_state(dev):
+    """flag_connect_input_to_layers=False (x never enters, custom_layers.py:366-368),
+    flag_return_all_hidden with masking, stateful initial / final state."""
+    B, T, F, N, K = 6, 9, 21, 36, 3
+    rng = np.random.default_rng(11)
+    P = O.synth_problem(B, T, F, N // 2, seed=9, ragged=True, density=0.1)
+    X = P["X"]
+    U, S, W, b = _random_mats(rng, K, N, F)
+    h0 = np.abs(rng.standard_normal(N)).astype(np.float32) * 0.2
+    h = _run(dev, X, U, S, W, b, h0, connect=False)
+    _check(h, O.cell_forward_dense(X, list(W), list(U), list(b), list(S), None, h0=h0,
+                                   connect_input=False))
+    h = _run(dev, X, U, S, W, b, h0, all_hidden=True)
+    _check(h, O.cell_forward_dense(X, list(W), list(U), list(b), list(S), None, h0=h0,
+                                   return_all_hidden=True))
+    init = np.abs(rng.standard_normal((B, N))).astype(np.float32)
+    h, fin = _run(dev, X, U, S, W, b, h0, initial_state=init, want_state=True)
+    ref, rfin = O.cell_forward_dense(X, list(W), list(U), list(b), list(S), None, h0=h0,
+                                     initial_state=init, return_state=True)
+    _check(h, ref)
+    _check(fin, rfin)
+
+
+def test_dense_graph_replay_is_deterministic(dev, monkeypatch):
+    B, T, F, N, K = 3, 70, 17, 20, 2          # T above one graph's frames + a remainder
+    rng = np.random.default_rng(3)
+    X = np.abs(rng.standard_normal((B, T, F))).astype(np.float32)
+    U, S, W, b = _random_mats(rng, K, N, F, scale=0.5)
+    h0 = np.zeros(N, np.float32)
+    h1 = _run(dev, X, U, S, W, b, h0)
+    h2 = _run(dev, X, U, S, W, b, h0)
+    np.testing.assert_array_equal(h1, h2)
+    monkeypatch.setenv("DRNMF_NO_GRAPH", "1")
+    np.testing.assert_array_equal(h1, _run(dev, X, U, S, W, b, h0))
+    _check(h1, O.cell_forward_dense(X, list(W), list(U), list(b), list(S), None, h0=h0))
+
+
+def test_layer_with_trained_dense_u_matches_reference_graph(dev):
+    """build_alt maps whose log_U1/log_Uk left the rank-structured form (a trained U): the layer
+    switches to the dense-matrix kernel and reproduces the reference's op graph
+    relu(p U_k + h S_k + x Wk_k + b_k) with the dense maps (enhance.py:161-204)."""
+    from drnmf_amd import layers
+    B, T, F, r, K = 5, 8, 33, 10, 3
+    P = O.synth_problem(B, T, F, r, seed=21, ragged=True, density=0.1)
+    N = 2 * r
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph", "log_U1", "log_Uk"])
+    model = layers.build_unfolded_snmf(p, device=dev)
+    cell = model.cell
+    with pytest.raises(NotImplementedError):      # no gradient for log_U1 / log_Uk: loud, not zero
+        model.compile(lr=1e-3)
+    x = torch.from_numpy(P["X"]).to(dev)
+    h_fused = cell.call(x, mask_value=-1.).cpu().numpy()
+    assert not cell._dense_now
+    # same weights through the dense kernel must agree with the fused kernels
+    cell._dense_now = True
+    _check(cell.call(x, mask_value=-1.).cpu().numpy(), h_fused)
+    # now really perturb U (as a training step on log_U1/log_Uk would)
+    rng = np.random.default_rng(2)
+    names = cell.weight_names
+    w = cell.get_weights()
+    for i, n in enumerate(names):
+        if n.endswith("log_U1") or n.endswith("log_Uk"):
+            w[i] = (w[i] + 0.3 * rng.standard_normal(w[i].shape)).astype(np.float32)
+    cell.set_weights(w)
+    assert cell._dense_now
+    h = cell.call(x, mask_value=-1.).cpu().numpy()
+    alt = {n[len(cell.name) + 1:]: v for n, v in zip(names[1:], w[1:])}
+    Wk, Uk, bk, Sk = O.maps_dense(alt, cell.maps_from_alt.labels_per_k, K, N)
+    _check(h, O.cell_forward_dense(P["X"], Wk, Uk, bk, Sk, w[0]))
+    with pytest.raises(NotImplementedError):
+        cell.forward_train(x, mask_value=-1.)
+    # the whole model (mask head on top) still predicts
+    irm = model.predict_on_batch(P["X"])
+    assert irm.shape == (B, T, F) and np.all(np.isfinite(irm))
+
+
+def test_layer_with_caller_maps_and_free_weights(dev):
+    """maps_from_alt supplied by the caller (plain callables on the alt-param dict, as the
+    reference's Theano lambdas) for W and b; U and S are free weights of the layer
+    (custom_layers.py:250-281); tanh; flag_nonnegative off -> `h0` weight."""
+    from drnmf_amd import layers
+    B, T, F, N, K = 4, 6, 23, 28, 2
+    rng = np.random.default_rng(5)
+    A = (0.2 * rng.standard_normal((F, N))).astype(np.float32)
+    c = (0.1 * rng.standard_normal((N,))).astype(np.float32)
+    maps = {"W": [lambda a: a["A"], lambda a: 0.5 * a["A"]], "b": lambda a: a["c"]}
+    np.random.seed(0)
+    cell = layers.SimpleDeepRNN(N, activation="tanh", K_layers=K, alt_params={"A": A, "c": c},
+                                keys_trainable=["A"], maps_from_alt=maps,
+                                flag_connect_input_to_layers=True, flag_nonnegative=False,
+                                return_sequences=True, device=dev)
+    X = rng.standard_normal((B, T, F)).astype(np.float32)
+    h = cell.call(torch.from_numpy(X).to(dev)).cpu().numpy()
+    names = [n[len(cell.name) + 1:] for n in cell.weight_names]
+    assert names == ["h0", "A", "c", "U_0", "U_1", "S_0to1"]
+    w = dict(zip(names, cell.get_weights()))
+    np.testing.assert_allclose(w["U_0"] @ w["U_0"].T, np.eye(N), atol=1e-5)   # orthogonal init
+    Wk = [A, 0.5 * A]
+    ref = O.cell_forward_dense(X, Wk, [w["U_0"], w["U_1"]], [c, c], [w["S_0to1"]], None,
+                               h0=w["h0"], activation="tanh", mask_value=np.nan)
+    _check(h, ref)
+    # set_weights invalidates the prepared block
+    w2 = cell.get_weights()
+    w2[0] = np.full(N, 0.25, np.float32)
+    cell.set_weights(w2)
+    h2 = cell.call(torch.from_numpy(X).to(dev)).cpu().numpy()
+    ref2 = O.cell_forward_dense(X, Wk, [w["U_0"], w["U_1"]], [c, c], [w["S_0to1"]], None,
+                                h0=w2[0], activation="tanh", mask_value=np.nan)
+    _check(h2, ref2)

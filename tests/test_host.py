@@ -80,7 +80,7 @@ def test_build_alt_matches_oracle():
             np.testing.assert_allclose(maps["S"][k](alt), Sk[k], rtol=1e-5, atol=1e-6)
 
 
-def test_simple_deep_rnn_rejects_uncovered_configs():
+def test_simple_deep_rnn_config_surface():
     from drnmf_amd import layers
     P = O.synth_problem(2, 3, 21, 6, seed=5)
     N, K = 12, 2
@@ -99,13 +99,20 @@ def test_simple_deep_rnn_rejects_uncovered_configs():
     st = layers.SimpleDeepRNN(N, **dict(ok, stateful=True))      # stateful mode is supported
     with pytest.raises(ValueError):
         st.reset_states()                                        # batch size not known yet
-    for bad in (dict(activation="tanh"), dict(flag_nonnegative=False),
-                dict(flag_connect_input_to_layers=False), dict(dropout_W=0.5),
-                dict(maps_from_alt={"W": lambda a: a})):
+    # configurations outside build_unfolded_snmf's are accepted (general dense-matrix kernel,
+    # forward only) ...
+    for generic in (dict(activation="tanh"), dict(flag_nonnegative=False),
+                    dict(flag_connect_input_to_layers=False), dict(dropout_W=0.5),
+                    dict(maps_from_alt={"W": lambda a: a})):
         kw = dict(ok)
-        kw.update(bad)
-        with pytest.raises(NotImplementedError):
-            layers.SimpleDeepRNN(N, **kw)
+        kw.update(generic)
+        g = layers.SimpleDeepRNN(N, **kw)
+        assert g._generic == ("dropout_W" not in generic)
+    # ... what has no meaning raises
+    with pytest.raises(ValueError):
+        layers.SimpleDeepRNN(N, **dict(ok, activation="swish"))
+    with pytest.raises(NotImplementedError):
+        layers.SimpleDeepRNN(N, **dict(ok, activation="tanh", operand_dtype="float16"))
 
 
 def test_build_unfolded_snmf_argument_errors():
