@@ -606,12 +606,21 @@ class SimpleDeepRNN(_Layer):
 # ------------------------------------------------------------------------------------------
 # build_unfolded_snmf  (enhance.py:209-317)
 def _require_h5py(path):
+    """h5py when it is importable, else the in-tree ctypes binding of the system's libhdf5
+    (h5lite.py: the same File / Group / attrs idioms)."""
     try:
         import h5py
         return h5py
     except ImportError:
-        raise ImportError("reading/writing the Keras HDF5 weight file %r needs h5py, which this "
-                          "environment lacks; use a '.npz' path (same tree of names)" % path)
+        pass
+    from . import h5lite
+    try:
+        h5lite.lib()
+    except ImportError as e:
+        raise ImportError("reading/writing the Keras HDF5 weight file %r needs h5py or a libhdf5 "
+                          ">= 1.10 for drnmf_amd.h5lite (%s); use a '.npz' path (same tree of "
+                          "names)" % (path, e))
+    return h5lite
 
 
 # ------------------------------------------------------------------------------------------
@@ -687,8 +696,10 @@ class UnfoldedSNMFModel(object):
             layer.set_weights(vals)
 
     def save_weights(self, path):
-        """'.npz': the weights_tree dict (numpy).  '.h5'/'.hdf5': the same tree written with h5py
-        in Keras 2.0.4's layout -- h5py is not part of this image, so that branch is unpinned."""
+        """'.npz': the weights_tree dict (numpy).  '.h5'/'.hdf5': the same tree in Keras 2.0.4's
+        HDF5 layout (root attrs layer_names / backend / keras_version, one group per layer with a
+        weight_names attr and one dataset per weight), written with h5py or, without it, through
+        the system's libhdf5 (h5lite.py)."""
         tree = self.weights_tree()
         if path.endswith('.npz'):
             np.savez(path, **tree)

@@ -132,8 +132,7 @@ def test_build_unfolded_snmf_argument_errors():
 def test_weight_files_follow_keras_layout(tmp_path):
     """save_weights / load_weights (enhance.py:1096-1166) on the Keras tree of names: layers with
     weights in order, the cell's weights matched by name (the reference's order there is Python-2
-    dict order), a reference-style layer name accepted, missing weights rejected.  HDF5 itself
-    needs h5py (absent here): that branch must fail loudly."""
+    dict order), a reference-style layer name accepted, missing weights rejected."""
     from drnmf_amd import layers
     P = O.synth_problem(2, 3, 21, 6, seed=5)
     p = dict(input_dim=21, hidden_dim=12, output_dim=21, mask_value=-1., maxseq=3, K_layers=2,
@@ -171,11 +170,7 @@ def test_weight_files_follow_keras_layout(tmp_path):
     bad["simple_deep_rnn_1/weight_names"] = np.array(rn[:-1])
     with pytest.raises(ValueError):
         m.load_weights_tree(bad)
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            m.load_weights(str(tmp_path / "model.hdf5"))
+    # (the HDF5 form of the same tree: tests/test_h5.py)
 
 
 def test_data_layout_helpers_match_reference_golden_vectors(golden):
