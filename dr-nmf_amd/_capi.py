@@ -82,6 +82,13 @@ SIGNATURES = {
     "drnmf_istft_masked": (_i32, [_vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz,
                                   _vp]),
     "drnmf_snr": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "drnmf_divide_a_by_aplusb": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "drnmf_add": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "drnmf_loss_forward_workspace_bytes": (_sz, [_i64]),
+    "drnmf_loss_forward": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
+                                  _f32, _vp, _vp, _sz, _vp]),
+    "drnmf_wav_int16_workspace_bytes": (_sz, []),
+    "drnmf_wav_int16": (_i32, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "drnmf_sdr_workspace_bytes": (_sz, [_i32, _i64, _i32]),
     "drnmf_sdr_corr": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drnmf_sdr_project": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -240,7 +240,7 @@ class DivideAbyAplusB(_Layer):
         if len(inputs) != 2:
             raise ValueError('DivideAbyAplusB takes exactly 2 inputs')
         A, B = inputs
-        return torch.exp(torch.log(1e-7 + A) - torch.log(1e-7 + A + B))
+        return ops.divide_a_by_aplusb(A, B)
 
 
 def divide_A_by_AplusB(inputs, **kwargs):
@@ -812,7 +812,7 @@ class UnfoldedSNMFModel(object):
         sse, cnt = float(flat[-2]), float(flat[-1])
         scale = 1.0 / max(cnt, 1.0)
         if o['clipnorm'] > 0:                       # global-norm clip [K2.0.4-memory]
-            norm = float(torch.sqrt(ops.sumsq(flat[:-2]))) * scale
+            norm = float(np.sqrt(ops.sumsq(flat[:-2]))) * scale
             if norm > o['clipnorm']:
                 scale *= o['clipnorm'] / norm
         lr = o['lr']
@@ -851,9 +851,7 @@ class UnfoldedSNMFModel(object):
         x, y = tt(x), tt(y)
         w = tt(sample_weight) if sample_weight is not None else \
             torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
-        m = self.forward(x)
-        mse = ((x * m - y) ** 2).mean(-1)
-        s = torch.stack([(mse * w).sum(), (w != 0).float().sum()])
+        s = ops.loss_forward(y, w, x_raw=x, mask=self.forward(x))
         dp.allreduce_sum_(s)
         return float(s[0]) / max(float(s[1]), 1.0)
 
@@ -952,7 +950,7 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
         """-> [x_recon, h_estimated]"""
         h = self.cell.call(x, mask_value=self.mask_value)
         _, A, Bn = ops.head_forward(h, self.clean.kernel, self.noise.kernel, want_ab=True)
-        return [A + Bn, h]
+        return [ops.add(A, Bn), h]
 
     def predict_on_batch(self, x):
         xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.cell.device)
@@ -994,9 +992,9 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
         y = x if y is None else tt(self._first(y))
         sw = self._first(sample_weight)
         w = tt(sw) if sw is not None else torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
-        xr, h = self.forward(x)
-        per = 0.5 * ((xr - y) ** 2).mean(-1) + self.loss_weights[1] * h.abs().mean(-1)
-        s = torch.stack([(per * w).sum(), (w != 0).float().sum()])
+        h = self.cell.call(x, mask_value=self.mask_value)
+        _, A, Bn = ops.head_forward(h, self.clean.kernel, self.noise.kernel, want_ab=True)
+        s = ops.loss_forward(y, w, A=A, Bn=Bn, hidden=h, l1_weight=self.loss_weights[1])
         dp.allreduce_sum_(s)
         return float(s[0]) / max(float(s[1]), 1.0)
 

@@ -356,7 +356,61 @@ def sumsq(g):
     out = torch.empty(256, dtype=torch.float32, device=g.device)
     rc = L.drnmf_sumsq(h, g.numel(), _capi.ptr(_f32c(g, "g")), _capi.ptr(out), _stream())
     _capi.check(rc, h, "drnmf_sumsq")
-    return out.double().sum()
+    return float(out.cpu().numpy().astype(np.float64).sum())     # 256 partials, summed on the host
+
+
+def divide_a_by_aplusb(A, B):
+    """exp(log(1e-7+A) - log(1e-7+A+B)) (custom_layers.py:41-45), elementwise."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(A))
+    A, B = _f32c(A, "A"), _f32c(B, "B")
+    if A.shape != B.shape:
+        raise ValueError("A and B must have the same shape")
+    out = torch.empty_like(A)
+    rc = L.drnmf_divide_a_by_aplusb(h, A.numel(), _capi.ptr(A), _capi.ptr(B), _capi.ptr(out),
+                                    _stream())
+    _capi.check(rc, h, "drnmf_divide_a_by_aplusb")
+    return out
+
+
+def add(a, b):
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(a))
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("a and b must have the same shape")
+    out = torch.empty_like(a)
+    rc = L.drnmf_add(h, a.numel(), _capi.ptr(a), _capi.ptr(b), _capi.ptr(out), _stream())
+    _capi.check(rc, h, "drnmf_add")
+    return out
+
+
+def loss_forward(y, w, x_raw=None, mask=None, A=None, Bn=None, hidden=None, l1_weight=0.0):
+    """Validation loss sums {sum_rows w*loss_row, #rows with w != 0} (device tensor of 2 floats).
+    mask given: mean_F (x_raw*mask - y)^2;  A, Bn, hidden given: the SNMF pretraining cost
+    0.5 mean_F (A+Bn-y)^2 + l1_weight * mean_N |hidden| (enhance.py:1027-1035)."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(y))
+    F = y.shape[-1]
+    rows = y.numel() // F
+    y, w = _f32c(y, "y"), _f32c(w, "w")
+    if w.numel() != rows:
+        raise ValueError("w must have one weight per row")
+    sums = torch.empty(2, dtype=torch.float32, device=y.device)
+    ws = torch.empty(L.drnmf_loss_forward_workspace_bytes(rows), dtype=torch.uint8, device=y.device)
+    if mask is not None:
+        x_raw, mask = _f32c(x_raw, "x_raw"), _f32c(mask, "mask")
+        rc = L.drnmf_loss_forward(h, rows, F, 0, _capi.ptr(x_raw), _capi.ptr(mask), None,
+                                  _capi.ptr(y), _capi.ptr(w), None, 0, 0, 0.0, _capi.ptr(sums),
+                                  _capi.ptr(ws), ws.numel(), _stream())
+    else:
+        A, Bn, hidden = _f32c(A, "A"), _f32c(Bn, "Bn"), _f32c(hidden, "hidden")
+        N2 = hidden.shape[-1]
+        rc = L.drnmf_loss_forward(h, rows, F, 1, None, _capi.ptr(A), _capi.ptr(Bn), _capi.ptr(y),
+                                  _capi.ptr(w), _capi.ptr(hidden), N2, N2, float(l1_weight),
+                                  _capi.ptr(sums), _capi.ptr(ws), ws.numel(), _stream())
+    _capi.check(rc, h, "drnmf_loss_forward")
+    return sums
 
 
 def ista_forward(X, W, H, lam1, alph, K, divergence="ed", beta=2.0):
@@ -576,7 +630,12 @@ def sdr_db(est, ref, flen=512, return_parts=False):
 def to_int16_wav(x):
     """util.wavwrite's float32 -> int16 conversion (util.py:37-45): divide by max|x| if it exceeds
     1, scale by 32767, truncate toward zero (numpy int16 cast)."""
-    m = x.abs().max()
-    if float(m) > 1.0:
-        x = x / m
-    return (x * 32767.0).to(torch.int16)
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(x))
+    x = _f32c(x, "x")
+    out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    ws = torch.empty(L.drnmf_wav_int16_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    rc = L.drnmf_wav_int16(h, x.numel(), _capi.ptr(x), _capi.ptr(out), _capi.ptr(ws), ws.numel(),
+                           _stream())
+    _capi.check(rc, h, "drnmf_wav_int16")
+    return out

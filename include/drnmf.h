@@ -315,6 +315,34 @@ int32_t drnmf_sdr_project(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32
                           double* energies, float* out_db, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* ---- small elementwise / reduction pieces around the model, so that no arithmetic of the
+ * product runs through host-framework ops:
+ *   drnmf_divide_a_by_aplusb  out = exp(log(1e-7+A) - log(1e-7+A+B)), n elements: DivideAbyAplusB as
+ *                             a stand-alone layer (custom_layers.py:33-56)
+ *   drnmf_add                 out = a + b: x_recon = clean_est + noise_est of model_pretrain
+ *                             (enhance.py:1024-1026)
+ *   drnmf_loss_forward        validation loss without gradients (val_loss of fit(), enhance.py:
+ *                             1152-1157); sums = {sum over rows, #rows with w != 0} as
+ *                             drnmf_loss_head_backward.
+ *                               mode 0: w * mean_F (x_raw*pred - y)^2            (pred = mask)
+ *                               mode 1: w * (0.5 mean_F (pred + pred2 - y)^2 + l1_weight *
+ *                                       mean_{n<N2} |hidden[row][n]|)   (pred, pred2 = A, Bn)
+ *   drnmf_wav_int16           util.wavwrite's float32 -> int16 (util.py:37-45): divide by max|x| if
+ *                             it exceeds 1, scale by 32767, truncate toward zero */
+int32_t drnmf_divide_a_by_aplusb(drnmf_handle_t h, int64_t n, const float* A, const float* B,
+                                 float* out, void* stream);
+int32_t drnmf_add(drnmf_handle_t h, int64_t n, const float* a, const float* b, float* out,
+                  void* stream);
+size_t drnmf_loss_forward_workspace_bytes(int64_t rows);
+int32_t drnmf_loss_forward(drnmf_handle_t h, int64_t rows, int32_t F, int32_t mode,
+                           const float* x_raw, const float* pred, const float* pred2,
+                           const float* y, const float* w, const float* hidden, int64_t ld_h,
+                           int32_t N2, float l1_weight, float* sums, void* workspace,
+                           size_t workspace_bytes, void* stream);
+size_t drnmf_wav_int16_workspace_bytes(void);
+int32_t drnmf_wav_int16(drnmf_handle_t h, int64_t n, const float* x, int16_t* out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,3 +199,38 @@ def test_layer_with_caller_maps_and_free_weights(dev):
     ref2 = O.cell_forward_dense(X, Wk, [w["U_0"], w["U_1"]], [c, c], [w["S_0to1"]], None,
                                 h0=w2[0], activation="tanh", mask_value=np.nan)
     _check(h2, ref2)
+
+
+def test_small_elementwise_kernels(dev):
+    """DivideAbyAplusB stand-alone (custom_layers.py:41-45), x_recon = A + Bn, the gradient-free
+    validation losses (enhance.py:1152-1157, 1027-1035) and wavwrite's int16 conversion
+    (util.py:37-45) against numpy."""
+    from drnmf_amd import layers, ops
+    rng = np.random.default_rng(8)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    A = np.abs(rng.standard_normal((3, 7, 33))).astype(np.float32)
+    Bn = np.abs(rng.standard_normal((3, 7, 33))).astype(np.float32)
+    A[0, 0] = 0
+    Bn[0, 0] = 0
+    m = layers.divide_A_by_AplusB([t(A), t(Bn)]).cpu().numpy()
+    np.testing.assert_allclose(m, O.divide_a_by_aplusb(A.astype(np.float64), Bn.astype(np.float64)),
+                               rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(ops.add(t(A), t(Bn)).cpu().numpy(), A + Bn)
+    x = np.abs(rng.standard_normal(A.shape)).astype(np.float32)
+    y = np.abs(rng.standard_normal(A.shape)).astype(np.float32)
+    w = (rng.random((3, 7)) < 0.7).astype(np.float32) * 1.5
+    s = ops.loss_forward(t(y), t(w), x_raw=t(x), mask=t(m)).cpu().numpy()
+    ref = np.sum(w * np.mean((x.astype(np.float64) * m - y) ** 2, -1))
+    np.testing.assert_allclose(s[0], ref, rtol=1e-5)
+    assert s[1] == np.count_nonzero(w)
+    hid = np.abs(rng.standard_normal((3, 7, 20))).astype(np.float32)
+    s = ops.loss_forward(t(y), t(w), A=t(A), Bn=t(Bn), hidden=t(hid), l1_weight=0.37).cpu().numpy()
+    ref = np.sum(w * (0.5 * np.mean((A.astype(np.float64) + Bn - y) ** 2, -1) +
+                      0.37 * np.mean(np.abs(hid), -1)))
+    np.testing.assert_allclose(s[0], ref, rtol=1e-5)
+    for scale in (0.5, 3.0):
+        sig = (scale * rng.standard_normal(5000)).astype(np.float32) / 3
+        q = ops.to_int16_wav(t(sig)).cpu().numpy()
+        mx = np.max(np.abs(sig))
+        want = np.int16((sig / mx if mx > 1 else sig) * np.float32(32767.0))
+        assert q.dtype == np.int16 and np.max(np.abs(q.astype(int) - want.astype(int))) <= 1
