@@ -247,6 +247,76 @@ def test_full_size_layer_against_oracle(dev):
     assert agree > 0.9999
 
 
+def test_full_size_full_length_properties(dev):
+    """BASELINE config 2 at its FULL size (F=513, N=2000, K=25 untied, B=64, T=2000: 98,000 cell
+    launches replayed from hipGraphs) through size-independent properties:
+      * prefix: the first 48 frames equal a 48-frame run on the same inputs, bit for bit;
+      * rows: the first 16 utterances run alone give the same rows (within H_TOL: another split of
+        the contraction);
+      * chaining: two stateful 1000-frame halves equal the one 2000-frame run (within H_TOL);
+      * a frame deep in the sequence (t = 1999) against the fp64 oracle stepped ONCE from the
+        device's own state at t = 1998 (tolerance H_TOL);
+      * masks of the head on the last frames are in (0, 1]."""
+    from drnmf_amd import layers, ops
+    B, T, F, r, K = 64, 2000, 513, 1000, 25
+    N = 2 * r
+    rng = np.random.Generator(np.random.PCG64(7654))
+    W = rng.random((F, N)) ** 4
+    W = (W / np.sqrt((W * W).sum(0, keepdims=True))).astype(np.float32)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    Wt = torch.from_numpy(W).to(dev)
+    X = torch.empty((B, T, F), dtype=torch.float32, device=dev)
+    for b in range(B):                      # synthetic mixture, generated on the device
+        Ht = (torch.rand((T, N), generator=g, device=dev) < 0.02) * \
+            torch.rand((T, N), generator=g, device=dev) * 5.0
+        X[b] = Ht @ Wt.t() + 0.01 * torch.rand((T, F), generator=g, device=dev)
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K, W=W,
+             alph=400.0, lam1=1.0, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph"])
+    np.random.seed(3)
+    model = layers.build_unfolded_snmf(p, device=dev)
+    cell = model.cell
+    w = cell.get_weights()                  # untied copies that really differ per layer
+    prng = np.random.default_rng(5)
+    names = cell.weight_names
+    for i, n in enumerate(names):
+        if "log_D_" in n or "log_alph_" in n:
+            w[i] = (w[i] + 0.02 * prng.standard_normal(w[i].shape)).astype(np.float32)
+    cell.set_weights(w)
+    h = cell.call(X, mask_value=-1.)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(h).all()) and float(h.min()) >= 0.0
+    # prefix and row independence
+    assert torch.equal(cell.call(X[:, :48].contiguous(), mask_value=-1.), h[:, :48])
+    # (16 rows alone use more atom ranges per bin tile -- another summation order: H_TOL, not bits)
+    h16 = cell.call(X[:16].contiguous(), mask_value=-1.)
+    assert float((h16 - h[:16]).abs().max()) <= H_TOL * float(h[:16].max())
+    # stateful chaining of two halves (state enters as given: start both from the same h0)
+    alt = {n[len(cell.name) + 1:]: v for n, v in zip(names[1:], w[1:])}
+    labels = cell.maps_from_alt.labels_per_k
+    desc = cell.prepare(B, T // 2)
+    h0 = torch.from_numpy(np.tile(O.softplus(w[0].astype(np.float64)).astype(np.float32), (B, 1))).to(dev)
+    st = torch.empty((B, N), dtype=torch.float32, device=dev)
+    ha = ops.cell_forward(X[:, :T // 2].contiguous(), -1., cell._params_block, desc, cell.log_h0,
+                          cell._u, initial_state=h0, final_state=st)
+    hb = ops.cell_forward(X[:, T // 2:].contiguous(), -1., cell._params_block, desc, cell.log_h0,
+                          cell._u, initial_state=st, final_state=st)
+    # (a supplied state enters with its row sum added in another order than the per-atom-block
+    # partial sums the kernels chain between frames: H_TOL, not bits)
+    tol = H_TOL * float(h.max())
+    assert float((ha - h[:, :T // 2]).abs().max()) <= tol
+    assert float((hb - h[:, T // 2:]).abs().max()) <= tol
+    # one oracle step deep in the sequence, from the device's own state
+    rows = slice(0, 8)
+    ref = O.cell_forward_factored(X[rows, T - 1:].cpu().numpy(), O.maps_factored(alt, labels, K),
+                                  O.u_scalars(alt), w[0], mask_value=-1.0,
+                                  initial_state=h[rows, T - 2].cpu().numpy().astype(np.float64))
+    _check_h(h[rows, T - 1:].cpu().numpy(), ref)
+    mask = ops.head_forward(h[:, T - 4:].contiguous(), model.clean.kernel, model.noise.kernel)
+    assert float(mask.min()) > 0.0 and float(mask.max()) <= 1.0 + 1e-6
+
+
 # ------------------------------------------------------------------ frame-parallel ISTA / MU
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 @pytest.mark.parametrize("name", ["ed", "kl", "beta"])
