@@ -211,3 +211,72 @@ def test_fit_with_reference_callbacks(dev, tmp_path):
     h2 = model.fit(P["X"], P["Y"], sample_weight=wmask, batch_size=4, epochs=10,
                    validation_data=val, callbacks=[stop2])
     assert len(h2["val_loss"]) == 3 and model.stop_training
+
+
+def test_full_size_training_step_properties(dev):
+    """BASELINE configs[2] at its full size -- the shipped training configuration (F=257, N=2000,
+    K=5 untied, B=32, T=500, ragged) -- through size-independent properties of the BPTT:
+      * two evaluations of loss + gradients are bit-identical (no atomics anywhere);
+      * the cell backward is linear in the incoming gradient: bwd(d1 + 2 d2) = bwd(d1) + 2 bwd(d2);
+      * the directional derivative along the log_D gradient equals the central finite difference
+        of the (gradient-free) loss kernel within 0.5 %;
+      * a few Adam steps lower the loss."""
+    from drnmf_amd import layers, ops
+    B, T, F, r, K = 32, 500, 257, 1000, 5
+    N = 2 * r
+    np.random.seed(1)
+    P = O.synth_problem(B, T, F, r, seed=7654, ragged=True, density=0.02)
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=400.0, lam1=1.0, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph"])
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.compile(lr=1e-3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    x, y = t(P["X"]), t(P["Y"])
+    w = t((P["X"] != -1.0).any(-1).astype(np.float32))
+    f1 = model.loss_and_grads(x, y, w).clone()
+    f2 = model.loss_and_grads(x, y, w).clone()
+    assert torch.equal(f1, f2)
+    assert bool(torch.isfinite(f1).all()) and float(f1[-1]) == float(w.sum())
+
+    # linearity of the BPTT in d_out
+    cell = model.cell
+    hall = cell.forward_train(x, mask_value=-1.)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    d1 = torch.randn((B, T, N), generator=g, device=dev) * w[..., None]
+    d2 = torch.randn((B, T, N), generator=g, device=dev) * w[..., None]
+    ga = {k: v.clone() for k, v in cell.backward(x, hall, d1).items()}
+    gb = {k: v.clone() for k, v in cell.backward(x, hall, d2).items()}
+    gc = cell.backward(x, hall, ops.add(d1, ops.add(d2, d2)))
+    for k in ("d_log_D", "d_log_alph", "d_log_h0"):
+        want = ga[k] + 2 * gb[k]
+        err = float((gc[k] - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+        assert err <= 1e-3, "%s: linearity off by %.2e" % (k, err)
+
+    # directional derivative along d log_D vs central differences of the loss
+    names = [n for n, _ in model._train_items if n.startswith("log_D")]
+    gD = {n: model._gview[n].clone() for n in names}
+    model.loss_and_grads(x, y, w)
+    gD = {n: model._gview[n].clone() for n in names}
+    gnorm = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in gD.values())))
+    L0 = float(f1[-2])
+    # (measured at this shape: steps of 5e-3 / 1.2e-3 / 3e-4 / 8e-5 of the loss give 0.4601 /
+    # 0.4822 / 0.4836 / 0.4838 against |g|^2 = 0.4837 -- third-order terms, not the gradient)
+    eps = 3e-4 * L0 / gnorm ** 2
+    base = {n: cell._alt[n].clone() for n in names}
+
+    def loss_at(sign):
+        for n in names:
+            cell._alt[n].copy_(base[n] + sign * eps * gD[n])
+        cell._weights_changed()
+        s = ops.loss_forward(y, w, x_raw=x, mask=model.forward(x))
+        return float(s[0])
+    fd = (loss_at(+1.0) - loss_at(-1.0)) / (2 * eps)
+    for n in names:
+        cell._alt[n].copy_(base[n])
+    cell._weights_changed()
+    assert abs(fd - gnorm ** 2) <= 5e-3 * gnorm ** 2, (fd, gnorm ** 2)
+
+    losses = [model.train_on_batch(x, y, w) for _ in range(6)]
+    assert losses[-1] < losses[0], losses
