@@ -244,6 +244,43 @@ def config5_bench(torch, dev, frames=64, B=64):
     return out
 
 
+def dense_graph_bench(torch, dev, F, r, K, B, frames=40):
+    """The reference's op graph as written -- relu(p U_k + h S_k + x Wk_k + b_k), dense U and
+    materialised Gram S (custom_layers.py:361-369; what cpu_baseline times on the host) -- on the
+    general dense-matrix kernel (csrc/cell_dense.hip), same shape as the headline.  Flops are the
+    ones this form executes, 2*B*(K*(N+F)+(K-1)*N)*N per frame; the algorithmic count of the
+    headline (4*F*N*K) is what `frames_per_s` should be compared on."""
+    from drnmf_amd import ops
+    N = 2 * r
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    U = torch.randn((K, N, N), generator=g, device=dev) * (0.5 / N ** 0.5)
+    S = torch.randn((K - 1, N, N), generator=g, device=dev) * (0.5 / N ** 0.5)
+    W = torch.randn((K, F, N), generator=g, device=dev) * (0.5 / F ** 0.5)
+    b = torch.zeros((K, N), device=dev)
+    X = torch.rand((B, frames, F), generator=g, device=dev)
+    h0 = torch.zeros(N, device=dev)
+    desc = ops.make_dense_desc(B, frames, F, N, K)
+    P = ops.dense_prepare_params(desc, U, S if K > 1 else None, W, b)
+    ws = ops.dense_workspace(desc, dev)
+    out = torch.empty((B, frames, N), device=dev)
+    ops.dense_cell_forward(X, None, P, desc, h0, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.dense_cell_forward(X, None, P, desc, h0, out=out, workspace=ws)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3
+    fl = 2.0 * B * frames * N * (K * (N + F) + (K - 1) * N)
+    res = {"frames": frames, "frames_per_s": B * frames / sec,
+           "us_per_layer_step": sec / (frames * K) * 1e6, "tflops_executed": fl / sec / 1e12,
+           "tflops_algorithmic": B * frames * 4.0 * F * N * K / sec / 1e12}
+    del U, S, W, P, ws, out, X
+    torch.cuda.empty_cache()
+    return res
+
+
 def run_guarded(fn, timeout_s, on_timeout):
     """fn() with a watchdog thread: exceptions become {'error': ...}; if fn has not returned after
     timeout_s the watchdog calls on_timeout() (which is expected to end the process)."""
@@ -436,6 +473,7 @@ def main():
             extra["mu_inference"] = mu_bench(torch, dev, F, N, W)
         if not a.no_slab and world == 1:
             extra["inference_slab_250"] = slab_bench(torch, dev, F, r, K, T)
+            extra["reference_op_graph_dense_kernel"] = dense_graph_bench(torch, dev, F, r, K, B)
         if not a.no_config5 and world == 1:
             extra["config5_shape"] = config5_bench(torch, dev)
         if not a.no_train and world == 1:
