@@ -332,7 +332,7 @@ class SimpleDeepRNN(_Layer):
             self.h0 = torch.zeros(N, dtype=torch.float32, device=self.device)   # :208-211
         self._alt = OrderedDict()
         for key in self.alt_params:                                       # custom_layers.py:216-228
-            v = np.asarray(self.alt_params[key], np.float32)
+            v = np.array(self.alt_params[key], dtype=np.float32, copy=True)   # never alias the caller's
             self._alt[key] = torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
         self.trainable_keys = [k for k in self._alt if k in self.keys_trainable]
         # matrices without a map are free weights of the layer (custom_layers.py:241-281)

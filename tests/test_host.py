@@ -208,3 +208,56 @@ def test_data_layout_helpers_match_reference_golden_vectors(golden):
     np.testing.assert_array_equal([D.get_mask_value(c) for c in cases], g["maskval_cases"])
     with pytest.raises(ValueError):
         D.pad_axis_toN_with_constant(g["m2f_x"], 1, 3, 0.)
+
+
+def test_dense_matrices_of_generic_layer_configurations():
+    """Host side of the general dense-matrix path: the matrices SimpleDeepRNN.build evaluates
+    (custom_layers.py:234-287) -- build_alt's maps against the oracle's dense maps, caller-supplied
+    maps, and free weights with the Keras initializers and the reference's weight names."""
+    from drnmf_amd import layers
+    P = O.synth_problem(2, 3, 21, 6, seed=5)
+    N, K, F = 12, 3, 21
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(3.0), lam1=np.float32(0.3))
+    alt, maps = layers.build_alt(N, K, params, ["log_D"])
+    cell = layers.SimpleDeepRNN(N, activation="relu", K_layers=K, alt_params=alt,
+                                maps_from_alt=maps, flag_connect_input_to_layers=True,
+                                flag_nonnegative=True, return_sequences=True, device="cpu")
+    cell.build((None, 3, F))
+    assert not cell._generic and not cell._dense_now
+    U, S, W, b = cell.dense_matrices()
+    oalt, olab = O.build_alt(N, K, params, ("log_D",))
+    Wk, Uk, bk, Sk = O.maps_dense(oalt, olab, K, N, dtype=np.float32)
+    np.testing.assert_allclose(U, np.stack(Uk), rtol=1e-6)
+    np.testing.assert_allclose(S, np.stack(Sk), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(W, np.stack(Wk), rtol=1e-6)
+    np.testing.assert_allclose(b, np.stack(bk), rtol=1e-6)
+    np.testing.assert_allclose(cell.initial_state_vector(),
+                               O.softplus(cell.get_weights()[0].astype(np.float64)), rtol=1e-6)
+    # a set_weights that breaks the rank structure of U switches the layer to the dense kernel
+    w = cell.get_weights()
+    i = cell.weight_names.index(cell.name + "_log_Uk")
+    w[i] = w[i] + np.float32(0.1) * np.arange(N * N, dtype=np.float32).reshape(N, N) / (N * N)
+    cell.set_weights(w)
+    assert cell._dense_now
+    w[i] = np.asarray(alt["log_Uk"], np.float32)
+    cell.set_weights(w)
+    assert not cell._dense_now
+
+    np.random.seed(4)
+    A = np.random.standard_normal((F, N)).astype(np.float32)
+    g = layers.SimpleDeepRNN(N, activation="tanh", K_layers=2, alt_params={"A": A},
+                             maps_from_alt={"W": lambda a: 2 * a["A"]},
+                             flag_connect_input_to_layers=True, flag_nonnegative=False,
+                             inner_init="orthogonal", device="cpu")
+    g.build((None, 3, F))
+    names = [n[len(g.name) + 1:] for n in g.weight_names]
+    assert names == ["h0", "A", "U_0", "b_0", "U_1", "b_1", "S_0to1"]
+    U, S, W, b = g.dense_matrices()
+    assert U.shape == (2, N, N) and S.shape == (1, N, N) and W.shape == (2, F, N) and b.shape == (2, N)
+    np.testing.assert_array_equal(W[1], 2 * A)
+    np.testing.assert_allclose(U[0] @ U[0].T, np.eye(N), atol=1e-5)
+    assert np.all(b == 0) and np.all(g.initial_state_vector() == 0)
+    assert g.compute_output_shape((5, 3, F)) == (5, N)          # return_sequences=False
+    with pytest.raises(ValueError):
+        g._initializer("he_weird", (3, 3))
