@@ -16,7 +16,7 @@ DIV_ED, DIV_KL, DIV_BETA = 0, 1, 2
 class CellDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("B", "T", "F", "N", "K", "n_D", "n_alph", "alph_len", "n_lam",
-                 "return_all_hidden", "operand_f16")]
+                 "return_all_hidden", "operand_f16", "divergence")]
 
 
 class DenseDesc(C.Structure):
@@ -43,6 +43,8 @@ SIGNATURES = {
                                   _vp]),
     "drnmf_cell_forward_stateful": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp,
                                            _vp, _vp, _sz, _vp]),
+    "drnmf_cell_forward_ista": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz,
+                                       _vp]),
     "drnmf_cell_profile": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _sz,
                                   _vp, _i32, C.POINTER(C.c_float)]),
     "drnmf_dense_params_bytes": (_sz, [_DDP]),

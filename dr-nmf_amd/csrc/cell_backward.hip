@@ -629,6 +629,8 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     if (rc) return rc;
     if (d->operand_f16)
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "cell_backward: operand_f16 is a forward-only mode");
+    if (d->divergence != DRNMF_DIV_ED)
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "cell_backward: the KL / beta cell is forward only");
     if (!d->return_all_hidden)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG,
                    "cell_backward needs the forward run with return_all_hidden=1 (all K hiddens)");

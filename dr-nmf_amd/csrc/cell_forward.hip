@@ -479,6 +479,30 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
     if (tid == 0) { tptr[0] = 0; tptr[16] = 0; }
 }
 
+// KL / beta cell: r = g(x_t, x^) on the packed [Bp][Fp] residual buffer, in place (x^ was left
+// there by cell_b in its no-input mode).  g = x/x^ - 1 (KL) or x x^(beta-2) - x^(beta-1)
+// (enhance.py:431, 450); padded bins are forced to 0 (0/0 otherwise).  Also the frame-counter
+// hand-over of the frame's first kernel (see cell_forward_impl).
+__global__ void __launch_bounds__(256)
+resid_div_kernel(const float* __restrict__ xp, float* __restrict__ r, const int* t_rd, int* t_wr,
+                 int div, float beta, int F, int Fp, int Bp) {
+    const int t = *t_rd;
+    if (t_wr && blockIdx.x == 0 && threadIdx.x == 0) *t_wr = t;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // one block = one 16 x 16 tile
+    if (i >= (size_t)Bp * Fp) return;
+    const int ft = (int)(blockIdx.x % (Fp / 16));
+    const int pos = threadIdx.x;                                   // rp_pos order: ((c&3)*16 + row)*4 + (c>>2)
+    const int c = 4 * (pos & 3) + (pos >> 6);
+    const int f = 16 * ft + c;
+    const float xv = xp[(size_t)t * Bp * Fp + i], xe = r[i];
+    float g = 0.f;
+    if (f < F) {
+        if (div == DRNMF_DIV_KL) g = xv / xe - 1.f;
+        else g = xv * powf(xe, beta - 2.f) - powf(xe, beta - 1.f);
+    }
+    r[i] = g;
+}
+
 template <int G, int KS, int RB, bool AH, bool HALF>
 void* a_func(bool first, bool last) {
     if (first && last) return (void*)&cell_a_kernel<G, KS, RB, true, true, AH, HALF>;
@@ -532,6 +556,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;
+    if (d->divergence != DRNMF_DIV_ED)
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
+                   "cell_forward is the reference's (Euclidean) cell; KL / beta: drnmf_cell_forward_ista");
     if (!x || !params || !log_h0 || !h_out || !workspace)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_forward: NULL pointer argument");
     const Workspace W = workspace_layout(d);
@@ -834,4 +861,213 @@ extern "C" int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t*
     }
     return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
                              workspace, workspace_bytes, stream_, frames, out_us_host);
+}
+
+extern "C" int32_t drnmf_cell_forward_ista(drnmf_handle_t h, const drnmf_cell_desc_t* d,
+                                           const float* x, float mask_value, const void* params,
+                                           const float* log_h0, float beta,
+                                           const float* initial_state, float* final_state,
+                                           float* h_out, void* workspace, size_t workspace_bytes,
+                                           void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    int rc = validate_cell_desc(h, d);
+    if (rc) return rc;
+    if (d->divergence != DRNMF_DIV_KL && d->divergence != DRNMF_DIV_BETA)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG,
+                   "cell_forward_ista: d->divergence must be DRNMF_DIV_KL or DRNMF_DIV_BETA");
+    if (!x || !params || !log_h0 || !h_out || !workspace)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_forward_ista: NULL pointer argument");
+    const Workspace W = workspace_layout(d);
+    if (workspace_bytes < W.total)
+        DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "cell_forward_ista: workspace %zu < required %zu",
+                   workspace_bytes, W.total);
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 255))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "workspace/params must be 256-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const ParamsLayout L = params_layout(d);
+    char* ws = (char*)workspace;
+    const char* pb = (const char*)params;
+    float* xp = (float*)(ws + W.off_xp);
+    unsigned char* valid = (unsigned char*)(ws + W.off_valid);
+    float* rpart = (float*)(ws + W.off_rpart);
+    float* hb[2] = {(float*)(ws + W.off_h0), (float*)(ws + W.off_h1)};
+    float* state = (float*)(ws + W.off_state);
+    float* rs_part = (float*)(ws + W.off_rs);
+    float* psum = (float*)(ws + W.off_psum);
+    int* tA = (int*)(ws + W.off_t);
+    int* tB = tA + 16;
+    const int K = d->K;
+
+    {   // prologue as the reference cell's (pack + mask, initial state, counters = 0)
+        const size_t rows = (size_t)d->T * W.Bp;
+        hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                           stream, x, xp, valid, mask_value, d->B, d->T, d->F, W.Bp, W.Fp);
+        if (initial_state)
+            hipLaunchKernelGGL(load_state_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream,
+                               initial_state, state, rs_part, tA, d->B, d->N, W.Np, W.Bp, W.numA);
+        else
+            hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
+                               rs_part, tA, d->N, W.Np, W.Bp, W.numA);
+        DRNMF_HIP(h, hipMemsetAsync(psum, 0, (size_t)W.Bp * 4, stream));   // read (times 0) by cell_a
+        DRNMF_HIP(h, hipGetLastError());
+    }
+
+    const int numM = W.Bp / (ROWS * W.RB), nft = W.nft_main;      // = Fp / 16: no odd-bin side path
+    const dim3 grid_a(8u * (unsigned)numM, (unsigned)(round_up(W.numA, 8) / 8));
+    const dim3 grid_b(8u * (unsigned)numM, (unsigned)(round_up(nft * W.KS, 8) / 8));
+    const dim3 grid_r((unsigned)((size_t)W.Bp * W.Fp / 256));
+    const size_t dstride = (size_t)L.Fp * L.Np * 4;
+    auto Dn_of = [&](int k) { return pb + L.off_dn + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
+    auto DnA_of = [&](int k) { return pb + L.off_dnA + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
+    auto tail_of = [&](int k) {
+        return (const float*)(pb + L.off_tail) + (d->n_D == 1 ? 0 : (size_t)k * MAX_TAIL * L.Np);
+    };
+    // layer k of a frame: cell_b (x^ = h_in Dn_k^T) -> resid_div (r = g(x_t, x^)) -> cell_a as a
+    // MIDDLE layer of the reference cell (h' = relu(h_in + (r Dn_k) / alpha_k + b_k), uko = 0);
+    // h_in = the state for k = 0.  Frame counters: the first resid kernel of a frame reads tB and
+    // republishes it as tA, the last cell_a reads tA and publishes tB = t + 1.
+    auto h_in_of = [&](int k) { return k == 0 ? state : hb[(k - 1) & 1]; };
+    auto make_b = [&](int k) {
+        CellBArgs b;
+        b.Dn_next = Dn_of(k);
+        b.h = h_in_of(k);
+        b.xp = nullptr;                 // rpart = + x^
+        b.rpart = rpart;
+        b.t_rd = tA;
+        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS;
+        b.logKS = 0;
+        b.nch_ks = W.nch_ks;
+        return b;
+    };
+    auto make_a = [&](int k) {
+        CellAArgs a;
+        memset(&a, 0, sizeof(a));
+        a.Dn = DnA_of(k);
+        a.inv_alpha = (const float*)(pb + L.off_inv_alpha) + (size_t)k * L.Np;
+        a.bias = (const float*)(pb + L.off_bias) + (size_t)k * L.Np;
+        a.rsrc = rpart;
+        a.h_in = h_in_of(k);
+        a.h_out = (k == K - 1) ? state : hb[k & 1];
+        a.state = state;
+        a.rs_part = rs_part;
+        a.psum = psum;
+        a.psum_all = (float*)(ws + W.off_psum_all);
+        a.valid = valid;
+        a.out = h_out;
+        a.t_rd = tA;
+        a.t_wr = (k == K - 1) ? tB : nullptr;
+        a.t_wr_add = 1;
+        a.u0d = 0.f; a.u0o = 0.f; a.uko = 0.f;
+        a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
+        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS; a.ntail = 0;
+        a.Dtail = tail_of(k);
+        a.Dtail_next = tail_of(k);
+        float* qp = (float*)(ws + W.off_qpart);
+        a.q_in = qp; a.q_out = qp;
+        a.xtail = (float*)(ws + W.off_xtail);
+        a.xcur = (float*)(ws + W.off_xcur);
+        a.out_width = d->return_all_hidden ? d->N * K : d->N;
+        a.out_off = d->return_all_hidden ? k * d->N : 0;
+        a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
+        return a;
+    };
+    const int div = d->divergence;
+    int F = d->F, Fp = W.Fp, Bp = W.Bp;
+
+    // one frame's launches, through `emit(func, grid, block, kernelParams)`
+    auto frame = [&](auto&& emit) -> int32_t {
+        for (int k = 0; k < K; ++k) {
+            CellBArgs b = make_b(k);
+            DRNMF_HIP(h, emit(pick_b_func(W.nch_ks, W.RB, false), grid_b, 64 * NW_B, CellBParams(b).p));
+            const float* xpp = xp;
+            float* rp = rpart;
+            const int* trd = (k == 0) ? tB : tA;
+            int* twr = (k == 0) ? tA : nullptr;
+            int dv = div;
+            float bt = beta;
+            void* kr[9] = {&xpp, &rp, &trd, &twr, &dv, &bt, &F, &Fp, &Bp};
+            DRNMF_HIP(h, emit((void*)&resid_div_kernel, grid_r, 256, kr));
+            CellAArgs a = make_a(k);
+            CellAParams ka(a);
+            // (never the IS_FIRST variant: layer 0 is a full ISTA step from the state)
+            DRNMF_HIP(h, emit(pick_a_func(nft, W.KS, W.RB, false, k == K - 1,
+                                          d->return_all_hidden != 0, false),
+                              grid_a, 64 * NW_A, ka.p));
+        }
+        return DRNMF_OK;
+    };
+
+    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr;
+    if (!use_graph) {
+        for (int t = 0; t < d->T; ++t) {
+            rc = frame([&](void* f, dim3 g, unsigned blk, void** kp) {
+                return hipLaunchKernel(f, g, dim3(blk), kp, 0, stream);
+            });
+            if (rc) return rc;
+        }
+        DRNMF_HIP(h, hipGetLastError());
+    } else {
+        int fpg = 600 / (3 * K);
+        fpg = fpg < 1 ? 1 : (fpg > 64 ? 64 : fpg);
+        if (fpg > d->T) fpg = d->T;
+        uint32_t bbits;
+        memcpy(&bbits, &beta, 4);
+        auto get_graph = [&](int frames, hipGraphExec_t* out) -> int32_t {
+            std::vector<uint64_t> key = {
+                0x157AULL, (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N,
+                (uint64_t)d->K, (uint64_t)d->n_D, (uint64_t)d->return_all_hidden,
+                (uint64_t)d->divergence, (uint64_t)bbits, (uint64_t)(uintptr_t)params,
+                (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)frames};
+            for (auto& g : h->graphs)
+                if (g.key == key) { *out = g.exec; return DRNMF_OK; }
+            if (h->graphs.size() >= 24) {
+                DRNMF_HIP(h, hipDeviceSynchronize());
+                (void)hipGraphExecDestroy(h->graphs.front().exec);
+                (void)hipGraphDestroy(h->graphs.front().graph);
+                h->graphs.erase(h->graphs.begin());
+            }
+            GraphEntry ge;
+            ge.key = key;
+            DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
+            hipGraphNode_t last = nullptr;
+            auto add = [&](void* f, dim3 g, unsigned blk, void** kp) -> hipError_t {
+                hipKernelNodeParams p;
+                memset(&p, 0, sizeof(p));
+                p.func = f;
+                p.gridDim = g;
+                p.blockDim = dim3(blk);
+                p.kernelParams = kp;
+                hipGraphNode_t node;
+                hipError_t e = hipGraphAddKernelNode(&node, ge.graph, last ? &last : nullptr,
+                                                     last ? 1 : 0, &p);
+                last = node;
+                return e;
+            };
+            for (int rep = 0; rep < frames; ++rep) {
+                int32_t r2 = frame(add);
+                if (r2) return r2;
+            }
+            DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+            h->graphs.push_back(ge);
+            *out = ge.exec;
+            return DRNMF_OK;
+        };
+        hipGraphExec_t ex = nullptr;
+        rc = get_graph(fpg, &ex);
+        if (rc) return rc;
+        int t = 0;
+        for (; t + fpg <= d->T; t += fpg) DRNMF_HIP(h, hipGraphLaunch(ex, stream));
+        if (t < d->T) {
+            rc = get_graph(1, &ex);
+            if (rc) return rc;
+            for (; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(ex, stream));
+        }
+    }
+    if (final_state) {
+        const size_t tot = (size_t)d->B * d->N;
+        hipLaunchKernelGGL(store_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                           stream, state, final_state, d->B, d->N, W.Np);
+        DRNMF_HIP(h, hipGetLastError());
+    }
+    return DRNMF_OK;
 }

@@ -209,7 +209,10 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.Fp = pad_f(d->F);
     W.Np = pad_n(d->N);
     W.numA = W.Np / ATOMS;
-    W.ntail = (d->F % 16 != 0 && d->F % 16 <= MAX_TAIL && d->F > 16) ? d->F % 16 : 0;
+    // (the KL / beta cell applies a nonlinear map to the COMPLETE x^ of every bin: no odd-bin side
+    // path, a single atom range)
+    const bool nonlin = d->divergence != DRNMF_DIV_ED;
+    W.ntail = (!nonlin && d->F % 16 != 0 && d->F % 16 <= MAX_TAIL && d->F > 16) ? d->F % 16 : 0;
     W.nft_main = W.ntail ? d->F / 16 : W.Fp / 16;
     // Row blocks per workgroup.  Measured on MI355X (F=513, N=2000, K=25; frames/s with 1 / 2 / 4
     // row blocks): B=128 343k / 332k / 206k, B=256 431k / 486k / 399k, B=512 526k / 572k / 537k,
@@ -235,6 +238,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         const int v = atoi(e);
         if ((v == 1 || v == 2 || v == 4 || v == 8) && (W.RB == 1 || v <= 2) && nchN / v >= 1) KS = v;
     }
+    if (nonlin) KS = 1;
     W.KS = KS;
     W.nch_ks = (nchN + KS - 1) / KS;
     size_t o = 0;

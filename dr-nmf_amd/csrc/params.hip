@@ -65,6 +65,10 @@ int validate_cell_desc(drnmf_handle_t h, const drnmf_cell_desc_t* d) {
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "alph_len must be 1 or N");
     if (d->operand_f16 != 0 && d->operand_f16 != 1)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "operand_f16 must be 0 or 1");
+    if (d->divergence < DRNMF_DIV_ED || d->divergence > DRNMF_DIV_BETA)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "divergence must be DRNMF_DIV_ED, _KL or _BETA");
+    if (d->divergence != DRNMF_DIV_ED && d->operand_f16)
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "the KL / beta cell runs on fp32 operands");
     if (d->operand_f16 && d->return_all_hidden)
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
                    "operand_f16 is a forward-only mode (return_all_hidden feeds the fp32 BPTT)");

@@ -261,8 +261,15 @@ class SimpleDeepRNN(_Layer):
                  dropout_W=0., dropout_U=0., K_layers=1, alt_params=None, keys_trainable=None,
                  maps_from_alt=None, flag_connect_input_to_layers=False, flag_nonnegative=False,
                  flag_return_all_hidden=False, return_sequences=False, input_shape=None,
-                 stateful=False, device=None, operand_dtype='float32', **kwargs):
+                 stateful=False, device=None, operand_dtype='float32', divergence='ed', beta=1.5,
+                 **kwargs):
         super(SimpleDeepRNN, self).__init__(**kwargs)
+        # extension (not in the reference): 'kl' / 'beta' run the reference's
+        # ista_kl / ista_beta iteration (enhance.py:421-456) recurrently instead of the Euclidean
+        # cell -- K full ISTA steps per frame warm-started from the previous frame; inference only
+        if divergence not in ops.DIVERGENCES:
+            raise ValueError("divergence must be 'ed', 'kl' or 'beta'")
+        self.divergence, self.beta = divergence, float(beta)
         # extension (BASELINE config 5): 'float16' rounds dictionary and activations to fp16 where
         # they enter the matrix cores (fp32 accumulation and state); inference only
         if operand_dtype not in ('float32', 'float16'):
@@ -300,6 +307,9 @@ class SimpleDeepRNN(_Layer):
         self._generic = (not isinstance(self.maps_from_alt, AltMaps) or activation != 'relu' or
                          not flag_connect_input_to_layers or not flag_nonnegative)
         self._dense_now = self._generic
+        if divergence != 'ed' and (self._generic or operand_dtype != 'float32'):
+            raise NotImplementedError("divergence='kl'|'beta' exists for the build_alt "
+                                      "configuration with fp32 operands")
         if self._generic and operand_dtype != 'float32':
             raise NotImplementedError("operand_dtype='float16' exists for the fused build_alt "
                                       "configuration only")
@@ -502,7 +512,8 @@ class SimpleDeepRNN(_Layer):
         alph_len = int(self._alt[lab['log_alph'][0]].numel())
         return ops.make_desc(B, T, self.input_dim, self.output_dim, self.K_layers, nD, nA,
                              alph_len, nL, self.flag_return_all_hidden,
-                             operand_f16=self.operand_dtype == 'float16')
+                             operand_f16=self.operand_dtype == 'float16',
+                             divergence=self.divergence)
 
     def _stacked_meta(self, name):
         lab = self.maps_from_alt.labels_per_k[name]
@@ -543,9 +554,14 @@ class SimpleDeepRNN(_Layer):
                 self.states = [torch.zeros((B, self.output_dim), dtype=torch.float32,
                                            device=x.device)]
             init = fin = self.states[0]
-        h = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
-                             out=out, workspace=self._ws[key], initial_state=init,
-                             final_state=fin)
+        if self.divergence != 'ed':
+            h = ops.cell_forward_ista(x, mask_value, self._params_block, desc, self.log_h0,
+                                      beta=self.beta, out=out, workspace=self._ws[key],
+                                      initial_state=init, final_state=fin)
+        else:
+            h = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
+                                 out=out, workspace=self._ws[key], initial_state=init,
+                                 final_state=fin)
         return h if self.return_sequences else h[:, -1]
 
     __call__ = call
@@ -557,6 +573,8 @@ class SimpleDeepRNN(_Layer):
         if self.operand_dtype != 'float32':
             raise NotImplementedError("training runs on fp32 operands (operand_dtype='float16' is "
                                       "an inference mode)")
+        if self.divergence != 'ed':
+            raise NotImplementedError("the KL / beta variant of the cell is forward only")
         if self._dense_now or self._train_blockers:
             raise NotImplementedError(
                 'BPTT exists for the fused build_alt configuration (relu, rank-structured U, no '
@@ -758,6 +776,8 @@ class UnfoldedSNMFModel(object):
         self.opt = dict(lr=float(lr), clipnorm=float(clipnorm), decay=float(decay),
                         b1=float(beta_1), b2=float(beta_2), eps=float(epsilon), iterations=0)
         cell = self.cell
+        if cell.divergence != 'ed':
+            raise NotImplementedError('the KL / beta variant of the cell is forward only')
         if cell._generic:
             raise NotImplementedError('training exists for the build_alt configuration of the cell '
                                       '(enhance.py:257-266); this one runs on the forward-only '
@@ -1053,7 +1073,8 @@ def build_unfolded_snmf(params_unfolded_snmf, device=None):
                          activation='relu', K_layers=K_layers, alt_params=alt_params,
                          keys_trainable=keys_trainable, maps_from_alt=maps_from_alt,
                          flag_connect_input_to_layers=True, flag_nonnegative=True, device=device,
-                         operand_dtype=p.get('operand_dtype', 'float32'))
+                         operand_dtype=p.get('operand_dtype', 'float32'),
+                         divergence=p.get('divergence', 'ed'), beta=p.get('beta', 1.5))
     cell.build((None, maxseq, input_dim))
     r = hidden_dim // 2
     log_W_clean = np.log(np.float32(1e-7) + W_noisy[:, :r])               # enhance.py:282

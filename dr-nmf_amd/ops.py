@@ -28,11 +28,16 @@ def _f32c(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+DIVERGENCES = {"ed": _capi.DIV_ED, "kl": _capi.DIV_KL, "beta": _capi.DIV_BETA}
+
+
 def make_desc(B, T, F, N, K, n_D=1, n_alph=1, alph_len=1, n_lam=1, return_all_hidden=False,
-              operand_f16=False):
+              operand_f16=False, divergence="ed"):
+    if divergence not in DIVERGENCES:
+        raise ValueError("divergence must be 'ed', 'kl' or 'beta'")
     return _capi.CellDesc(int(B), int(T), int(F), int(N), int(K), int(n_D), int(n_alph),
                           int(alph_len), int(n_lam), int(bool(return_all_hidden)),
-                          int(bool(operand_f16)))
+                          int(bool(operand_f16)), DIVERGENCES[divergence])
 
 
 def prepare_params(desc, log_D, log_alph, log_lam1, out=None):
@@ -195,6 +200,39 @@ def dense_cell_forward(x, mask_value, params, desc, h0, out=None, workspace=None
                                     _capi.ptr(final_state), _capi.ptr(out), _capi.ptr(workspace),
                                     workspace.numel(), _stream())
     _capi.check(rc, h, "drnmf_dense_cell_forward")
+    return out
+
+
+def cell_forward_ista(x, mask_value, params, desc, log_h0, beta=1.5, out=None, workspace=None,
+                      initial_state=None, final_state=None):
+    """KL / beta variant of the cell (desc.divergence = 'kl' | 'beta'): every frame runs K full
+    ISTA steps of the reference's ista_kl / ista_beta warm-started from the previous frame's
+    output.  x [B,T,F] -> h [B,T,N] (or [B,T,K*N])."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(x))
+    x, log_h0 = _f32c(x, "x"), _f32c(log_h0, "log_h0")
+    if tuple(x.shape) != (desc.B, desc.T, desc.F):
+        raise ValueError("x has shape %s, descriptor says (%d,%d,%d)" %
+                         (tuple(x.shape), desc.B, desc.T, desc.F))
+    if log_h0.numel() != desc.N:
+        raise ValueError("log_h0 must have N=%d elements" % desc.N)
+    width = desc.N * (desc.K if desc.return_all_hidden else 1)
+    if out is None:
+        out = torch.empty((desc.B, desc.T, width), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (desc.B, desc.T, width) or not out.is_contiguous():
+        raise ValueError("out must be a contiguous (B,T,%d) float32 tensor" % width)
+    if workspace is None:
+        workspace = cell_workspace(desc, x.device)
+    for st in (initial_state, final_state):
+        if st is not None and (tuple(st.shape) != (desc.B, desc.N) or st.dtype != torch.float32
+                               or not st.is_contiguous()):
+            raise ValueError("states must be contiguous float32 (B,N) tensors")
+    mv = float("nan") if mask_value is None else float(mask_value)
+    rc = L.drnmf_cell_forward_ista(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
+                                   _capi.ptr(log_h0), float(beta), _capi.ptr(initial_state),
+                                   _capi.ptr(final_state), _capi.ptr(out), _capi.ptr(workspace),
+                                   workspace.numel(), _stream())
+    _capi.check(rc, h, "drnmf_cell_forward_ista")
     return out
 
 

@@ -58,6 +58,9 @@ typedef struct drnmf_cell_desc {
                                 * and activations rounded to fp16 where they enter the matrix
                                 * cores, fp32 accumulation and state (BASELINE config 5; forward
                                 * only -- drnmf_cell_backward returns DRNMF_ERR_UNSUPPORTED)      */
+    int32_t divergence;        /* DRNMF_DIV_ED (0): the reference's cell.  DRNMF_DIV_KL / _BETA: the
+                                * warm-started ISTA cell of drnmf_cell_forward_ista (extension,
+                                * forward only)                                                  */
 } drnmf_cell_desc_t;
 
 int32_t drnmf_version(void);
@@ -105,6 +108,23 @@ int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d
                                     float u0_diag, float u0_off, float uk_off,
                                     const float* initial_state, float* final_state, float* h_out,
                                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* KL / beta-divergence variant of the recurrent cell (NOT in the
+ * reference, whose cell is built for the Euclidean cost only): the reference's frame-parallel
+ * iterations ista_kl / ista_beta (enhance.py:421-456) run recurrently, frame t warm-started from
+ * the output of frame t-1 -- for every layer k = 0..K-1, with h^(0) = p = h_{t-1}:
+ *     h^(k+1) = max(0, h^(k) + (g(x_t, h^(k) Dn_k^T) Dn_k) / alpha_k - lam_k / alpha_k)
+ *     g(x, x^) = x / x^ - 1 (KL)   |   x * x^(beta-2) - x^(beta-1) (beta)
+ * i.e. frame t of row b equals ista_kl(x_t, Dn, p, lam, alpha, K) when the parameters are tied.
+ * Same parameters / prepared block / masking / outputs as drnmf_cell_forward; no U term (the
+ * reference's U_0 = I, U_k = 0 up to 1e-7); d->divergence must be DRNMF_DIV_KL or DRNMF_DIV_BETA and
+ * equal in the drnmf_prepare_params / workspace calls.  As in the reference iteration, x^ = 0
+ * under x > 0 divides by zero. */
+int32_t drnmf_cell_forward_ista(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                float mask_value, const void* params, const float* log_h0,
+                                float beta, const float* initial_state, float* final_state,
+                                float* h_out, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 /* Measurement aid (no reference counterpart; used by bench.py only): runs the first `frames`
  * frames of the same forward with plain launches, every launch bracketed by HIP events on

@@ -252,6 +252,44 @@ def cell_forward_factored(x, layers, u, log_h0, mask_value=-1.0, return_all_hidd
 
 # --------------------------------------------------------------------------------------------
 # head: custom_layers.py:15-56, enhance.py:269-305
+def cell_forward_ista_warm(x, layers, log_h0, divergence='kl', beta=1.5, mask_value=-1.0,
+                           return_all_hidden=False, dtype=np.float64, initial_state=None,
+                           return_state=False):
+    """KL / beta variant of the recurrent cell (not in the reference): the
+    iteration of ista_kl / ista_beta (enhance.py:421-456) run recurrently -- every frame does K full
+    steps  h <- max(0, h + (g(x_t, h Dn_k^T) Dn_k) / alpha_k - lam_k / alpha_k)  warm-started from
+    the previous frame's output, with the cell's per-layer parameters (`layers` =
+    maps_factored(...)), initial state softplus(log_h0) and the K.rnn masking rule of
+    cell_forward_dense.  g: 'ed' x - x^ | 'kl' x / x^ - 1 | 'beta' x x^(beta-2) - x^(beta-1)."""
+    x = np.asarray(x, dtype=dtype)
+    B, T, F = x.shape
+    K = len(layers)
+    N = layers[0][0].shape[1]
+    grad = {'ed': lambda v, e: v - e, 'kl': lambda v, e: v / e - 1,
+            'beta': lambda v, e: v * e ** (beta - 2.) - e ** (beta - 1.)}[divergence]
+    xm, valid = masking(x, dtype(mask_value))
+    state = np.tile(softplus(np.asarray(log_h0, dtype=dtype))[None, :], (B, 1))
+    if initial_state is not None:
+        state = np.array(initial_state, dtype=dtype, copy=True)
+    width = K * N if return_all_hidden else N
+    out_prev = np.zeros((B, width), dtype=dtype)
+    hs = np.empty((B, T, width), dtype=dtype)
+    with np.errstate(all='ignore'):
+        for t in range(T):
+            h = state
+            hidden = []
+            for Dn, ia, b in layers:
+                Dn = np.asarray(Dn, dtype)
+                h = relu(h + (grad(xm[:, t], h @ Dn.T) @ Dn) * ia + b)
+                hidden.append(h)
+            out = np.concatenate(hidden, axis=1) if return_all_hidden else h
+            v = valid[:, t][:, None]
+            out_prev = np.where(v, out, out_prev)
+            state = np.where(v, h, state)
+            hs[:, t] = out_prev
+    return (hs, state) if return_state else hs
+
+
 # --------------------------------------------------------------------------------------------
 def dense_nonneg(inputs, kernel):
     """DenseNonNegW.call, custom_layers.py:23-24 (use_bias=False, no activation)."""

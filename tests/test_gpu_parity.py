@@ -733,3 +733,98 @@ def test_end_to_end_enhancement_pipeline(dev):
         assert abs(snr_d[u] - O.snr_db(y, clean[u].astype(np.float64))) <= 1e-2
         assert abs(sdr_d[u] - O.sdr_db(y, clean[u].astype(np.float64), 32)) <= 1e-2
     assert m.sum() == sum(nfr) and x.shape[0] == sum(-(-f // maxlen) for f in nfr)
+
+
+# ------------------------------------------------------------------ KL / beta variant of the cell
+def _run_ista_cell(dev, P, alt, labels, N, K, divergence, beta=1.5, return_all_hidden=False,
+                   initial_state=None, want_state=False):
+    from drnmf_amd import ops
+    X = P["X"]
+    B, T, F = X.shape
+    stack = lambda name: np.stack([alt[k] for k in dict.fromkeys(labels[name])], 0)
+    logD, logA, logL = stack("log_D"), stack("log_alph"), stack("log_lam1")
+    desc = ops.make_desc(B, T, F, N, K, n_D=logD.shape[0], n_alph=logA.shape[0],
+                         alph_len=int(np.asarray(logA[0]).size), n_lam=logL.shape[0],
+                         return_all_hidden=return_all_hidden, divergence=divergence)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    params = ops.prepare_params(desc, t(logD), t(logA.reshape(logA.shape[0], -1)), t(logL.reshape(-1)))
+    fin = torch.empty((B, N), dtype=torch.float32, device=dev) if want_state else None
+    h = ops.cell_forward_ista(t(X), -1.0, params, desc, t(P["log_h0"]), beta=beta,
+                              initial_state=t(initial_state), final_state=fin)
+    torch.cuda.synchronize()
+    return (h.cpu().numpy(), fin.cpu().numpy()) if want_state else h.cpu().numpy()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, T=6, F=21, r=6, K=3),
+    dict(B=17, T=4, F=33, r=8, K=1),                          # K = 1, two row tiles
+    dict(B=5, T=5, F=65, r=20, K=4, untied=()),               # tied, F = 16 k + 1 (no side path here)
+    dict(B=4, T=3, F=513, r=100, K=2, untie_alph=True),
+    dict(B=40, T=3, F=34, r=17, K=2, ragged=False),
+])
+@pytest.mark.parametrize("divergence", ["kl", "beta"])
+def test_kl_beta_cell_matches_oracle(dev, cfg, divergence):
+    """The warm-started ISTA cell (drnmf_cell_forward_ista; the reference's ista_kl / ista_beta run
+    recurrently, tests/test_oracle.py pins the restatement to them) against the fp64 oracle."""
+    cfg = dict(cfg)
+    K = cfg.pop("K")
+    P, alt, labels, N = _problem(cfg.pop("B"), cfg.pop("T"), cfg.pop("F"), cfg.pop("r"), K,
+                                 ragged=cfg.pop("ragged", True), density=0.3, **cfg)
+    P["X"] = np.where(P["X"] == -1.0, -1.0, P["X"] + 0.05).astype(np.float32)   # keep x^ away from 0
+    layers = O.maps_factored(alt, labels, K)
+    for ah in (False, True):
+        h = _run_ista_cell(dev, P, alt, labels, N, K, divergence, return_all_hidden=ah)
+        ref = O.cell_forward_ista_warm(P["X"], layers, P["log_h0"], divergence=divergence,
+                                       beta=1.5, return_all_hidden=ah)
+        _check_h(h, ref)
+    init = np.abs(np.random.default_rng(0).standard_normal((P["X"].shape[0], N))).astype(np.float32)
+    h, fin = _run_ista_cell(dev, P, alt, labels, N, K, divergence, initial_state=init,
+                            want_state=True)
+    ref, rfin = O.cell_forward_ista_warm(P["X"], layers, P["log_h0"], divergence=divergence,
+                                         beta=1.5, initial_state=init, return_state=True)
+    _check_h(h, ref)
+    _check_h(fin, rfin)
+
+
+def test_kl_beta_cell_entry_points_are_kept_apart(dev):
+    from drnmf_amd import ops
+    P, alt, labels, N = _problem(2, 2, 21, 6, 2)
+    with pytest.raises(ValueError):             # the reference cell's entry refuses a KL descriptor
+        desc = ops.make_desc(2, 2, 21, N, 2, divergence="kl")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        prm = ops.prepare_params(desc, t(alt["log_D_0"][None]), t(alt["log_alph_0"].reshape(1, -1)),
+                                 t(alt["log_lam1"].reshape(-1)))
+        ops.cell_forward(t(P["X"]), -1.0, prm, desc, t(P["log_h0"]), (1.0, 0.0, 0.0))
+    with pytest.raises(ValueError):             # and the ISTA entry refuses an ED descriptor
+        desc = ops.make_desc(2, 2, 21, N, 2)
+        prm = ops.prepare_params(desc, t(alt["log_D_0"][None]), t(alt["log_alph_0"].reshape(1, -1)),
+                                 t(alt["log_lam1"].reshape(-1)))
+        ops.cell_forward_ista(t(P["X"]), -1.0, prm, desc, t(P["log_h0"]))
+
+
+def test_kl_cell_through_the_layer_surface(dev):
+    """build_unfolded_snmf(..., divergence='kl') (extension key): the model predicts with the KL
+    cell under the unchanged mask head; training is refused."""
+    from drnmf_amd import layers
+    B, T, F, r, K = 5, 7, 33, 10, 3
+    P = O.synth_problem(B, T, F, r, seed=4, ragged=True, density=0.3)
+    P["X"] = np.where(P["X"] == -1.0, -1.0, P["X"] + 0.05).astype(np.float32)
+    N = 2 * r
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph"], divergence="kl")
+    model = layers.build_unfolded_snmf(p, device=dev)
+    irm = model.predict_on_batch(P["X"])
+    w = model.get_weights()
+    names = ["log_h0"] + list(model.cell._alt.keys()) + ["kc", "kn"]
+    wd = dict(zip(names, w))
+    alt = {k: wd[k] for k in model.cell._alt.keys()}
+    labels = model.cell.maps_from_alt.labels_per_k
+    h = O.cell_forward_ista_warm(P["X"], O.maps_factored(alt, labels, K), wd["log_h0"],
+                                 divergence="kl")
+    ref, _, _ = O.head_forward(h, wd["kc"], wd["kn"])
+    assert np.mean((irm - ref) ** 2) <= MASK_MSE_TOL
+    with pytest.raises(NotImplementedError):
+        model.compile(lr=1e-3)
+    with pytest.raises(ValueError):
+        layers.build_unfolded_snmf(dict(p, divergence="is"), device=dev)

@@ -240,3 +240,29 @@ def test_sdr_oracle_is_the_least_squares_projection():
     clean = np.convolve(ref, [0.0, 0.0, 0.5, 0.25])[:n]
     assert O.sdr_db(clean, ref, flen) > 25.0          # only the truncated tail counts as error
     assert O.sdr_db(est, ref, flen) >= O.snr_db(est, ref) - 1e-9
+
+
+def test_warm_ista_cell_is_the_reference_iteration_run_recurrently():
+    """The KL / beta cell variant (oracle restatement) against the golden-pinned restatements of the
+    reference's ista_kl / ista_beta / ista_ed: frame t of a row = K iterations from that row's
+    previous output (tied parameters)."""
+    rng = np.random.default_rng(3)
+    B, T, F, r, K = 3, 4, 19, 5, 3
+    P = O.synth_problem(B, T, F, r, seed=2, density=0.3)
+    X = P["X"] + 0.05
+    N = 2 * r
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(4.0), lam1=np.float32(0.2))
+    alt, labels = O.build_alt(N, K, params, ())
+    layers = O.maps_factored(alt, labels, K)
+    Dn, ia, b = layers[0]
+    alph, lam = 1.0 / ia[0], -b[0] / ia[0]
+    for name, fn in (("kl", lambda x, H: O.ista_kl(x, Dn, H, lam, alph, K)),
+                     ("beta", lambda x, H: O.ista_beta(x, Dn, H, lam, alph, K, 1.5)),
+                     ("ed", lambda x, H: O.ista_ed(x, Dn, H, lam, alph, K))):
+        hs = O.cell_forward_ista_warm(X, layers, P["log_h0"], divergence=name, beta=1.5,
+                                      mask_value=np.nan)
+        H = np.tile(O.softplus(P["log_h0"].astype(np.float64))[:, None], (1, B))     # (N, B)
+        for t in range(T):
+            H = fn(X[:, t].astype(np.float64).T, H)
+            np.testing.assert_allclose(hs[:, t], H.T, rtol=1e-10, atol=1e-12)
