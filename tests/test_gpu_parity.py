@@ -761,6 +761,7 @@ def _run_ista_cell(dev, P, alt, labels, N, K, divergence, beta=1.5, return_all_h
     dict(B=5, T=5, F=65, r=20, K=4, untied=()),               # tied, F = 16 k + 1 (no side path here)
     dict(B=4, T=3, F=513, r=100, K=2, untie_alph=True),
     dict(B=40, T=3, F=34, r=17, K=2, ragged=False),
+    dict(B=250, T=2, F=513, r=1000, K=2, ragged=False, alph=400.0),      # row-blocked kernels
 ])
 @pytest.mark.parametrize("divergence", ["kl", "beta"])
 def test_kl_beta_cell_matches_oracle(dev, cfg, divergence):
