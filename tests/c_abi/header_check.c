@@ -1,0 +1,25 @@
+/* include/drnmf.h must be a plain C header: compiled with `gcc -std=c99 -Wall -Werror -pedantic
+ * -fsyntax-only` by tests/test_host.py.  Taking the address of every export also checks that each
+ * declaration is a complete prototype. */
+#include "drnmf.h"
+
+typedef void (*fn_t)(void);
+#define REF(f) (fn_t)(f)
+
+fn_t drnmf_all_exports[] = {
+    REF(drnmf_version), REF(drnmf_create), REF(drnmf_destroy), REF(drnmf_last_error),
+    REF(drnmf_params_bytes), REF(drnmf_prepare_params), REF(drnmf_cell_workspace_bytes),
+    REF(drnmf_cell_forward), REF(drnmf_cell_forward_stateful), REF(drnmf_cell_forward_ista),
+    REF(drnmf_cell_profile), REF(drnmf_dense_params_bytes), REF(drnmf_dense_prepare_params),
+    REF(drnmf_dense_workspace_bytes), REF(drnmf_dense_cell_forward), REF(drnmf_padded_f),
+    REF(drnmf_head_forward), REF(drnmf_loss_head_workspace_bytes), REF(drnmf_loss_head_backward),
+    REF(drnmf_snmf_cost_head_backward), REF(drnmf_cell_backward_workspace_bytes),
+    REF(drnmf_cell_backward), REF(drnmf_adam_step), REF(drnmf_sumsq),
+    REF(drnmf_ista_workspace_bytes), REF(drnmf_ista_forward), REF(drnmf_mu_workspace_bytes),
+    REF(drnmf_mu_forward), REF(drnmf_snmf_train_workspace_bytes), REF(drnmf_snmf_train_init),
+    REF(drnmf_snmf_train_step), REF(drnmf_stft_frames), REF(drnmf_stft_mag), REF(drnmf_stft),
+    REF(drnmf_istft_workspace_bytes), REF(drnmf_istft_masked), REF(drnmf_snr),
+    REF(drnmf_sdr_workspace_bytes), REF(drnmf_sdr_corr), REF(drnmf_sdr_project),
+    REF(drnmf_divide_a_by_aplusb), REF(drnmf_add), REF(drnmf_loss_forward_workspace_bytes),
+    REF(drnmf_loss_forward), REF(drnmf_wav_int16_workspace_bytes), REF(drnmf_wav_int16),
+};

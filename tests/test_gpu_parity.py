@@ -829,3 +829,39 @@ def test_kl_cell_through_the_layer_surface(dev):
         model.compile(lr=1e-3)
     with pytest.raises(ValueError):
         layers.build_unfolded_snmf(dict(p, divergence="is"), device=dev)
+
+
+def test_plain_c_host_program_over_the_c_abi(dev, tmp_path):
+    """tests/c_abi/cell_smoke.c: a C99 host program (gcc, libamdhip64 + libdrnmf.so, no Python or
+    torch in the process) runs prepare_params + cell_forward and reproduces the oracle."""
+    import os
+    import shutil
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("needs gcc and the ROCm headers")
+    K = 3
+    P, alt, labels, N = _problem(5, 6, 33, 8, K, ragged=True)
+    ref = _oracle_cell(P, alt, labels, K)
+    B, T, F = P["X"].shape
+    u = O.u_scalars(alt, np.float32)
+    blob = struct.pack("<5i3ff", B, T, F, N, K, float(u[0]), float(u[1]), float(u[2]), -1.0)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).tobytes()
+    blob += f32(P["X"]) + f32(np.stack([alt["log_D_%d" % k] for k in range(K)]))
+    blob += f32(np.stack([alt["log_alph_%d" % k] for k in range(K)])) + f32(alt["log_lam1"])
+    blob += f32(P["log_h0"]) + f32(ref)
+    prob = tmp_path / "problem.bin"
+    prob.write_bytes(blob)
+    exe = str(tmp_path / "cell_smoke")
+    libdir = os.path.join(root, "dr-nmf_amd")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__",
+                    "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", "cell_smoke.c"), "-L/opt/rocm/lib",
+                    "-lamdhip64", "-L" + libdir, "-ldrnmf", "-lm", "-Wl,-rpath,/opt/rocm/lib",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe, str(prob)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    err, mx = (float(out.stdout.split(k)[1].split()[0]) for k in ("max_abs_err", "max_ref"))
+    assert mx > 0 and err <= H_TOL * mx, out.stdout

@@ -261,3 +261,20 @@ def test_dense_matrices_of_generic_layer_configurations():
     assert g.compute_output_shape((5, 3, F)) == (5, N)          # return_sequences=False
     with pytest.raises(ValueError):
         g._initializer("he_weird", (3, 3))
+
+
+def test_header_is_plain_c_and_lists_every_export():
+    """include/drnmf.h compiles as C99 (-Wall -Werror -pedantic) and tests/c_abi/header_check.c,
+    which takes the address of every declaration, names exactly the exports of the ctypes table."""
+    import re
+    import shutil
+    import subprocess
+    from drnmf_amd import _capi
+    src = os.path.join(ROOT, "tests", "c_abi", "header_check.c")
+    names = set(re.findall(r"REF\((drnmf_\w+)\)", open(src).read()))
+    assert names == set(_capi.SIGNATURES), names ^ set(_capi.SIGNATURES)
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
+                    "-I" + os.path.join(ROOT, "include"), src], check=True)
