@@ -381,7 +381,7 @@ def test_ista_bin_counts_around_the_tile_size(dev, F, name):
     assert np.max(np.abs(got - want)) <= 2e-5 * max(np.max(np.abs(want)), 1e-6)
 
 
-@pytest.mark.parametrize("beta", [2.0, 1.0, 1.5])
+@pytest.mark.parametrize("beta", [2.0, 1.0, 1.5, 0.0, 0.5, 3.0])
 def test_mu_inference_and_irm_vs_oracle(dev, beta):
     from drnmf_amd import ops
     rng = np.random.default_rng(6)
@@ -433,7 +433,8 @@ def test_stft_mag_vs_oracle(dev, N, hop, nsampl, int16):
 
 
 # ------------------------------------------------------------------ sparse-NMF dictionary training
-@pytest.mark.parametrize("beta,cf", [(2.0, "ed"), (1.0, "kl"), (1.5, None)])
+@pytest.mark.parametrize("beta,cf", [(2.0, "ed"), (1.0, "kl"), (1.5, None), (0.0, "is"),
+                                     (0.5, None), (3.0, None)])
 def test_snmf_training_matches_oracle(dev, beta, cf):
     """W/H multiplicative updates + renormalisation + objective vs the numpy restatement of
     sparse_nmf_gpu.m (same explicit inits), incl. a frozen half of the dictionary."""
