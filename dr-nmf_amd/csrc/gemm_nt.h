@@ -79,31 +79,52 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Ep
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
+    // The loads of tile kt+1 are issued before tile kt's MFMAs and first consumed after them
+    // (swrite).  In the vector path the out-of-range zeroing is therefore applied in swrite, not
+    // at the load: a select right behind the load made the compiler wait for every load (vmcnt)
+    // ahead of the MFMA phase, i.e. the global-load latency was exposed once per k-tile.
     f32x4 ra[4], rb[4];
+    auto raw4 = [&](const float* base, int64_t row, int64_t nrows, int64_t ld, int k) {
+        const int64_t rr = row < nrows ? row : nrows - 1;
+        const int kc = k < g.K ? k : 0;
+        return *(const f32x4*)(base + rr * ld + kc);
+    };
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = load4<VEC>(g.A, m0 + srow + 32 * i, g.M, g.lda, k0 + sk, g.K);
-            rb[i] = load4<VEC>(g.Bt, n0 + srow + 32 * i, g.N, g.ldb, k0 + sk, g.K);
+            if (VEC) {
+                ra[i] = raw4(g.A, m0 + srow + 32 * i, g.M, g.lda, k0 + sk);
+                rb[i] = raw4(g.Bt, n0 + srow + 32 * i, g.N, g.ldb, k0 + sk);
+            } else {
+                ra[i] = load4<false>(g.A, m0 + srow + 32 * i, g.M, g.lda, k0 + sk, g.K);
+                rb[i] = load4<false>(g.Bt, n0 + srow + 32 * i, g.N, g.ldb, k0 + sk, g.K);
+            }
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int buf, int k0) {
         float* As = lds + buf * 2 * BM * LDS_LD;
         float* Bs = As + BM * LDS_LD;
+        const bool kok = k0 + sk < g.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(f32x4*)(As + (srow + 32 * i) * LDS_LD + sk) = ra[i];
-            *(f32x4*)(Bs + (srow + 32 * i) * LDS_LD + sk) = rb[i];
+            f32x4 va = ra[i], vb = rb[i];
+            if (VEC) {
+                if (!(kok && m0 + srow + 32 * i < g.M)) va = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(kok && n0 + srow + 32 * i < g.N)) vb = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            *(f32x4*)(As + (srow + 32 * i) * LDS_LD + sk) = va;
+            *(f32x4*)(Bs + (srow + 32 * i) * LDS_LD + sk) = vb;
         }
     };
 
     const int nkt = (g.K + BK - 1) / BK;
     gload(0);
-    swrite(0);
+    swrite(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) gload((kt + 1) * BK);   // in flight during this tile's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         const float* As = lds + buf * 2 * BM * LDS_LD + (wm * 64 + li) * LDS_LD + 4 * kk;
         const float* Bs = lds + buf * 2 * BM * LDS_LD + BM * LDS_LD + (wn * 64 + li) * LDS_LD +
                           4 * kk;
@@ -121,7 +142,8 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Ep
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
             }
         }
-        if (kt + 1 < nkt) swrite(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nkt) swrite(buf ^ 1, (kt + 1) * BK);
         __syncthreads();
     }
 
