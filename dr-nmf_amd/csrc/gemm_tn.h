@@ -73,32 +73,52 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
+    // (vector path: the out-of-range zeroing is applied when the staged tile is written to LDS,
+    // not right behind the load, so that the loads stay in flight under the MFMAs -- gemm_nt.h)
     f32x4 ra[4], rb[4];
+    auto raw4 = [&](const float* base, int64_t k, int64_t ld, int c, int C) {
+        const int64_t kr2 = k < g.Kdim ? k : g.Kdim - 1;
+        const int cc = c < C ? c : 0;
+        return *(const f32x4*)(base + kr2 * ld + cc);
+    };
     auto gload = [&](int64_t kt) {
         const int64_t k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = load4<VEC>(g.A, k0 + kr + 8 * i, g.Kdim, g.lda, m0 + c4, g.M);
-            rb[i] = load4<VEC>(g.B, k0 + kr + 8 * i, g.Kdim, g.ldb, n0 + c4, g.N);
+            if (VEC) {
+                ra[i] = raw4(g.A, k0 + kr + 8 * i, g.lda, m0 + c4, g.M);
+                rb[i] = raw4(g.B, k0 + kr + 8 * i, g.ldb, n0 + c4, g.N);
+            } else {
+                ra[i] = load4<false>(g.A, k0 + kr + 8 * i, g.Kdim, g.lda, m0 + c4, g.M);
+                rb[i] = load4<false>(g.B, k0 + kr + 8 * i, g.Kdim, g.ldb, n0 + c4, g.N);
+            }
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int buf, int64_t kt) {
         float* As = lds + buf * 2 * BK * BM;
         float* Bs = As + BK * BM;
+        const int64_t k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(f32x4*)(As + (kr + 8 * i) * BM + c4) = ra[i];
-            *(f32x4*)(Bs + (kr + 8 * i) * BN + c4) = rb[i];
+            f32x4 va = ra[i], vb = rb[i];
+            if (VEC) {
+                const bool kok = k0 + kr + 8 * i < g.Kdim;
+                if (!(kok && m0 + c4 < g.M)) va = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(kok && n0 + c4 < g.N)) vb = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            *(f32x4*)(As + (kr + 8 * i) * BM + c4) = va;
+            *(f32x4*)(Bs + (kr + 8 * i) * BN + c4) = vb;
         }
     };
 
     if (kt0 < kt1) {
         gload(kt0);
-        swrite(0);
+        swrite(0, kt0);
         __syncthreads();
         for (int64_t kt = kt0; kt < kt1; ++kt) {
             const int buf = (int)((kt - kt0) & 1);
             if (kt + 1 < kt1) gload(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
             const float* As = lds + buf * 2 * BK * BM + kk * BM + wm * 64 + li;
             const float* Bs = lds + buf * 2 * BK * BM + BK * BM + kk * BN + wn * 64 + li;
 #pragma unroll
@@ -110,7 +130,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
-            if (kt + 1 < kt1) swrite(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < kt1) swrite(buf ^ 1, kt + 1);
             __syncthreads();
         }
     }
