@@ -147,7 +147,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Ep
         __syncthreads();
     }
 
-    // epilogue: register v of lane l holds row (v&3) + 8*(v>>2) + 4*(l>>5), column l&31
+    // epilogue: register v of lane l holds row (v&3) + 8*(v>>2) + 4*(l>>5), column l&31.
+    // Row indices are formed in 32 bits (launch() refuses M >= 2^31): the functors' row * ld then
+    // is one 32 x 32 -> 64-bit multiply-add instead of a 64 x 32-bit product per element.
+    const int M32 = (int)g.M, m032 = (int)m0;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -157,14 +160,14 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Ep
             f32x2 pv[16];
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                int64_t row = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                row = row < g.M ? row : g.M - 1;
+                int row = m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+                row = row < M32 ? row : M32 - 1;
                 pv[v] = epi.pre(row, col);
             }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int64_t row = m0 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                if (row < g.M) epi(row, col, acc[a][b][v], pv[v]);
+                const int row = m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+                if (row < M32) epi(row, col, acc[a][b][v], pv[v]);
             }
         }
 }
@@ -174,7 +177,7 @@ inline hipError_t launch(const Operands& g, const Epi& epi, hipStream_t stream) 
     const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) &&
                      (((uintptr_t)g.A & 15) == 0) && (((uintptr_t)g.Bt & 15) == 0);
     const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    if (tiles <= 0 || tiles > 0x7fffffff) return hipErrorInvalidValue;
+    if (tiles <= 0 || tiles > 0x7fffffff || g.M > 0x7fffff00) return hipErrorInvalidValue;
     if (vec)
         hipLaunchKernelGGL((gemm_nt_kernel<Epi, true>), dim3((unsigned)tiles), dim3(256), 0, stream,
                            g, epi);
