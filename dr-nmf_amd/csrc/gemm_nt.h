@@ -12,6 +12,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 namespace gemm {
@@ -151,25 +153,30 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Ep
     // Row indices are formed in 32 bits (launch() refuses M >= 2^31): the functors' row * ld then
     // is one 32 x 32 -> 64-bit multiply-add instead of a 64 x 32-bit product per element.
     const int M32 = (int)g.M, m032 = (int)m0;
+    auto tile_epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;   // every row of the tile is inside M
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + wn * 64 + b * 32 + li;
-            if (col >= g.N) continue;
-            f32x2 pv[16];
+            for (int b = 0; b < 2; ++b) {
+                const int col = n0 + wn * 64 + b * 32 + li;
+                if (col >= g.N) continue;
+                f32x2 pv[16];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                int row = m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                row = row < M32 ? row : M32 - 1;
-                pv[v] = epi.pre(row, col);
+                for (int v = 0; v < 16; ++v) {
+                    int row = m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+                    if (!FULL) row = row < M32 ? row : M32 - 1;
+                    pv[v] = epi.pre(row, col);
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+                    if (FULL || row < M32) epi(row, col, acc[a][b][v], pv[v]);
+                }
             }
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                if (row < M32) epi(row, col, acc[a][b][v], pv[v]);
-            }
-        }
+    };
+    if (m032 + BM <= M32) tile_epilogue(std::true_type{});
+    else tile_epilogue(std::false_type{});
 }
 
 template <class Epi>
