@@ -36,6 +36,8 @@
 // latency; all of a wave's operand loads are issued before its first MFMA.
 #include "cell_shared.h"
 
+#include <type_traits>
+
 namespace {
 
 struct CellAArgs {
@@ -73,7 +75,8 @@ struct CellAArgs {
 // What the operand addresses need is passed as leading scalar arguments (preloaded into SGPRs by
 // the command processor, see cell_b_kernel); the rest of the struct is fetched by scalar loads that
 // are not on the path to the first operand load.
-template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN, bool HALF = false>
+template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN, bool HALF = false,
+          bool LATE = false>
 __global__ void __launch_bounds__(64 * NW_A)
 cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, int Fp_, int Np_,
               int numA_, int nchunks_, const CellAArgs a_in) {
@@ -174,29 +177,32 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // keep it (and the wait for those loads) behind the first operand loads
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- epilogue operands (tiny, needed last; issued behind the GEMM operands) --------------
+    // ---- epilogue operands (tiny, needed last).  Their loads are issued behind the FIRST chunk's
+    // MFMAs (load_epilogue_operands below): issued ahead of the GEMM loop they sat between the
+    // prefetched operand chunks and the first MFMA in the in-order vmcnt count, so that the first
+    // MFMA waited for them (and for all prefetched chunks) instead of for chunk 0 alone.
     const int erow = (tid & 255) >> 4, ec = (tid & 15) * 2;
     const int n = n0 + ec;
     const size_t hoff0 = ((size_t)mb0 * NAC + ac0 + (ec >> 4)) * 256 + hp_pos(erow, ec & 15);
     const size_t hstep = (size_t)NAC * 256;                                        // per row block
-    const f32x2 ia = *(const f32x2*)(a.inv_alpha + n);
-    const f32x2 bs = *(const f32x2*)(a.bias + n);
-    if (!IS_FIRST && WRITE_OUT) {
-        t = *a.t_rd;
-        if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
-    }
+    f32x2 ia, bs;
     f32x2 hp[RB];
     float ps[RB];
     bool vld[RB];
     // tail bins (F = 16*nchunks + ntail): residual r_tail = x_tail - sum over atom blocks of the
-    // partial dot products left by the previous layer.  Only the LOADS are issued here; they are
-    // reduced after the MFMA loop (consuming them now would force an in-order vmcnt wait on every
-    // operand load issued so far).
+    // partial dot products left by the previous layer.  Only the LOADS are issued; they are
+    // reduced after the MFMA loop (consuming them earlier would force an in-order vmcnt wait on
+    // every operand load issued so far).
     float xt[RB][MAX_TAIL];
     float qv[RB][MAX_TAIL][4];
-    // (unconditional loads: a guarded load here makes hipcc wait for EVERY outstanding load
-    // before the GEMM loop; without tail bins the values are never used)
     f32x2 dt[MAX_TAIL], dtn[MAX_TAIL];   // tail rows of this layer's and the next layer's dictionary
+    auto load_epilogue_operands = [&]() {
+    ia = *(const f32x2*)(a.inv_alpha + n);
+    bs = *(const f32x2*)(a.bias + n);
+    if (!IS_FIRST && WRITE_OUT) {
+        t = *a.t_rd;
+        if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
+    }
 #pragma unroll
     for (int i = 0; i < MAX_TAIL; ++i) {
         dt[i] = *(const f32x2*)(a.Dtail + (size_t)i * Np + n);
@@ -244,6 +250,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             }
         }
     }
+    };
 
     // ---- GEMM:  g[16*RB x 32] = r[16*RB x F] . Dn[F x 32] ---------------------------------------
     auto compute_chunk = [&](int base, int g) {
@@ -290,17 +297,20 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // wave owns a whole number of groups (all 2^k+1 STFT sizes from 512 up: nchunks % 16 == 0)
     // the last group is peeled and issues only the one load that is still needed.
     const bool exact = (a.nchunks % (NW_A * G)) == 0;
-    int base = 0;
-    for (; base + (exact ? G : 0) < per_wave; base += G) {
+    auto full_group = [&](int base, auto epi_tag) {      // every chunk's load runs PF chunks ahead
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             load_chunk(base + g + PF, (g + PF) % G);
             __builtin_amdgcn_sched_barrier(0);
             compute_chunk(base, g);
             __builtin_amdgcn_sched_barrier(0);
+            if (decltype(epi_tag)::value && g == 0) {
+                load_epilogue_operands();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-    }
-    if (exact) {
+    };
+    auto last_group = [&](int base) {                     // a whole last group: one load is left
         load_chunk(base + PF, PF % G);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -308,6 +318,35 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             compute_chunk(base, g);
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    // Where the epilogue operand loads go (LATE, picked per shape by pick_a_func).  With two
+    // groups per wave (F = 513) issuing them behind the first chunk's MFMAs measures 310 -> 316 k
+    // frames/s at the headline shape (N = 200: +1.4 %); a single group (F = 257: -1 %) and long
+    // contractions (F = 1025: -5 %) keep them ahead of the loop, where they overlap the initial
+    // load latency.  Both orders in ONE kernel behind a runtime switch cost up to 35 % at other
+    // shapes, hence the template parameter.  Measured, not derived: the same order without the
+    // (unreached) single-group branch below compiles to a kernel that gains nothing (309.9 k).
+    if (LATE) {
+        if (exact && per_wave <= G) {      // (not reached with the shapes pick_a_func sends here)
+            load_chunk(PF, PF % G);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                __builtin_amdgcn_sched_barrier(0);
+                compute_chunk(0, g);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 0) load_epilogue_operands();
+            }
+        } else {
+            full_group(0, std::true_type{});
+            int base = G;
+            for (; base + (exact ? G : 0) < per_wave; base += G) full_group(base, std::false_type{});
+            if (exact && base < per_wave) last_group(base);
+        }
+    } else {
+        load_epilogue_operands();
+        int base = 0;
+        for (; base + (exact ? G : 0) < per_wave; base += G) full_group(base, std::false_type{});
+        if (exact) last_group(base);
     }
 
     // ---- cross-wave reduction of the 4 F-splits through LDS --------------------------------
@@ -503,12 +542,12 @@ resid_div_kernel(const float* __restrict__ xp, float* __restrict__ r, const int*
     r[i] = g;
 }
 
-template <int G, int KS, int RB, bool AH, bool HALF>
+template <int G, int KS, int RB, bool AH, bool HALF, bool LATE = false>
 void* a_func(bool first, bool last) {
-    if (first && last) return (void*)&cell_a_kernel<G, KS, RB, true, true, AH, HALF>;
-    if (first) return (void*)&cell_a_kernel<G, KS, RB, true, false, AH, HALF>;
-    if (last) return (void*)&cell_a_kernel<G, KS, RB, false, true, AH, HALF>;
-    return (void*)&cell_a_kernel<G, KS, RB, false, false, AH, HALF>;
+    if (first && last) return (void*)&cell_a_kernel<G, KS, RB, true, true, AH, HALF, LATE>;
+    if (first) return (void*)&cell_a_kernel<G, KS, RB, true, false, AH, HALF, LATE>;
+    if (last) return (void*)&cell_a_kernel<G, KS, RB, false, true, AH, HALF, LATE>;
+    return (void*)&cell_a_kernel<G, KS, RB, false, false, AH, HALF, LATE>;
 }
 
 template <int KS, int RB, bool AH, bool HALF>
@@ -516,6 +555,9 @@ void* a_func_g(int per_wave, bool first, bool last) {
     // G operand slots; operand registers G * (4*KS*RB + 8)
     if (per_wave <= 2) return a_func<2, KS, RB, AH, HALF>(first, last);
     // (8 slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch)
+    // two groups per wave (F = 513), one row block, fp32: epilogue operand loads behind the first chunk
+    if (RB == 1 && !HALF && per_wave > 4 && per_wave <= 8)
+        return a_func<4, KS, RB, AH, HALF, (RB == 1 && !HALF)>(first, last);
     return a_func<4, KS, RB, AH, HALF>(first, last);
 }
 
