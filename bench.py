@@ -281,6 +281,32 @@ def dense_graph_bench(torch, dev, F, r, K, B, frames=40):
     return res
 
 
+def stft_bench(torch, dev, n_sig=64, seconds=10.0, N=1024, hop=256, reps=10):
+    """The STFT-magnitude front end alone: white-noise int16 PCM, 16 kHz, 10 s per
+    signal -> |STFT| (util.py:171-201, audio_dataset.py:22-23,194).  HBM-bound: bytes = PCM in +
+    magnitudes out."""
+    from drnmf_amd import ops
+    nsampl = int(16000 * seconds)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    pcm = torch.randint(-20000, 20000, (n_sig, nsampl), generator=g, device=dev,
+                        dtype=torch.int32).to(torch.int16)
+    mag = ops.stft_mag(pcm, N=N, hop=hop)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        mag = ops.stft_mag(pcm, N=N, hop=hop)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    frames = mag.shape[0] * mag.shape[1]
+    nbytes = pcm.numel() * 2 + mag.numel() * 4
+    return {"signals": n_sig, "seconds_each": seconds, "N_fft": N, "hop": hop,
+            "frames_per_s": frames / sec, "us": sec * 1e6, "GBps_in_plus_out": nbytes / sec / 1e9,
+            "frac_of_8TBps": nbytes / sec / 8e12}
+
+
 def run_guarded(fn, timeout_s, on_timeout):
     """fn() with a watchdog thread: exceptions become {'error': ...}; if fn has not returned after
     timeout_s the watchdog calls on_timeout() (which is expected to end the process)."""
@@ -478,6 +504,7 @@ def main():
         if not a.no_ista:
             extra["ista_frame_parallel"] = safe(ista_bench, torch, dev, F, N, K, W)
             extra["mu_inference"] = safe(mu_bench, torch, dev, F, N, W)
+            extra["stft_front_end"] = safe(stft_bench, torch, dev)
         if not a.no_slab and world == 1:
             extra["inference_slab_250"] = safe(slab_bench, torch, dev, F, r, K, T)
             extra["reference_op_graph_dense_kernel"] = safe(dense_graph_bench, torch, dev, F, r, K, B)
