@@ -6,30 +6,55 @@
 // librosa 0.5.1 conjugates the spectrum; the magnitude this path produces is unaffected.
 //
 // One workgroup per (signal, frame): window + zero-padded framing on load, an in-LDS radix-2
-// FFT (bit-reversed load, log2 N butterfly stages; window and twiddles from per-size tables), and the
+// FFT (bit-reversed load, two butterfly stages per pass; window and twiddles from per-size tables), and the
 // magnitude of bins 0..N/2 written as one coalesced row.  fp32 arithmetic as in the reference (scipy
 // fftpack on float32 input).  Measured (bench.py extra.stft_front_end, 64 x 10 s at 16 kHz, N = 1024,
-// hop = 256): 276 us = 146 M frames/s, 374 GB/s in + out -- 4.7 % of the HBM rate: the radix-2 stages
-// are LDS-latency / barrier bound (ten stages of two butterflies per thread), not memory bound; the
-// front end is ~470x faster than the recurrent cell consumes frames, so it was left at that.
+// hop = 256): 217 us = 186 M frames/s, 475 GB/s in + out -- 5.9 % of the HBM rate: the FFT passes are
+// LDS-latency / barrier bound (two radix-2 stages per pass: 293 -> 217 us together with the tables),
+// not memory bound; the front end is ~600x faster than the recurrent cell consumes frames.
 #include "common.h"
 
 namespace {
 
 // in-place radix-2 DIT FFT of N complex points in LDS (input already bit-reversed); tw[k] =
 // e^{-2 pi i k / N}, k < N/2
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+
 __device__ __forceinline__ void fft_lds(float2* buf, const float2* tw, int N, int logN, int tid) {
-    for (int s = 1; s <= logN; ++s) {
-        const int half = 1 << (s - 1);
-        const int tstride = N >> s;
+    int s = 1;
+    if (logN & 1) {                      // odd log2 N: one radix-2 stage first
         for (int b = tid; b < N / 2; b += 256) {
+            const float2 u = buf[2 * b], v = buf[2 * b + 1];      // twiddle 1
+            buf[2 * b] = make_float2(u.x + v.x, u.y + v.y);
+            buf[2 * b + 1] = make_float2(u.x - v.x, u.y - v.y);
+        }
+        __syncthreads();
+        s = 2;
+    }
+    // two radix-2 stages (s, s+1) per pass, the intermediate values in registers: half the LDS
+    // round trips and barriers of the stage-by-stage loop (the kernel is bound by those, not by
+    // memory); the butterflies and their order are exactly the radix-2 ones
+    for (; s < logN; s += 2) {
+        const int half = 1 << (s - 1);
+        const int ts1 = N >> s, ts2 = N >> (s + 1);
+        for (int b = tid; b < N / 4; b += 256) {
             const int pos = b & (half - 1);
-            const int i0 = ((b >> (s - 1)) << s) + pos, i1 = i0 + half;
-            const float2 w = tw[pos * tstride];
-            const float2 u = buf[i0], v = buf[i1];
-            const float2 t = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-            buf[i0] = make_float2(u.x + t.x, u.y + t.y);
-            buf[i1] = make_float2(u.x - t.x, u.y - t.y);
+            const int base = ((b >> (s - 1)) << (s + 1)) + pos;
+            const float2 w1 = tw[pos * ts1], w2 = tw[pos * ts2], w3 = tw[(pos + half) * ts2];
+            const float2 p0 = buf[base], p1 = buf[base + half], p2 = buf[base + 2 * half],
+                         p3 = buf[base + 3 * half];
+            const float2 t1 = cmul(p1, w1), t3 = cmul(p3, w1);
+            const float2 a0 = make_float2(p0.x + t1.x, p0.y + t1.y);
+            const float2 a1 = make_float2(p0.x - t1.x, p0.y - t1.y);
+            const float2 a2 = make_float2(p2.x + t3.x, p2.y + t3.y);
+            const float2 a3 = make_float2(p2.x - t3.x, p2.y - t3.y);
+            const float2 u2 = cmul(a2, w2), u3 = cmul(a3, w3);
+            buf[base] = make_float2(a0.x + u2.x, a0.y + u2.y);
+            buf[base + 2 * half] = make_float2(a0.x - u2.x, a0.y - u2.y);
+            buf[base + half] = make_float2(a1.x + u3.x, a1.y + u3.y);
+            buf[base + 3 * half] = make_float2(a1.x - u3.x, a1.y - u3.y);
         }
         __syncthreads();
     }
