@@ -406,6 +406,8 @@ def test_mu_inference_and_irm_vs_oracle(dev, beta):
 
 # ------------------------------------------------------------------ STFT-magnitude front end
 @pytest.mark.parametrize("N,hop,nsampl,int16", [(64, 16, 1000, False), (512, 128, 16000, True),
+                                                (128, 32, 3000, False), (2048, 512, 9999, True),
+                                                (4096, 2048, 20000, False),
                                                 (1024, 512, 40000, True), (1024, 256, 777, False),
                                                 (4096, 1024, 20000, True)])
 def test_stft_mag_vs_oracle(dev, N, hop, nsampl, int16):
