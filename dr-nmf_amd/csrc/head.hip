@@ -49,14 +49,23 @@ struct HeadArgs {
     int64_t rows, ld_h;
     int h_off, F, Fp, r, rp, square;
     int mode;   // 0: exp(log(1e-7+A) - log(1e-7+A+B)) (custom_layers.py:44); 1: A/(1e-9+A+B) (enhance.py:852)
+    int ncol;   // column workgroups per row block (set by launch_head)
 };
 
 // workgroup = 4 waves x 32 rows; each wave owns 2 row tiles x FT bin tiles x {A, Bn}.
 template <int FT, bool ALIGNED>
 __global__ void __launch_bounds__(256) head_kernel(const HeadArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, q = l >> 4;
-    const int64_t rowbase = (int64_t)blockIdx.x * 128 + w * 32;
-    const int f0 = blockIdx.y * FT * 16;
+    // 1-D grid, XCD-aware: workgroup id -> (XCD slot = id % 8, column = (id / 8) % ncol, group =
+    // id / (8 ncol)), row block = 8 group + slot.  The ncol workgroups that read the same 128 rows
+    // of `hidden` (1 MB at N = 2000) then run on ONE XCD and are dispatched next to each other, so
+    // the rows come from HBM once instead of once per column (row-major ids: 11 x 1 GB at C2).
+    const int ncol = a.ncol;
+    const unsigned id = blockIdx.x;
+    const int col = (int)((id >> 3) % (unsigned)ncol);
+    const int64_t rowblock = (int64_t)(id / (8u * (unsigned)ncol)) * 8 + (id & 7);
+    const int64_t rowbase = rowblock * 128 + w * 32;
+    const int f0 = col * FT * 16;
     if (rowbase >= a.rows) return;
 
     const float* hrow[2];
@@ -155,7 +164,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadArgs a) {
         }
 }
 
-void launch_head(const HeadArgs& a, hipStream_t stream) {
+void launch_head(const HeadArgs& a, hipStream_t stream) {   // (rows < 2^31 * 16: checked by the callers' row counts)
     const bool aligned = (a.ld_h % 4 == 0) && (a.h_off % 4 == 0) && (a.r % 4 == 0) &&
                          (((uintptr_t)a.hidden & 15) == 0);
     const int nt = a.Fp / 16;
@@ -163,9 +172,12 @@ void launch_head(const HeadArgs& a, hipStream_t stream) {
     int FT = 4, best = round_up(nt, 4);
     if (round_up(nt, 3) < best) { FT = 3; best = round_up(nt, 3); }
     if (round_up(nt, 2) < best) { FT = 2; }
-    dim3 grid((unsigned)((a.rows + 127) / 128), (unsigned)((nt + FT - 1) / FT));
+    HeadArgs a2 = a;
+    a2.ncol = (nt + FT - 1) / FT;
+    const int64_t rowblocks = (a.rows + 127) / 128;
+    dim3 grid((unsigned)(((rowblocks + 7) / 8) * 8 * a2.ncol));
 #define LAUNCH_HEAD(FT_, AL_) \
-    hipLaunchKernelGGL((head_kernel<FT_, AL_>), grid, dim3(256), 0, stream, a)
+    hipLaunchKernelGGL((head_kernel<FT_, AL_>), grid, dim3(256), 0, stream, a2)
     if (aligned) {
         if (FT == 4) LAUNCH_HEAD(4, true); else if (FT == 3) LAUNCH_HEAD(3, true);
         else LAUNCH_HEAD(2, true);
