@@ -233,7 +233,12 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     const int tiles = (W.Bp / (ROWS * W.RB)) * W.nft_main;
     const int nchN = W.Np / 16;
     int KS = 1;
-    while (KS < (W.RB > 1 ? 2 : MAX_KS) && tiles * KS < 224 && nchN / (KS * 2) >= 4) KS *= 2;
+    // (measured, frames/s with 2 / 4 / 8 ranges at N = 2000: B=16 F=257 481k / 514k / 495k; B=16 F=513
+    // 87k / 90k / 76k; B=32 F=257 931k / 991k / 943k and the training step 48.3 / 46.4 / 48.4 ms;
+    // B=32 F=513 166k / 171k / -; B=48 242k / 231k / -; B=64 291k / 279k / -: never more than 4, and
+    // the smallest count that gives ~192 workgroups -- each extra range is another residual partial
+    // for every cell_a workgroup to read)
+    while (KS < (W.RB > 1 ? 2 : 4) && tiles * KS < 192 && nchN / (KS * 2) >= 4) KS *= 2;
     if (const char* e = getenv("DRNMF_KS")) {   // tuning aid: force the number of atom ranges
         const int v = atoi(e);
         if ((v == 1 || v == 2 || v == 4 || v == 8) && (W.RB == 1 || v <= 2) && nchN / v >= 1) KS = v;
