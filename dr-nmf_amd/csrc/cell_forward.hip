@@ -557,7 +557,8 @@ void* a_func_g(int per_wave, bool first, bool last) {
     // (8 slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch)
     // two groups per wave (F = 513), one row block, fp32: epilogue operand loads behind the first chunk
     bool late = RB == 1 && !HALF && per_wave > 4 && per_wave <= 8;
-    if (const char* e = getenv("DRNMF_LATE")) late = late && atoi(e) != 0;   // tuning aid
+    if (const char* e = getenv("DRNMF_LATE"))   // tuning aid: 0 = never, 2 = whenever instantiated
+        late = atoi(e) == 2 ? (RB == 1 && !HALF && per_wave > 2) : (late && atoi(e) != 0);
     if (late) return a_func<4, KS, RB, AH, HALF, (RB == 1 && !HALF)>(first, last);
     return a_func<4, KS, RB, AH, HALF>(first, last);
 }
