@@ -2,17 +2,24 @@
 """Benchmark of the DR-NMF hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+          --master-port P bench.py --gpus N ...; a bare `python bench.py --gpus N` starts exactly that
+          as a child process before anything touches the GPU and relays its output)
 
-Workload (BASELINE.json configs[1]): K=25 unrolled SNMF forward (recurrent cell + mask head),
-dictionary 513x2000 (1000 speech + 1000 noise atoms, untied per layer as the shipped configs do),
-synthetic 513x2000-frame spectrograms, batch 64 per GPU.  One step = one forward over the batch,
-inputs resident in HBM.  Utterances shard over GPUs with no data-path collective (weak scaling:
-64 utterances per GPU).  Prints ONE JSON line on rank 0.
+Metric (BASELINE.json): STFT frames/sec (fwd+bwd), 513-bin x 2000-frame, K=25 unrolls.
+Workload (BASELINE.json configs[1] shape): dictionary 513x2000 (1000 speech + 1000 noise atoms,
+log_D / log_alph untied per layer as the shipped configs do), synthetic 513-bin x 2000-frame
+spectrograms, 64 utterances per GPU, inputs resident in HBM.  One step = forward (recurrent cell +
+mask head) + loss + BPTT + Adam over the batch (`train_on_batch`); with N > 1 GPUs every rank holds
+64 utterances of its own (weak scaling) and the step contains the ONE collective of the path, the
+all-reduce of the flat gradient (RCCL through libdrnmf's C ABI).  The forward alone -- the
+north-star target and round 1's headline -- is timed the same way and reported beside it as
+`forward` with its own roofline block.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,8 +36,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=2000)
     ap.add_argument("--bins", type=int, default=513)
@@ -40,15 +47,18 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ista", action="store_true", help="skip the frame-parallel ISTA line")
     ap.add_argument("--operand-f16", action="store_true",
-                    help="fp16 MFMA operands, fp32 accumulate (BASELINE config 5 mode; the headline "
-                         "metric is quoted in fp32)")
+                    help="forward block with fp16 MFMA operands, fp32 accumulate (BASELINE config 5 "
+                         "mode; the headline metric is quoted in fp32)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the config-5 shape lines (F=1025, N=8000, K=50)")
     ap.add_argument("--no-slab", action="store_true",
                     help="skip the 250-utterance inference slab line")
-    ap.add_argument("--no-train", action="store_true", help="skip the training-step lines")
-    ap.add_argument("--no-train-c2", action="store_true",
-                    help="skip the training step at the headline shape (needs ~70 GB of HBM)")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the training step at the shipped configuration (configs[2])")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="time the forward only (value = forward frames/s, metric says so): for "
+                         "profiling passes and boxes without the ~75 GB the BPTT needs")
+    ap.add_argument("--no-extras", action="store_true", help="headline + forward blocks only")
     ap.add_argument("--cpu-frames", type=int, default=0,
                     help="frame-steps of the CPU baseline sample (0 = auto, ~15-25 s)")
     return ap.parse_args()
@@ -130,7 +140,7 @@ def mu_bench(torch, dev, F, N, W, n=32768, iters=20):
             "ms_per_iteration": sec / iters * 1e3}
 
 
-def train_bench(torch, dev, steps=3, shape=(32, 500, 257, 1000, 5), ragged=True):
+def train_bench(torch, dev, steps=20, warmup=5, shape=(32, 500, 257, 1000, 5), ragged=True):
     """Forward + BPTT + Adam per step on a synthetic batch.  Default shape = BASELINE configs[2],
     the shipped training configuration (downsample1: F=257, maxlen=500, batch 32, K=5, r=1000,
     untied log_D/log_alph, ragged lengths); bench also runs it at the headline shape (F=513,
@@ -152,13 +162,22 @@ def train_bench(torch, dev, steps=3, shape=(32, 500, 257, 1000, 5), ragged=True)
              params_untied=["log_D", "log_alph"], params_trainable=["log_D", "log_alph"])
     model = layers.build_unfolded_snmf(p, device=dev)
     model.compile(lr=1e-3)
-    losses = [model.train_on_batch(x, y, w)]          # warm-up (graph build)
+    losses = [model.train_on_batch(x, y, w) for _ in range(max(warmup, 1))]   # graph build + warm-up
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(steps):
         losses.append(model.train_on_batch(x, y, w))
+    e1.record()
     torch.cuda.synchronize()
-    sec = (time.perf_counter() - t0) / steps
+    sec = e0.elapsed_time(e1) * 1e-3 / steps
+    model.backward_profile = {}
+    model.phase_events = {}
+    model.train_on_batch(x, y, w)
+    bp, pe = model.backward_profile, model.phase_events
+    fwd_ms = pe["cell_forward"][0].elapsed_time(pe["cell_forward"][1])
+    launches = T * (2 * K - 1) + bp["chain_launches"]
+    launch_us = (fwd_ms + bp["chain_ms"]) * 1e3 / launches
     valid = float(w.sum().item())
     flops = (12.0 * F * N * K - 2.0 * F * N) * B * T
     del model, x, y, w
@@ -168,6 +187,11 @@ def train_bench(torch, dev, steps=3, shape=(32, 500, 257, 1000, 5), ragged=True)
                        100.0 * valid / (B * T)),
             "ms_per_step": sec * 1e3, "frames_per_s": B * T / sec,
             "valid_frames_per_s": valid / sec, "tflops": flops / sec / 1e12,
+            "frac_of_f32_mfma_peak": flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "chain_launches_per_step": launches, "chain_launch_us": launch_us,
+            "cell_forward_ms": fwd_ms, "bptt_sequential_ms": bp["chain_ms"],
+            "bptt_time_batched_ms": bp["batched_ms"], "steps": steps, "warmup": warmup,
+            "timing": "HIP events",
             "loss_first": losses[0], "loss_last": losses[-1]}
 
 
@@ -234,8 +258,18 @@ def config5_bench(torch, dev, frames=64, B=64):
         torch.cuda.synchronize()
         sec = e0.elapsed_time(e1) * 1e-3
         tf = B * frames * 4.0 * F * N * K / sec / 1e12
+        launch_us = sec / (frames * (2 * K - 1)) * 1e6
+        # HBM-bound at this shape (K = 50 untied dictionaries = 1.6 GB fp16 / 3.3 GB fp32, past the
+        # 256 MB Infinity Cache): algorithmic bytes per launch = the layer's dictionary once (one
+        # packing) + the activations it exchanges (h in, residual out, or the reverse)
+        esz = 2 if name == "f16" else 4
+        bytes_launch = float(F) * N * esz + B * (N + F) * esz
+        gbs = bytes_launch / (launch_us * 1e-6) / 1e9
         out[name] = {"frames_per_s": B * frames / sec, "tflops": tf, "frac_of_mfma_peak": tf / peak,
-                     "launch_us": sec / (frames * (2 * K - 1)) * 1e6}
+                     "launch_us": launch_us,
+                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                                  "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                  "bytes_per_launch": bytes_launch}}
         masks[name] = m_buf.clone()
         del model
     out["mask_mse_f16_vs_f32"] = float(((masks["f16"] - masks["f32"]) ** 2).mean())
@@ -345,58 +379,208 @@ def pmc_traffic():
     return None, None
 
 
+def rocprof_launch_us():
+    """Average launch duration of the chain kernels in the newest committed rocprofv3
+    --kernel-trace --stats summary of this command (profiles/*_kernel_stats.csv): the PROFILED
+    figure, reported next to the unprofiled HIP-event one (the kernel-trace instrumentation adds
+    ~0.9 us to these 4-us kernels: compare trace and events inside the profiled run,
+    profiles/README.md)."""
+    import csv
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    tot, calls, per = 0.0, 0, {}
+    try:
+        for row in csv.DictReader(open(files[-1])):
+            name = row["Name"]
+            for key in ("cell_a_kernel", "cell_b_kernel", "bwd_a_kernel", "bwd_edge_kernel"):
+                if key in name:
+                    c, d = int(row["Calls"]), float(row["TotalDurationNs"])
+                    tot += d
+                    calls += c
+                    a = per.setdefault(key, [0, 0.0])
+                    a[0] += c
+                    a[1] += d
+    except (OSError, ValueError, KeyError):
+        return None
+    if not calls:
+        return None
+    return {"file": "profiles/" + os.path.basename(files[-1]), "mean_us": tot / calls * 1e-3,
+            "per_kernel_us": {k: v[1] / v[0] * 1e-3 for k, v in per.items()}}
+
+
+def _limit_threads(t):
+    """Context manager capping the BLAS pools at t threads (no-op without threadpoolctl)."""
+    import contextlib
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=int(t))
+    except Exception:        # noqa: BLE001
+        return contextlib.nullcontext()
+
+
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:        # noqa: BLE001
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(F, r, K, B, frames, tied):
     """The reference's op graph (dense p.U_k, materialised Gram h.S_k, x.Wk_k, bias+relu, K layers
     per frame inside a loop over time; custom_layers.py:361-369 + enhance.py:161-204) restated in
-    numpy fp32 (oracle/), timed on this host's cores on a bounded sample of the same workload."""
+    numpy fp32 (oracle/), timed on this host's cores on a bounded sample of the same workload
+    (forward: the reference's Theano graph cannot run here, and its backward is Theano autodiff).
+    The BLAS thread count is swept (64-row GEMMs oversubscribe a 128-thread pool) and the best is
+    reported with its count."""
     from oracle import drnmf_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
     N = 2 * r
-    P = O.synth_problem(B, max(frames, 1), F, r, seed=7654)
+    P = O.synth_problem(B, 2, F, r, seed=7654)
     params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
                   alph=np.float32(400.0 if r >= 1000 else 50.0), lam1=np.float32(1.0))
     alt, labels = O.build_alt(N, K, params, () if tied else ("log_D", "log_alph"))
     t0 = time.perf_counter()
     Wk, Uk, bk, Sk = O.maps_dense(alt, labels, K, N, dtype=np.float32)
     t_maps = time.perf_counter() - t0
-    if frames <= 0:      # auto-size: probe one frame-step, aim at ~15 s
+    fact = O.maps_factored(alt, labels, K, np.float32)
+    us = O.u_scalars(alt, np.float32)
+
+    def run_dense(Pp):
         t0 = time.perf_counter()
-        O.cell_forward_dense(P["X"][:, :1], Wk, Uk, bk, Sk, P["log_h0"], dtype=np.float32)
-        t1 = time.perf_counter() - t0
-        frames = int(max(2, min(200, 15.0 / max(t1, 1e-3))))
-        P = O.synth_problem(B, frames, F, r, seed=7654)
-    t0 = time.perf_counter()
-    O.cell_forward_dense(P["X"], Wk, Uk, bk, Sk, P["log_h0"], dtype=np.float32)
-    t_dense = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.cell_forward_factored(P["X"], O.maps_factored(alt, labels, K, np.float32),
-                            O.u_scalars(alt, np.float32), P["log_h0"], dtype=np.float32)
-    t_fact = time.perf_counter() - t0
+        O.cell_forward_dense(Pp["X"], Wk, Uk, bk, Sk, Pp["log_h0"], dtype=np.float32)
+        return time.perf_counter() - t0
+
+    def run_fact(Pp):
+        t0 = time.perf_counter()
+        O.cell_forward_factored(Pp["X"], fact, us, Pp["log_h0"], dtype=np.float32)
+        return time.perf_counter() - t0
+    max_threads = _blas_threads()
+    sweep = {}
+    cands = sorted(set([t for t in (4, 8, 16, 32, 64, 128) if t <= max_threads] + [max_threads]))
+    best_t, best_rate = max_threads, 0.0
+    for t in cands:
+        with _limit_threads(t):
+            run_dense(P)                              # warm
+            sec = run_dense(P)
+        sweep[str(t)] = B * 2 / sec
+        if sweep[str(t)] > best_rate:
+            best_rate, best_t = sweep[str(t)], t
+    if frames <= 0:      # ~15 s at the best thread count
+        frames = int(max(4, min(400, 15.0 * best_rate / B)))
+    P = O.synth_problem(B, frames, F, r, seed=7654)
+    with _limit_threads(best_t):
+        t_dense = run_dense(P)
+        t_fact = run_fact(P)
     return {
-        "value": B * frames / t_dense, "unit": "frames/s", "cores": int(threads), "kind": "port",
+        "value": B * frames / t_dense, "unit": "frames/s", "cores": int(best_t), "kind": "port",
         "sample": "numpy fp32 restatement of the reference op graph (dense U, Gram S, per-step "
-                  "GEMMs) on %d utterances x %d frames of the same workload (recurrent cell only; "
-                  "Gram/matrix build %.1f s excluded); factored form on the same sample: %.0f "
-                  "frames/s" % (B, frames, t_maps, B * frames / t_fact),
+                  "GEMMs), FORWARD of the recurrent cell on %d utterances x %d frames of the same "
+                  "workload (Gram/matrix build %.1f s excluded); BLAS threads swept, best of %s "
+                  "reported (host exposes %d); factored form on the same sample and threads: %.0f "
+                  "frames/s" % (B, frames, t_maps, sorted(int(k) for k in sweep), max_threads,
+                                B * frames / t_fact),
+        "thread_sweep_frames_per_s": sweep,
     }
+
+
+def config1_bench(torch, dev):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case: W 513 x 200, K = 10, ONE
+    utterance (T = 1000 synthetic frames) -- on the GPU (cell + head) and on the host (oracle port,
+    same two op-graph forms as cpu_baseline).  B = 1 is where the GPU advantage is smallest: one
+    16-row MFMA tile is 1/16 full and every launch is pure latency."""
+    from drnmf_amd import layers, ops
+    from oracle import drnmf_oracle as O
+    F, r, K, T = 513, 100, 10, 1000
+    N = 2 * r
+    W, log_h0, X = synth_on_device(torch, dev, 1, T, F, r, seed=11)
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K, W=W,
+             alph=50.0, lam1=1.0, params_trainable=["log_D", "log_alph"],
+             params_untied=["log_D", "log_alph"])
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.cell.log_h0.copy_(torch.from_numpy(log_h0))
+    h_buf = torch.empty((1, T, N), dtype=torch.float32, device=dev)
+    m_buf = torch.empty((1, T, F), dtype=torch.float32, device=dev)
+
+    def step():
+        h = model.cell.call(X, mask_value=-1., out=h_buf)
+        ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    out = {"shape": "F=%d N=%d K=%d B=1 T=%d untied" % (F, N, K, T),
+           "gpu_frames_per_s": T / sec, "gpu_ms_per_utterance": sec * 1e3,
+           "gpu_launch_us": sec / (T * (2 * K - 1)) * 1e6}
+    Xh = X.cpu().numpy()
+    params = dict(W=W, U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(50.0), lam1=np.float32(1.0))
+    alt, labels = O.build_alt(N, K, params, ("log_D", "log_alph"))
+    Wk, Uk, bk, Sk = O.maps_dense(alt, labels, K, N, dtype=np.float32)
+    fact, us = O.maps_factored(alt, labels, K, np.float32), O.u_scalars(alt, np.float32)
+    best = {}
+    for t in (1, 4, 16):
+        with _limit_threads(t):
+            t0 = time.perf_counter()
+            O.cell_forward_dense(Xh, Wk, Uk, bk, Sk, log_h0, dtype=np.float32)
+            td = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            hf = O.cell_forward_factored(Xh, fact, us, log_h0, dtype=np.float32)
+            tf = time.perf_counter() - t0
+        best[str(t)] = {"dense_graph_frames_per_s": T / td, "factored_frames_per_s": T / tf}
+    out["cpu_port_by_blas_threads"] = best
+    out["cpu_best_frames_per_s"] = max(max(v.values()) for v in best.values())
+    hd = h_buf.cpu().numpy()
+    out["max_abs_dh_vs_cpu_port_rel"] = float(np.max(np.abs(hd - hf)) / max(np.max(np.abs(hf)), 1e-30))
+    del model, X, h_buf, m_buf
+    torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside a launcher: start N ranks with torch.distributed.run as
+    a CHILD process (nothing in this process has touched the GPU yet) and leave with its code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher; starting: %s\n" % (a.gpus, " ".join(cmd)))
+    return subprocess.call(cmd)
 
 
 def main():
     a = parse()
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and "RANK" not in os.environ and a.gpus > 1:
+            raise SystemExit(spawn_ranks(a))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with python -m "
+                         "torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr "
+                         "127.0.0.1 --master-port P bench.py --gpus %d ..." %
+                         (a.gpus, world, a.gpus, a.gpus))
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # (test aids: DRNMF_BENCH_BACKEND=gloo and DRNMF_BENCH_DEVICE=<i> let the N > 1 path run with
-        # several ranks on ONE GPU, where RCCL refuses duplicate devices)
+        # several ranks on ONE GPU, where RCCL refuses duplicate devices; the gradient all-reduce
+        # then goes through torch.distributed as well, DRNMF_DP_BACKEND=torch)
         if "DRNMF_BENCH_DEVICE" in os.environ:
             local = int(os.environ["DRNMF_BENCH_DEVICE"])
         backend = os.environ.get("DRNMF_BENCH_BACKEND", "nccl")
@@ -404,6 +588,7 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
         else:
+            os.environ.setdefault("DRNMF_DP_BACKEND", "torch")
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
@@ -412,88 +597,200 @@ def main():
 
     import __graft_entry__ as G
     G.build()
-    from drnmf_amd import layers
+    from drnmf_amd import layers, ops
 
     B, T, F, r, K = a.batch, a.frames, a.bins, a.r, a.layers
     N = 2 * r
-    W, log_h0, X = synth_on_device(torch, dev, B, T, F, r, seed=7654 + rank)
+    W, log_h0, X, Y = synth_on_device(torch, dev, B, T, F, r, seed=7654 + rank, want_clean=True)
     p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K, W=W,
              alph=400.0 if r >= 1000 else 50.0, lam1=1.0, params_trainable=["log_D", "log_alph"])
     if not a.tied:
         p["params_untied"] = ["log_D", "log_alph"]
-    if a.operand_f16:
-        p["operand_dtype"] = "float16"
     model = layers.build_unfolded_snmf(p, device=dev)
     model.cell.log_h0.copy_(torch.from_numpy(log_h0))
-    h_buf = torch.empty((B, T, N), dtype=torch.float32, device=dev)
-    m_buf = torch.empty((B, T, F), dtype=torch.float32, device=dev)
-    from drnmf_amd import ops
-
-    cell_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    cell_ms = []
-
-    def step(timed=False):
-        if timed:
-            cell_ev[0].record()
-        h = model.cell.call(X, mask_value=-1., out=h_buf)
-        if timed:
-            cell_ev[1].record()
-        ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
-        if timed:          # rank-local bookkeeping after the step's work is enqueued
-            cell_ev[1].synchronize()
-            cell_ms.append(cell_ev[0].elapsed_time(cell_ev[1]))
+    wts = torch.ones((B, T), dtype=torch.float32, device=dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for i in range(a.steps):
-        step(timed=(i == a.steps - 1))
-    e1.record()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
-    ev_ms = e0.elapsed_time(e1)
+    def timed(step, steps, warmup):
+        """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks; returns
+        (wall seconds, HIP-event milliseconds of this rank's stream)."""
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall = float(tt.item())
+        return wall, e0.elapsed_time(e1)
 
-    ok = bool(torch.isfinite(m_buf).all().item()) and float(m_buf.min()) > 0.0
-    frames_total = world * B * T * a.steps
-    value = frames_total / wall
-    # algorithmic MFMA work: fwd = 4*F*N*K per frame = two B x F x N
-    # contractions per layer-step; one cell_a / cell_b launch carries one of them for all B rows.
-    flops_per_frame = 4.0 * F * N * K
-    whole = (B * T * a.steps) * flops_per_frame / (ev_ms * 1e-3) / 1e12
-    flops_per_launch = 2.0 * B * F * N
-    # Dominant kernels: cell_a / cell_b (2K-1 launches per frame, each one B x F x N contraction =
-    # 2*B*F*N algorithmic flops, near-equal durations).  Average launch duration = HIP-event time
-    # of the cell's launches on the launch stream / number of launches (the hipGraph replays run
-    # back to back, so this includes the ~1.7 us launch boundary, as rocprofv3's kernel trace of
-    # the same command does: it reports zero gaps between consecutive kernels).
-    n_launch = T * (2 * K - 1)
-    launch_us = (sum(cell_ms) / len(cell_ms)) * 1e3 / n_launch
-    ach = flops_per_launch / (launch_us * 1e-6) / 1e12
+    n_chain = T * (2 * K - 1)            # launches of one pass over the batch (forward or BPTT)
+    flops_per_launch = 2.0 * B * F * N    # one B x F x N contraction (SURVEY.md 8d)
     traffic, traffic_src = pmc_traffic()
-    roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": traffic_src,
-            "kernel": "cell_a_kernel / cell_b_kernel (mean over the 2K-1 launches of a frame)",
-            "launch_us": launch_us, "flops_per_launch": flops_per_launch}
+    prof = rocprof_launch_us()
+
+    # ---------------- headline: forward + loss + BPTT + Adam (the metric's "fwd+bwd") ----------
+    out = {}
+    train = None
+    if not a.forward_only:
+        def on_timeout():
+            # a collective that never comes back: say so and leave with a failure code (the
+            # launcher must see it); never re-exec a process that has touched the GPU
+            if rank == 0:
+                print(json.dumps({"metric": "STFT frames/sec (fwd+bwd)", "value": None,
+                                  "error": "training step timed out (collective?)",
+                                  "n_gpus": world}), flush=True)
+            os._exit(3)
+
+        def headline():
+            model.compile(lr=1e-3)
+            model.phase_events = {}
+            losses = []
+            wall, ev_ms = timed(lambda: losses.append(model.train_on_batch(X, Y, wts)),
+                                a.steps, a.warmup)
+            pe = model.phase_events            # events of the LAST timed step
+            phases = {k: v[0].elapsed_time(v[1]) for k, v in pe.items()}
+            model.phase_events = None
+            # one more step with the backward's phase boundaries bracketed (synchronising aid)
+            model.backward_profile = {}
+            model.train_on_batch(X, Y, wts)
+            bp = dict(model.backward_profile)
+            model.backward_profile = None
+            return dict(wall=wall, ev_ms=ev_ms, phases=phases, bp=bp, losses=losses)
+        train = run_guarded(headline, 900.0, on_timeout)
+    if train is not None and "error" not in train:
+        wall, ev_ms = train["wall"], train["ev_ms"]
+        value = world * B * T * a.steps / wall
+        fwd_ms, bwd_chain_ms = train["phases"]["cell_forward"], train["bp"]["chain_ms"]
+        launches = n_chain + train["bp"]["chain_launches"]
+        launch_us = (fwd_ms + bwd_chain_ms) * 1e3 / launches
+        ach = flops_per_launch / (launch_us * 1e-6) / 1e12
+        flops_step = (12.0 * F * N * K - 2.0 * F * N) * B * T
+        out = {
+            "metric": "STFT frames/sec (fwd+bwd), %d-bin x %d-frame, K=%d unrolls" % (F, T, K),
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] shape, forward + loss + BPTT + Adam "
+                                   "(train_on_batch): K=%d unrolled SNMF, W %dx%d, %s "
+                                   "log_D/log_alph, batch %d x %d frames per GPU%s" %
+                                   (K, F, N, "tied" if a.tied else "untied", B, T,
+                                    ", one RCCL all-reduce of the flat gradient per step"
+                                    if world > 1 else ""),
+                       "B_per_gpu": B, "T": T, "F": F, "N": N, "K": K, "untied": not a.tied},
+            "roofline": {
+                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": traffic_src,
+                "kernel": "the chain kernels cell_a / cell_b (forward) and cell_b / bwd_a (BPTT): "
+                          "each launch is one B x F x N contraction",
+                "launch_us": launch_us, "flops_per_launch": flops_per_launch,
+                "launches_per_step": launches,
+                "duration_source": "HIP events on the launch stream, unprofiled run: (cell forward "
+                                   "of the last timed step + sequential pass of the BPTT bracketed "
+                                   "by drnmf_cell_backward_profile) / launches; includes the "
+                                   "~1.5 us launch boundary, as a zero-gap kernel trace does",
+                "launch_us_rocprof": prof,
+            },
+            "step_breakdown_ms": {
+                "cell_forward_chain": fwd_ms, "head_and_loss": train["phases"]["head_and_loss"],
+                "cell_backward_total": train["phases"]["cell_backward"],
+                "bptt_sequential_pass": bwd_chain_ms,
+                "bptt_time_batched_weight_gradients": train["bp"]["batched_ms"],
+                "hip_event_ms_per_step": ev_ms / a.steps},
+            "whole_step_tflops_algorithmic": flops_step / (ev_ms / a.steps * 1e-3) / 1e12,
+            "whole_step_frac_of_f32_mfma_peak":
+                flops_step / (ev_ms / a.steps * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "loss_first": train["losses"][0], "loss_last": train["losses"][-1],
+        }
+    elif train is not None:
+        out = {"metric": "STFT frames/sec (fwd+bwd), %d-bin x %d-frame, K=%d unrolls" % (F, T, K),
+               "value": None, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "error": train["error"]}
+
+    # release the training state (hall, dz, dR: ~60 GB at the headline shape) before the rest
+    model._opt_state = model._flat = model._gview = None
+    model.cell._ws.clear()
+    del Y
+    torch.cuda.empty_cache()
+
+    # ---------------- forward alone: recurrent cell + mask head (north-star target) ------------
+    if a.operand_f16:
+        p2 = dict(p, operand_dtype="float16")
+        model = layers.build_unfolded_snmf(p2, device=dev)
+        model.cell.log_h0.copy_(torch.from_numpy(log_h0))
+    h_buf = torch.empty((B, T, N), dtype=torch.float32, device=dev)
+    m_buf = torch.empty((B, T, F), dtype=torch.float32, device=dev)
+    cell_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    cell_ms = []
+
+    def fwd_step():
+        cell_ev[0].record()
+        h = model.cell.call(X, mask_value=-1., out=h_buf)
+        cell_ev[1].record()
+        ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
+        cell_ev[1].synchronize()
+        cell_ms.append(cell_ev[0].elapsed_time(cell_ev[1]))
+    fwall, fev_ms = timed(fwd_step, a.steps, a.warmup)
+    cell_ms = cell_ms[-a.steps:]
+    ok = bool(torch.isfinite(m_buf).all().item()) and float(m_buf.min()) > 0.0
+    f_launch_us = (sum(cell_ms) / len(cell_ms)) * 1e3 / n_chain
+    f_ach = flops_per_launch / (f_launch_us * 1e-6) / 1e12
+    whole = (B * T * a.steps) * 4.0 * F * N * K / (fev_ms * 1e-3) / 1e12
+    per_kernel = None
+    if rank == 0 and world == 1:
+        try:   # launch-by-launch HIP events over the first frames (plain launches, no graph)
+            desc = model.cell._desc(B, T)
+            per_kernel = ops.cell_profile(X, -1., model.cell._params_block, desc, model.cell.log_h0,
+                                          model.cell._u, h_buf, model.cell._ws[(B, T)], frames=8)
+        except Exception as e:        # noqa: BLE001
+            per_kernel = {"error": repr(e)[:200]}
+    forward = {
+        "value": world * B * T * a.steps / fwall, "unit": "frames/s",
+        "ms_per_step": fwall * 1e3 / a.steps,
+        "dtype": "f16 operands, f32 accumulate" if a.operand_f16 else "f32",
+        "workload": "BASELINE configs[1]: K=%d unrolled SNMF forward (recurrent cell + mask head), "
+                    "same model and batch" % K,
+        "roofline": {"bound": "mfma", "achieved": f_ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": f_ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                     "traffic_unit": traffic_src,
+                     "kernel": "cell_a_kernel / cell_b_kernel (mean over the 2K-1 launches of a frame)",
+                     "launch_us": f_launch_us, "flops_per_launch": flops_per_launch,
+                     "duration_source": "HIP events around the cell's graph replays, unprofiled "
+                                        "run, / T(2K-1) launches",
+                     "launch_us_rocprof": prof,
+                     "per_kernel_us_plain_launches_with_events": per_kernel},
+        "whole_forward_tflops": whole,
+        "whole_forward_frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
+        "finite_positive_masks": ok,
+    }
+    if a.forward_only or not out:
+        out = {"metric": "STFT frames/sec (fwd only: --forward-only), %d-bin x %d-frame, K=%d "
+                         "unrolls" % (F, T, K),
+               "value": forward["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": forward["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": forward["dtype"], "data": "synthetic",
+               "config": {"workload": forward["workload"], "B_per_gpu": B, "T": T, "F": F, "N": N,
+                          "K": K, "untied": not a.tied},
+               "roofline": forward["roofline"]}
+    out["forward"] = forward
+
     extra = {}
-    if rank == 0:
-        extra = {"frame_us": launch_us * (2 * K - 1), "cell_ms_per_step": sum(cell_ms) / len(cell_ms),
-                 "whole_forward_tflops": whole,
-                 "whole_forward_frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS}
+    if rank == 0 and world == 1 and not a.no_extras:
         def safe(fn, *args, **kw):
             """An extra line must never cost the headline line."""
             try:
@@ -501,62 +798,36 @@ def main():
             except Exception as e:       # noqa: BLE001 -- reported in the JSON line instead
                 torch.cuda.empty_cache()
                 return {"error": repr(e)[:300]}
+        del h_buf, m_buf
+        torch.cuda.empty_cache()
         if not a.no_ista:
             extra["ista_frame_parallel"] = safe(ista_bench, torch, dev, F, N, K, W)
             extra["mu_inference"] = safe(mu_bench, torch, dev, F, N, W)
             extra["stft_front_end"] = safe(stft_bench, torch, dev)
-        if not a.no_slab and world == 1:
+        extra["config1_single_utterance"] = safe(config1_bench, torch, dev)
+        if not a.no_slab:
             extra["inference_slab_250"] = safe(slab_bench, torch, dev, F, r, K, T)
             extra["reference_op_graph_dense_kernel"] = safe(dense_graph_bench, torch, dev, F, r, K, B)
-        if not a.no_config5 and world == 1:
+        if not a.no_config5:
             extra["config5_shape"] = safe(config5_bench, torch, dev)
-        if not a.no_train and world == 1:
+        if not a.no_train:
             del X
             torch.cuda.empty_cache()
             extra["train_step_configs2"] = safe(train_bench, torch, dev)
-            if not a.no_train_c2:
-                extra["train_step_headline_shape"] = safe(
-                    train_bench, torch, dev, steps=2, shape=(B, T, F, r, K), ragged=False)
-    out = {
-        "metric": "STFT frames/sec (fwd; fwd+bwd in extra.train_step_headline_shape), %d-bin x "
-                  "%d-frame, K=%d unrolls" % (F, T, K),
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 operands, f32 accumulate" if a.operand_f16 else "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: K=%d unrolled SNMF forward (recurrent cell + "
-                               "mask head), W %dx%d, %s log_D/log_alph, batch %d x %d frames per "
-                               "GPU" % (K, F, N, "tied" if a.tied else "untied", B, T),
-                   "B_per_gpu": B, "T": T, "F": F, "N": N, "K": K, "untied": not a.tied},
-        "roofline": roof,
-        "finite_positive_masks": ok,
-        "extra": extra,
-    }
+    out["extra"] = extra
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(F, r, K, B, a.cpu_frames, a.tied)
         except Exception as e:           # noqa: BLE001 -- the GPU line is still valid without it
             out["cpu_baseline"] = {"error": repr(e)[:300]}
-    if world > 1 and not a.no_train:
-        # BASELINE configs[3]: data-parallel training, 32 utterances per GPU, one RCCL all-reduce of
-        # the flat gradient per step (every rank takes part).  Guarded: a collective that does not
-        # come back must not cost the headline line -- after 180 s rank 0 prints what it has and
-        # every rank leaves.
-        def on_timeout():
-            if rank == 0:
-                out["extra"]["train_step_configs3_dp"] = {"error": "timed out after 180 s"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        res = run_guarded(lambda: train_bench(torch, dev, steps=3), 180.0, on_timeout)
-        if rank == 0:
-            if "error" not in res:
-                res.update({"n_gpus": world, "global_batch": 32 * world,
-                            "frames_per_s_all_gpus": res["frames_per_s"] * world})
-            out["extra"]["train_step_configs3_dp"] = res
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        from drnmf_amd import dp
+        dp.comm_destroy()
         dist.destroy_process_group()
+    if out.get("value") is None:
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

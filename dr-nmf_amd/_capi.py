@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdrnmf.so")
 
 OK = 0
+COMM_ID_BYTES = 128          # DRNMF_COMM_ID_BYTES
 DIV_ED, DIV_KL, DIV_BETA = 0, 1, 2
 
 
@@ -65,6 +66,9 @@ SIGNATURES = {
     "drnmf_cell_backward_workspace_bytes": (_sz, [_DP]),
     "drnmf_cell_backward": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _sz,
                                    _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "drnmf_cell_backward_profile": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp,
+                                           _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp,
+                                           C.POINTER(C.c_float)]),
     "drnmf_adam_step": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "drnmf_sumsq": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "drnmf_ista_workspace_bytes": (_sz, [_i64, _i32, _i32]),
@@ -93,6 +97,12 @@ SIGNATURES = {
     "drnmf_wav_int16": (_i32, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "drnmf_sdr_workspace_bytes": (_sz, [_i32, _i64, _i32]),
     "drnmf_sdr_corr": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "drnmf_comm_unique_id": (_i32, [_vp, _vp]),
+    "drnmf_comm_init": (_i32, [_vp, _vp, _i32, _i32]),
+    "drnmf_comm_destroy": (_i32, [_vp]),
+    "drnmf_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "drnmf_allreduce_grads": (_i32, [_vp, _vp, _i64, _vp]),
+    "drnmf_broadcast_params": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "drnmf_sdr_project": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

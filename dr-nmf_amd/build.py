@@ -98,7 +98,7 @@ def _build_locked(force, verbose):
         with open(stamp, "w") as f:
             f.write(want + "\n")
     tmp = LIB + ".tmp.%d" % os.getpid()
-    cmd = [HIPCC] + ARCH + ["-shared", "-fPIC", "-o", tmp] + objs
+    cmd = [HIPCC] + ARCH + ["-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

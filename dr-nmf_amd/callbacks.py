@@ -55,7 +55,9 @@ class EarlyStopping(Callback):
         cur = (logs or {}).get(self.monitor)
         if cur is None:
             return
-        if self.is_better(cur + self.sign * self.min_delta, self.best):
+        # Keras 2.0.4 negates min_delta for 'min' monitors and tests current - min_delta: an
+        # improvement must exceed min_delta
+        if self.is_better(cur - self.sign * self.min_delta, self.best):
             self.best, self.wait = cur, 0
         else:
             if self.wait >= self.patience:
@@ -70,6 +72,8 @@ class ModelCheckpoint(Callback):
     """Save the weights after every epoch, or only when `monitor` improves (save_best_only).
     The file is what `model.save_weights(filepath)` writes ('.npz' tree, or Keras HDF5 when h5py
     is available); `filepath` may contain '{epoch}' / '{val_loss}'-style fields."""
+
+    rank0_only = True        # data parallelism: one writer (fit() drops it on the other ranks)
 
     def __init__(self, filepath, monitor='val_loss', verbose=0, save_best_only=False,
                  save_weights_only=False, mode='auto', period=1):
@@ -100,6 +104,8 @@ class ModelCheckpoint(Callback):
 class LossHistory(Callback):
     """custom_callbacks.py:4-27: per-batch and per-epoch metric lists, pickled to `histfile` after
     every epoch as {'on_batch_end': {...}, 'on_epoch_end': {...}}."""
+
+    rank0_only = True
 
     def __init__(self, histfile):
         self.histfile = histfile

@@ -616,14 +616,14 @@ extern "C" size_t drnmf_cell_backward_workspace_bytes(const drnmf_cell_desc_t* d
     return bwd_layout(d, workspace_layout(d)).total;
 }
 
-extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
-                                       const void* params, const float* log_h0, float u0_diag,
-                                       float u0_off, float uk_off, const float* hall,
-                                       const float* d_out, const void* fwd_workspace,
-                                       size_t fwd_workspace_bytes, void* bwd_workspace,
-                                       size_t bwd_workspace_bytes, float* d_log_D,
-                                       float* d_log_alph, float* d_log_lam1, float* d_log_h0,
-                                       void* stream_) {
+static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                  const void* params, const float* log_h0, float u0_diag,
+                                  float u0_off, float uk_off, const float* hall,
+                                  const float* d_out, const void* fwd_workspace,
+                                  size_t fwd_workspace_bytes, void* bwd_workspace,
+                                  size_t bwd_workspace_bytes, float* d_log_D,
+                                  float* d_log_alph, float* d_log_lam1, float* d_log_h0,
+                                  void* stream_, float* prof_ms) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;
@@ -680,6 +680,12 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     float* P = (float*)(bw + L.off_P);
     float* crp = (float*)(bw + L.off_cr);
 
+    // measurement aid (drnmf_cell_backward_profile): HIP events at the phase boundaries
+    hipEvent_t pev[3] = {nullptr, nullptr, nullptr};
+    if (prof_ms) {
+        for (auto& e : pev) DRNMF_HIP(h, hipEventCreate(&e));
+        DRNMF_HIP(h, hipEventRecord(pev[0], stream));
+    }
     // ---- sequential pass: T replays of the per-frame graph in reverse time ---------------------
     DRNMF_HIP(h, hipMemsetAsync(bw, 0, L.off_dh0, stream));   // dstate .. counters
     const dim3 grid_a(8u * (unsigned)numM, (unsigned)(round_up(W.numA, 8) / 8));
@@ -760,12 +766,9 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     for (auto& g : h->graphs)
         if (g.key == gkey) { entry = &g; break; }
     if (!entry) {
-        if (h->graphs.size() >= 24) {   // bounded cache shared with the forward: drop the oldest
-            // (rare) the evicted graph may still be replaying on some stream
-            DRNMF_HIP(h, hipDeviceSynchronize());
-            (void)hipGraphExecDestroy(h->graphs.front().exec);
-            (void)hipGraphDestroy(h->graphs.front().graph);
-            h->graphs.erase(h->graphs.begin());
+        {   // bounded cache: the oldest entry is retired without synchronising (common.h)
+            const int32_t erc = graph_cache_make_room(h, stream, 24);
+            if (erc) return erc;
         }
         GraphEntry ge;
         ge.key = gkey;
@@ -801,6 +804,7 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
         h->graphs.push_back(ge);
         entry = &h->graphs.back();
     }
+    entry->last_stream = stream;
     *out = entry->exec;
     return DRNMF_OK;
     };
@@ -820,6 +824,7 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     hipLaunchKernelGGL(dlogh0_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dh0_part,
                        log_h0, d_log_h0, N, W.Np, numM);
     DRNMF_HIP(h, hipGetLastError());
+    if (prof_ms) DRNMF_HIP(h, hipEventRecord(pev[1], stream));
 
     // ---- time-batched phase ----------------------------------------------------------------------
     DRNMF_HIP(h, hipMemsetAsync(xpad, 0, (size_t)BT * W.Fp * 4, stream));
@@ -865,5 +870,39 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
                            (d->n_lam == 1 && k > 0) ? 1 : 0);
     }
     DRNMF_HIP(h, hipGetLastError());
+    if (prof_ms) {
+        DRNMF_HIP(h, hipEventRecord(pev[2], stream));
+        DRNMF_HIP(h, hipStreamSynchronize(stream));
+        DRNMF_HIP(h, hipEventElapsedTime(&prof_ms[0], pev[0], pev[1]));
+        DRNMF_HIP(h, hipEventElapsedTime(&prof_ms[1], pev[1], pev[2]));
+        prof_ms[2] = (float)T * (float)(2 * K - 1) + 1.f;   // launches of the sequential pass
+        for (auto& e : pev) (void)hipEventDestroy(e);
+    }
     return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                       const void* params, const float* log_h0, float u0_diag,
+                                       float u0_off, float uk_off, const float* hall,
+                                       const float* d_out, const void* fwd_workspace,
+                                       size_t fwd_workspace_bytes, void* bwd_workspace,
+                                       size_t bwd_workspace_bytes, float* d_log_D,
+                                       float* d_log_alph, float* d_log_lam1, float* d_log_h0,
+                                       void* stream_) {
+    return cell_backward_impl(h, d, x, params, log_h0, u0_diag, u0_off, uk_off, hall, d_out,
+                              fwd_workspace, fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes,
+                              d_log_D, d_log_alph, d_log_lam1, d_log_h0, stream_, nullptr);
+}
+
+extern "C" int32_t drnmf_cell_backward_profile(
+    drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x, const void* params,
+    const float* log_h0, float u0_diag, float u0_off, float uk_off, const float* hall,
+    const float* d_out, const void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
+    size_t bwd_workspace_bytes, float* d_log_D, float* d_log_alph, float* d_log_lam1,
+    float* d_log_h0, void* stream_, float* out_ms_host) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (!out_ms_host) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_backward_profile: NULL out_ms_host");
+    return cell_backward_impl(h, d, x, params, log_h0, u0_diag, u0_off, uk_off, hall, d_out,
+                              fwd_workspace, fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes,
+                              d_log_D, d_log_alph, d_log_lam1, d_log_h0, stream_, out_ms_host);
 }

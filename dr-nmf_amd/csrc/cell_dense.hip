@@ -411,12 +411,10 @@ extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_
                 (uint64_t)d->return_all_hidden, (uint64_t)(uintptr_t)params,
                 (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)frames, (uint64_t)nw};
             for (auto& g : h->graphs)
-                if (g.key == key) { *out = g.exec; return DRNMF_OK; }
-            if (h->graphs.size() >= 24) {
-                DRNMF_HIP(h, hipDeviceSynchronize());
-                (void)hipGraphExecDestroy(h->graphs.front().exec);
-                (void)hipGraphDestroy(h->graphs.front().graph);
-                h->graphs.erase(h->graphs.begin());
+                if (g.key == key) { g.last_stream = stream; *out = g.exec; return DRNMF_OK; }
+            {   // bounded cache: the oldest entry is retired without synchronising (common.h)
+                const int32_t erc = graph_cache_make_room(h, stream, 24);
+                if (erc) return erc;
             }
             GraphEntry ge;
             ge.key = key;
@@ -448,6 +446,7 @@ extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_
                 }
             }
             DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+            ge.last_stream = stream;
             h->graphs.push_back(ge);
             *out = ge.exec;
             return DRNMF_OK;

@@ -805,12 +805,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     for (auto& g : h->graphs)
         if (g.key == gkey) { entry = &g; break; }
     if (!entry) {
-        if (h->graphs.size() >= 24) {   // bounded cache: drop the oldest
-            // (rare) the evicted graph may still be replaying on some stream
-            DRNMF_HIP(h, hipDeviceSynchronize());
-            (void)hipGraphExecDestroy(h->graphs.front().exec);
-            (void)hipGraphDestroy(h->graphs.front().graph);
-            h->graphs.erase(h->graphs.begin());
+        {   // bounded cache: the oldest entry is retired without synchronising (common.h)
+            const int32_t erc = graph_cache_make_room(h, stream, 24);
+            if (erc) return erc;
         }
         GraphEntry ge;
         ge.key = gkey;
@@ -852,6 +849,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         h->graphs.push_back(ge);
         entry = &h->graphs.back();
     }
+    entry->last_stream = stream;
     *out = entry->exec;
     return DRNMF_OK;
     };

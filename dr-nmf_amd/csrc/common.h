@@ -48,13 +48,27 @@ struct GraphEntry {
     std::vector<uint64_t> key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the most recent replay (eviction waits on it)
 };
 
 struct drnmf_handle_s {
     int device = 0;
     char err[512] = {0};
     std::vector<GraphEntry> graphs;
+    // graphs dropped from the bounded cache: destroyed once the work that was enqueued when they
+    // were retired has completed (graph_cache_insert, no device-wide synchronisation)
+    struct Retired { GraphEntry g; hipEvent_t done; };
+    std::vector<Retired> retired;
+    // RCCL communicator (comm.hip): one rank per handle / GPU
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
 };
+
+// Bounded graph cache shared by the forward / backward / dense cells.  Evicting an entry must not
+// synchronise the device (ABI contract: calls only enqueue): the evicted executable may still be
+// replaying on `stream`, so it is parked with an event recorded on that stream and destroyed by a
+// later call once the event has completed.
+int32_t graph_cache_make_room(drnmf_handle_t h, hipStream_t stream, size_t max_entries);
 
 extern char g_create_err[512];
 

@@ -41,13 +41,48 @@ extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
     return DRNMF_OK;
 }
 
+extern "C" int32_t drnmf_comm_destroy(drnmf_handle_t h);
+
 extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
+    (void)drnmf_comm_destroy(h);
+    for (auto& r : h->retired) {      // (destroy is the one call that may wait)
+        (void)hipEventSynchronize(r.done);
+        (void)hipEventDestroy(r.done);
+        if (r.g.exec) (void)hipGraphExecDestroy(r.g.exec);
+        if (r.g.graph) (void)hipGraphDestroy(r.g.graph);
+    }
     for (auto& g : h->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     delete h;
+    return DRNMF_OK;
+}
+
+int32_t graph_cache_make_room(drnmf_handle_t h, hipStream_t stream, size_t max_entries) {
+    // reap retired graphs whose last replay has completed (a query, never a wait)
+    for (size_t i = 0; i < h->retired.size();) {
+        if (hipEventQuery(h->retired[i].done) == hipSuccess) {
+            (void)hipEventDestroy(h->retired[i].done);
+            if (h->retired[i].g.exec) (void)hipGraphExecDestroy(h->retired[i].g.exec);
+            if (h->retired[i].g.graph) (void)hipGraphDestroy(h->retired[i].g.graph);
+            h->retired.erase(h->retired.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+    (void)hipGetLastError();          // hipErrorNotReady of the query is not an error
+    while (h->graphs.size() >= max_entries) {
+        drnmf_handle_s::Retired r;
+        r.g = h->graphs.front();
+        h->graphs.erase(h->graphs.begin());
+        DRNMF_HIP(h, hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+        // the evicted executable was last replayed on r.g.last_stream (this call's stream when it
+        // never ran): everything enqueued there so far precedes the event
+        DRNMF_HIP(h, hipEventRecord(r.done, r.g.last_stream ? r.g.last_stream : stream));
+        h->retired.push_back(r);
+    }
     return DRNMF_OK;
 }
 

@@ -600,11 +600,11 @@ class SimpleDeepRNN(_Layer):
         self._train_ctx = (desc, key, mask_value)
         return hall
 
-    def backward(self, x, hall, d_out, grads=None):
+    def backward(self, x, hall, d_out, grads=None, profile=None):
         """Gradients w.r.t. the stacked log-domain parameters (see ops.cell_backward)."""
         desc, key, _ = self._train_ctx
         return ops.cell_backward(x, self._params_block, desc, self.log_h0, self._u, hall, d_out,
-                                 self._ws[key], grads=grads)
+                                 self._ws[key], grads=grads, profile=profile)
 
     def grad_slices(self):
         """[(weight name, stacked-gradient key, index)] mapping each alt parameter to its slice
@@ -765,14 +765,28 @@ class UnfoldedSNMFModel(object):
     __call__ = forward
 
     # -- training: loss 'mse_of_masked' + Adam (enhance.py:1040-1073, 1152) -----------------
+    N_SCALARS = 3      # tail of the flat buffer: [sum w*mse, #frames with w != 0, #frames]
+
     def compile(self, loss='mse', optimizer='adam', lr=1e-3, clipnorm=0., decay=0., beta_1=0.9,
-                beta_2=0.999, epsilon=1e-8, sample_weight_mode='temporal'):
+                beta_2=0.999, epsilon=1e-8, sample_weight_mode='temporal',
+                loss_norm='masked_mean'):
         """model.compile(loss='mse', optimizer=Adam(lr, clipnorm, decay),
         sample_weight_mode='temporal') applied to output_masked = input * mask
-        (enhance.py:1042, 1057, 1071-1073)."""
+        (enhance.py:1042, 1057, 1071-1073).
+
+        loss_norm ([K2.0.4-memory] either way): 'masked_mean' = sum(w*mse) /
+        #(w != 0), Keras' weighted loss when the Masking layer's mask does NOT reach the output;
+        'keras204' = the same divided once more by p = mean(mask) -- Keras 2.0.4's
+        weighted_masked_objective applies score*m/mean(m) AND score*w/mean(w != 0) when the mask
+        does propagate (the sample weights are the mask itself, enhance.py:1148-1152).  The two
+        differ by the per-batch factor 1/p on loss and gradients (Adam largely cancels it).
+        Under torch.distributed rank 0's weights are broadcast so that all replicas start equal."""
         if loss != 'mse' or optimizer != 'adam' or sample_weight_mode != 'temporal':
             raise NotImplementedError("only loss='mse', optimizer='adam', temporal sample weights "
                                       "(the reference's training configuration)")
+        if loss_norm not in ('masked_mean', 'keras204'):
+            raise ValueError("loss_norm must be 'masked_mean' or 'keras204'")
+        self.loss_norm = loss_norm
         self.opt = dict(lr=float(lr), clipnorm=float(clipnorm), decay=float(decay),
                         b1=float(beta_1), b2=float(beta_2), eps=float(epsilon), iterations=0)
         cell = self.cell
@@ -795,26 +809,59 @@ class UnfoldedSNMFModel(object):
         self._opt_state = {n: (torch.zeros_like(t), torch.zeros_like(t))
                            for n, t in self._train_items}
         total = sum(int(t.numel()) for _, t in self._train_items)
-        self._flat = torch.zeros(total + 2, dtype=torch.float32, device=cell.device)
+        self._flat = torch.zeros(total + self.N_SCALARS, dtype=torch.float32, device=cell.device)
         self._gview, o = {}, 0
         for n, t in self._train_items:
             self._gview[n] = self._flat[o:o + t.numel()].view(t.shape)
             o += t.numel()
+        self.sync_replicas()
         return self
+
+    def sync_replicas(self, root=0):
+        """Data parallelism: every weight of the model (trainable or not) is replaced by rank
+        `root`'s, in one broadcast of a flat buffer -- replicas must not depend on every rank
+        having drawn the same random initial log_h0.  No-op for a single rank."""
+        from . import dp
+        if dp.world_size() <= 1:
+            return
+        ws = self.weights
+        flat = torch.cat([w.reshape(-1) for w in ws]).contiguous()
+        dp.broadcast_(flat, root)
+        o = 0
+        for w in ws:
+            w.copy_(flat[o:o + w.numel()].view(w.shape))
+            o += w.numel()
+        for l in (self.cell, self.clean, self.noise):
+            l._weights_changed()
 
     def loss_and_grads(self, x, y, sample_weight):
         """Unnormalised loss/gradients of one (local) batch into the flat buffer; returns the
-        flat tensor [grads..., sum w*mse, count]."""
+        flat tensor [grads..., sum w*mse, count, frames].  `self.phase_events` (bench.py only): a
+        dict that receives (start, end) torch events of the cell forward, the head + loss, and the
+        BPTT, recorded on the current stream without synchronising."""
         cell = self.cell
         N, K = cell.output_dim, cell.K_layers
+        pe = getattr(self, 'phase_events', None)
+
+        def mark(name, which):
+            if pe is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                pe.setdefault(name, [None, None])[which] = ev
+        mark('cell_forward', 0)
         hall = cell.forward_train(x, mask_value=self.mask_value)
+        mark('cell_forward', 1)
+        mark('head_and_loss', 0)
         h_off = (K - 1) * N
         mask, A, Bn = ops.head_forward(hall, self.clean.kernel, self.noise.kernel,
                                        square=self.square, want_ab=True, h_off=h_off)
         sums, d_hidden, dkc, dkn = ops.loss_head_backward(
             x, hall, self.clean.kernel, self.noise.kernel, mask, A, Bn, y, sample_weight,
             square=self.square, h_off=h_off)
-        g = cell.backward(x, hall, d_hidden)
+        mark('head_and_loss', 1)
+        mark('cell_backward', 0)
+        g = cell.backward(x, hall, d_hidden, profile=getattr(self, 'backward_profile', None))
+        mark('cell_backward', 1)
         self._flat.zero_()
         gv = self._gview
         gv['log_h0'].copy_(g['d_log_h0'])
@@ -823,16 +870,26 @@ class UnfoldedSNMFModel(object):
                 gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
         gv['kernel_clean'].copy_(dkc)
         gv['kernel_noise'].copy_(dkn)
-        self._flat[-2:].copy_(sums)
+        self._set_scalars(sums, x)
         return self._flat
+
+    def _set_scalars(self, sums, x):
+        ns = self.N_SCALARS
+        self._flat[-ns:-ns + 2].copy_(sums)
+        self._flat[-1] = float(x.shape[0] * x.shape[1])
 
     def apply_gradients(self, flat):
         """Adam step from the (already all-reduced) flat buffer; returns the normalised loss."""
         o = self.opt
-        sse, cnt = float(flat[-2]), float(flat[-1])
+        ns = self.N_SCALARS
+        sse, cnt, rows = (float(v) for v in flat[-ns:].tolist())
         scale = 1.0 / max(cnt, 1.0)
+        if getattr(self, 'loss_norm', 'masked_mean') == 'keras204':
+            # weighted_masked_objective with a propagated mask: one more division by
+            # p = mean(mask) = count / frames (global numbers under data parallelism)
+            scale *= rows / max(cnt, 1.0)
         if o['clipnorm'] > 0:                       # global-norm clip [K2.0.4-memory]
-            norm = float(np.sqrt(ops.sumsq(flat[:-2]))) * scale
+            norm = float(np.sqrt(ops.sumsq(flat[:-ns]))) * scale
             if norm > o['clipnorm']:
                 scale *= o['clipnorm'] / norm
         lr = o['lr']
@@ -845,8 +902,11 @@ class UnfoldedSNMFModel(object):
             ops.adam_step(p, self._gview[n].contiguous(), m, v, lr_t, o['b1'], o['b2'], o['eps'],
                           grad_scale=scale)
         o['iterations'] = t
-        self.cell._weights_changed()
-        return sse * (1.0 / max(cnt, 1.0))
+        # the prepared parameter block is stale; the (u0_diag, u0_off, uk_off) scalars are derived
+        # from log_U1 / log_Uk, which compile() refuses to train: re-deriving them here would cost
+        # two N x N device-to-host copies and a host pass per step
+        self.cell._params_block_valid = False
+        return sse * scale
 
     def train_on_batch(self, x, y, sample_weight=None):
         """One optimiser step.  x, y: (B,T,F); sample_weight: (B,T) (the data mask,
@@ -871,9 +931,15 @@ class UnfoldedSNMFModel(object):
         x, y = tt(x), tt(y)
         w = tt(sample_weight) if sample_weight is not None else \
             torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
-        s = ops.loss_forward(y, w, x_raw=x, mask=self.forward(x))
-        dp.allreduce_sum_(s)
-        return float(s[0]) / max(float(s[1]), 1.0)
+        s3 = torch.empty(3, dtype=torch.float32, device=dev)
+        s3[:2].copy_(ops.loss_forward(y, w, x_raw=x, mask=self.forward(x)))
+        s3[2] = float(x.shape[0] * x.shape[1])
+        dp.allreduce_sum_(s3)
+        sse, cnt, rows = s3.tolist()
+        scale = 1.0 / max(cnt, 1.0)
+        if getattr(self, 'loss_norm', 'masked_mean') == 'keras204':
+            scale *= rows / max(cnt, 1.0)
+        return sse * scale
 
     def fit(self, x, y, sample_weight=None, batch_size=32, epochs=1, validation_data=None,
             shuffle=True, seed=7654, verbose=0, callbacks=None):
@@ -881,11 +947,17 @@ class UnfoldedSNMFModel(object):
         Keras-style callbacks (callbacks.py: on_train_begin / on_batch_end / on_epoch_end with
         logs {'loss', 'val_loss'}; a callback may set model.stop_training), returns {'loss': [...],
         'val_loss': [...]} per epoch.  Under torch.distributed every rank passes ITS shard of the
-        data; batches are all-reduced per step."""
+        data; batches are all-reduced per step and the ranks take the same number of steps
+        (a rank with fewer batches joins the remaining reductions with zero weights)."""
+        from . import dp
         n = x.shape[0]
         rng = np.random.RandomState(seed)
         hist = {'loss': [], 'val_loss': []}
-        callbacks = list(callbacks or [])
+        # file-writing callbacks (rank0_only: ModelCheckpoint, LossHistory) run on rank 0 only --
+        # every rank holds the same weights and logs; the others (EarlyStopping) run everywhere so
+        # that all ranks stop together
+        callbacks = [cb for cb in (callbacks or [])
+                     if dp.rank() == 0 or not getattr(cb, 'rank0_only', False)]
         self.stop_training = False
         for cb in callbacks:
             if hasattr(cb, 'set_model'):
@@ -894,15 +966,21 @@ class UnfoldedSNMFModel(object):
                 cb.model = self
             if hasattr(cb, 'on_train_begin'):
                 cb.on_train_begin({})
+        # every train_on_batch is a collective: all ranks must take the same number of steps even
+        # when their shards differ in size (dp.shard hands the remainder to the first ranks)
+        steps = dp.max_over_ranks(epoch_steps(n, batch_size))
         for ep in range(epochs):
             for cb in callbacks:
                 if hasattr(cb, 'on_epoch_begin'):
                     cb.on_epoch_begin(ep, {})
             idx = rng.permutation(n) if shuffle else np.arange(n)
             tot, cnt = 0.0, 0
-            for s0 in range(0, n, batch_size):
-                b = idx[s0:s0 + batch_size]
+            for b, live in epoch_batches(idx, batch_size, steps):
                 sw = None if sample_weight is None else sample_weight[b]
+                if not live:
+                    # this rank has run out of data: it joins the all-reduce with zero weights
+                    # (zero gradient, zero count) on a batch it has already used
+                    sw = np.zeros((len(b), x.shape[1]), np.float32)
                 loss = self.train_on_batch(x[b], y[b], sw)
                 tot += loss
                 for cb in callbacks:
@@ -915,7 +993,7 @@ class UnfoldedSNMFModel(object):
                 xv, yv, wv = validation_data
                 logs['val_loss'] = self.test_on_batch(xv, yv, wv)
                 hist['val_loss'].append(logs['val_loss'])
-            if verbose:
+            if verbose and dp.rank() == 0:
                 print('epoch %d loss %.6f%s' % (ep + 1, logs['loss'],
                       (' val_loss %.6f' % logs['val_loss']) if validation_data else ''))
             for cb in callbacks:
@@ -927,6 +1005,24 @@ class UnfoldedSNMFModel(object):
             if hasattr(cb, 'on_train_end'):
                 cb.on_train_end({})
         return hist
+
+
+def epoch_steps(n_local, batch_size):
+    """Mini-batches one epoch of fit() takes over n_local sequences."""
+    return (int(n_local) + int(batch_size) - 1) // int(batch_size)
+
+
+def epoch_batches(idx, batch_size, steps):
+    """The (index array, live) pairs of one epoch: the rank's own mini-batches of `idx`, then --
+    when the data-parallel group takes more steps than this rank has batches -- its first batch
+    again, flagged not live (fit() gives it zero sample weights)."""
+    n = len(idx)
+    own = epoch_steps(n, batch_size)
+    for s in range(steps):
+        if s < own:
+            yield idx[s * batch_size:(s + 1) * batch_size], True
+        else:
+            yield idx[:batch_size], False
 
 
 def l1_of_output(y_true=None, y_pred=None):
@@ -996,7 +1092,7 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
                 gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
         gv['kernel_clean'].copy_(dkc)
         gv['kernel_noise'].copy_(dkn)
-        self._flat[-2:].copy_(sums)
+        self._set_scalars(sums, x)
         return self._flat
 
     def train_on_batch(self, x, y=None, sample_weight=None):

@@ -341,10 +341,12 @@ def snmf_cost_head_backward(x_raw, hidden, kernel_clean, kernel_noise, A, Bn, w,
     return sums, d_hidden, dkc, dkn
 
 
-def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=None):
+def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=None, profile=None):
     """BPTT through the cell (forward must have been run with return_all_hidden=True on the same
     workspace).  Returns dict(d_log_D [n_D,F,N], d_log_alph [n_alph,alph_len], d_log_lam1 [n_lam],
-    d_log_h0 [N]); `grads` may supply preallocated output tensors."""
+    d_log_h0 [N]); `grads` may supply preallocated output tensors.  `profile` (a dict, bench.py
+    only) switches to drnmf_cell_backward_profile, which synchronises and fills chain_ms /
+    batched_ms / chain_launches."""
     L = _capi.lib()
     h = _capi.handle(_dev_index(x))
     x, hall, d_out = _f32c(x, "x"), _f32c(hall, "hall"), _f32c(d_out, "d_out")
@@ -366,13 +368,21 @@ def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=
     }
     nbytes = L.drnmf_cell_backward_workspace_bytes(C.byref(desc))
     bws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    rc = L.drnmf_cell_backward(h, C.byref(desc), _capi.ptr(x), _capi.ptr(params),
-                               _capi.ptr(log_h0), float(u[0]), float(u[1]), float(u[2]),
-                               _capi.ptr(hall), _capi.ptr(d_out), _capi.ptr(fwd_workspace),
-                               fwd_workspace.numel(), _capi.ptr(bws), nbytes,
-                               _capi.ptr(out["d_log_D"]), _capi.ptr(out["d_log_alph"]),
-                               _capi.ptr(out["d_log_lam1"]), _capi.ptr(out["d_log_h0"]), _stream())
-    _capi.check(rc, h, "drnmf_cell_backward")
+    args = (h, C.byref(desc), _capi.ptr(x), _capi.ptr(params),
+            _capi.ptr(log_h0), float(u[0]), float(u[1]), float(u[2]),
+            _capi.ptr(hall), _capi.ptr(d_out), _capi.ptr(fwd_workspace),
+            fwd_workspace.numel(), _capi.ptr(bws), nbytes,
+            _capi.ptr(out["d_log_D"]), _capi.ptr(out["d_log_alph"]),
+            _capi.ptr(out["d_log_lam1"]), _capi.ptr(out["d_log_h0"]), _stream())
+    if profile is not None:
+        res = (C.c_float * 3)()
+        rc = L.drnmf_cell_backward_profile(*(args + (res,)))
+        _capi.check(rc, h, "drnmf_cell_backward_profile")
+        profile.update(chain_ms=float(res[0]), batched_ms=float(res[1]),
+                       chain_launches=int(res[2]))
+    else:
+        rc = L.drnmf_cell_backward(*args)
+        _capi.check(rc, h, "drnmf_cell_backward")
     return out
 
 

@@ -12,7 +12,8 @@
  *    the library allocates nothing persistent except the opaque handle (error string, cached
  *    hipGraph executables);
  *  - every call enqueues on the caller's `stream` (a hipStream_t passed as void*), never
- *    synchronises the device, and returns a status (0 = OK, <0 = error; text via
+ *    synchronises the device (exceptions, named where they are declared: drnmf_cell_profile, and
+ *    drnmf_comm_init, which is a rendezvous), and returns a status (0 = OK, <0 = error; text via
  *    drnmf_last_error).  Nothing throws or aborts across the ABI;
  *  - all tensors are float32, dense, row-major ("C order") with the shapes given.
  */
@@ -33,7 +34,8 @@ enum {
     DRNMF_ERR_INVALID_ARG = -1,
     DRNMF_ERR_UNSUPPORTED = -2,
     DRNMF_ERR_HIP = -3,
-    DRNMF_ERR_WORKSPACE = -4
+    DRNMF_ERR_WORKSPACE = -4,
+    DRNMF_ERR_RCCL = -5
 };
 
 /* divergence selector for the frame-parallel ISTA / MU kernels */
@@ -236,6 +238,20 @@ int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const 
                             void* bwd_workspace, size_t bwd_workspace_bytes, float* d_log_D,
                             float* d_log_alph, float* d_log_lam1, float* d_log_h0, void* stream);
 
+/* Measurement aid (bench.py only; no reference counterpart): the same backward with HIP events at
+ * its phase boundaries; SYNCHRONISES the stream and returns
+ *   out_ms_host[0] = sequential pass (T reverse-time replays of the 2K-1-launch frame graph), ms
+ *   out_ms_host[1] = time-batched weight-gradient phase, ms
+ *   out_ms_host[2] = number of kernel launches in the sequential pass */
+int32_t drnmf_cell_backward_profile(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                    const void* params, const float* log_h0, float u0_diag,
+                                    float u0_off, float uk_off, const float* hall,
+                                    const float* d_out, const void* fwd_workspace,
+                                    size_t fwd_workspace_bytes, void* bwd_workspace,
+                                    size_t bwd_workspace_bytes, float* d_log_D, float* d_log_alph,
+                                    float* d_log_lam1, float* d_log_h0, void* stream,
+                                    float* out_ms_host);
+
 /* ---- training: Adam (enhance.py:1052-1057; keras.optimizers.Adam [K2.0.4-memory]):
  *   g = grad*grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps)
  * lr_t (bias correction, decay) and grad_scale (1/count, clipnorm factor) are host-computed.
@@ -244,6 +260,27 @@ int32_t drnmf_adam_step(drnmf_handle_t h, int64_t n, float* param, const float* 
                         float* v, float lr_t, float beta1, float beta2, float eps, float grad_scale,
                         void* stream);
 int32_t drnmf_sumsq(drnmf_handle_t h, int64_t n, const float* g, float* out256, void* stream);
+
+/* ---- data-parallel training: ONE all-reduce(sum) per optimiser step over the flat fp32 buffer
+ * [gradients..., sum w*mse, count, rows] and one broadcast that makes the replicas' weights
+ * identical.  The reference is single-device (enhance.py:579: one Theano device);
+ * there is no reference interface to cite, the entry points mirror RCCL's.  The handle owns the
+ * communicator: one handle = one GPU = one rank (one process per GPU).  librccl.so.1 is resolved
+ * with dlopen at the first comm call -- the copy already loaded in the process if there is one.
+ *   drnmf_comm_unique_id   rank 0 obtains the 128-byte id (host memory) and hands it to the other
+ *                          ranks by any out-of-band channel (file, socket, the host's launcher)
+ *   drnmf_comm_init        collective over all `world` ranks (blocks until every rank arrives)
+ *   drnmf_allreduce_grads  in-place sum over ranks of flat[0..n), enqueued on `stream`
+ *   drnmf_broadcast_params buf[0..n) of `root` replaces every rank's, enqueued on `stream`
+ * Errors of the collective library come back as DRNMF_ERR_RCCL with RCCL's text. */
+#define DRNMF_COMM_ID_BYTES 128
+int32_t drnmf_comm_unique_id(drnmf_handle_t h, void* id_out_host);
+int32_t drnmf_comm_init(drnmf_handle_t h, const void* id_host, int32_t rank, int32_t world);
+int32_t drnmf_comm_destroy(drnmf_handle_t h);
+int32_t drnmf_comm_info(drnmf_handle_t h, int32_t* rank, int32_t* world);
+int32_t drnmf_allreduce_grads(drnmf_handle_t h, float* flat, int64_t n, void* stream);
+int32_t drnmf_broadcast_params(drnmf_handle_t h, float* buf, int64_t n, int32_t root,
+                               void* stream);
 
 /* ---- frame-parallel ISTA: replaces ista_ed / ista_kl / ista_beta (enhance.py:402-456).
  * Row-vector layout (frames are rows):  X [n][F], W [F][N] (used as given, NOT re-normalised),

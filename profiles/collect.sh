@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round evidence recipe; run from the repo root on the GPU box:
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r02'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r02a'
 # Writes under gpurun_out/<tag>/ (scratch); copy what should be judged into profiles/.
-# PMC passes are separate runs with --kernel-trace only (never with sys/hip/hsa traces).
+# PMC passes are separate runs with --kernel-trace only (never with sys/hip/hsa traces); the
+# program after `--` is python3 itself (no env/bash hop).
 set -u
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,16 +11,28 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
-# 1. the default bench line
+stats() {   # stats <name> <program args...>: rocprofv3 --kernel-trace --stats summary -> $OUT/<name>_kernel_stats.csv
+    local name=$1; shift
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -o stats -- python3 "$@" \
+        > "$OUT/${name}_under_rocprof.json" 2> "$OUT/$name.err"
+    cp "$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${name}_kernel_stats.csv" 2>/dev/null
+    find "$OUT/$name" -name '*kernel_trace.csv' -size +8M -delete
+    find "$OUT/$name" -name "*.db" -delete
+}
+# 1. the default bench line (fwd+bwd headline, forward block, extras, CPU baseline)
 python3 "$B" > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"
-# 2. kernel trace + stats of the headline workload alone (1 step; the extra lines of the default
-#    command reuse the same kernel templates at other shapes and would blur the per-kernel means)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$B" --steps 1 --warmup 1 \
-    --no-cpu-baseline --no-ista --no-train --no-slab --no-config5 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
-cp "$OUT"/stats/*/stats_kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null || \
-    cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
-# 3. PMC passes, 20 frames of the headline workload (cell + head only)
-SMALL="--frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-ista --no-train --no-slab --no-config5"
+# 2. kernel trace + stats of the headline workload alone: one warm-up + one timed training step
+#    (forward chain, head, loss, BPTT chain, time-batched weight gradients, Adam) and the forward
+#    block; the extra lines reuse the same kernel templates at other shapes and would blur the means
+stats bench "$B" --steps 1 --warmup 1 --no-cpu-baseline --no-extras
+# 3. the forward alone (what the PMC passes below also run)
+stats fwd "$B" --forward-only --steps 1 --warmup 1 --no-cpu-baseline --no-extras
+# 4. frame-parallel ISTA GEMMs, the config-5 shape (fp32 and fp16 operands), the shipped training config
+stats ista "$ROOT/tools/ista_profile.py" 32768 513 2000 25
+stats c5 "$ROOT/tools/c5_profile.py" 16
+stats train_c3 "$ROOT/tools/train_profile.py" 32 500 257 1000 5 3
+# 5. PMC passes, 20 frames of the headline forward (cell + head only)
+SMALL="--forward-only --frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch" -o p -- python3 "$B" $SMALL \
     > /dev/null 2> "$OUT/pmc_fetch.err"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d "$OUT/pmc_write" -o p -- python3 "$B" $SMALL \
@@ -32,4 +45,4 @@ python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_summary.json" "$OUT/pmc_fetc
 find "$OUT" -name '*counter_collection.csv' -size +8M -delete
 find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
 find "$OUT" -name "*.db" -delete
-ls -laR "$OUT" | head -60
+ls -laR "$OUT" | head -80

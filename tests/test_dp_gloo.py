@@ -89,3 +89,48 @@ def test_two_rank_allreduce_equals_unsharded(tmp_path):
     b = _flat_grads(P, alt, labels, K, kc, kn, w, 3, 6)
     naive = 0.5 * (a[:-2] / a[-1] + b[:-2] / b[-1]).numpy()
     assert np.max(np.abs(naive - ref[:-1])) > 1e-6 * np.max(np.abs(ref[:-1]))
+
+
+def _plan_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from drnmf_amd import dp, layers
+    lo, hi = dp.shard(17)                       # 9 / 8 sequences: 2 / 1 mini-batches of 8
+    n = hi - lo
+    steps = dp.max_over_ranks(layers.epoch_steps(n, 8))
+    plan = [(b.tolist(), live) for b, live in layers.epoch_batches(np.arange(n), 8, steps)]
+    # every step is a collective in fit(): stand in for it with the flat-buffer all-reduce
+    tot = []
+    for b, live in plan:
+        flat = torch.tensor([float(len(b)) if live else 0.0, 1.0], dtype=torch.float64)
+        dp.allreduce_sum_(flat)
+        tot.append(flat.tolist())
+    # broadcast: rank 1 starts with different "weights"
+    wts = torch.full((5,), float(rank + 1))
+    dp.broadcast_(wts, 0)
+    np.save(os.path.join(out_dir, "plan%d.npy" % rank),
+            np.array([steps, len(plan)] + [x for t in tot for x in t] + wts.tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_uneven_shards_take_the_same_number_of_steps(tmp_path):
+    """fit() under data parallelism: 17 utterances over 2 ranks with batch_size 8 give 2 and 1
+    local mini-batches; both ranks must run 2 collective steps (the short rank joins the second
+    with zero weights), and broadcast_ makes the replicas equal."""
+    port = _free_port()
+    mp.spawn(_plan_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "plan0.npy"), np.load(tmp_path / "plan1.npy")
+    assert p0[0] == p1[0] == 2 and p0[1] == p1[1] == 2
+    # step 0: 8 + 8 live sequences, step 1: 1 + 0; both ranks took part in both reductions
+    np.testing.assert_array_equal(p0[2:6], [16.0, 2.0, 1.0, 2.0])
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(p0[6:], np.ones(5))
+
+
+def test_epoch_batches_single_rank():
+    from drnmf_amd import layers
+    idx = np.arange(10)[::-1]
+    got = list(layers.epoch_batches(idx, 4, layers.epoch_steps(10, 4)))
+    assert [b.tolist() for b, _ in got] == [[9, 8, 7, 6], [5, 4, 3, 2], [1, 0]]
+    assert all(live for _, live in got)

@@ -1,0 +1,159 @@
+"""Data parallelism of the PRODUCT training step on the GPU.
+
+1. The collective behind the C ABI (drnmf_comm_init / drnmf_allreduce_grads / drnmf_broadcast_params,
+   RCCL resolved by dlopen) on the one GPU of the test box: a single-rank communicator is a real
+   RCCL communicator, so the whole call path (id, init, stream-ordered collectives, destroy) runs.
+2. Two ranks sharing that GPU (RCCL refuses duplicate devices, so the gradient exchange goes through
+   the gloo process group: DRNMF_DP_BACKEND=torch): each rank runs the product's own
+   fit() / train_on_batch -- HIP forward, BPTT, Adam -- on ITS shard of 17 utterances (9 + 8, batch
+   size 8: the short rank joins the last reduction with zero weights), with DIFFERENT initial
+   log_h0 per rank (compile() must broadcast rank 0's) and a keras204 loss normalisation.
+   Expected: both ranks end with bit-identical weights, equal (fp32 summation order aside) to ONE
+   process stepping over the same global batches, and only rank 0 writes the checkpoint.
+3. loss_norm='keras204' against the oracle's 'keras_mask_and_weight'.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import drnmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from drnmf_amd import _capi
+    _capi.handle(0)
+    return torch.device("cuda:0")
+
+
+def test_rccl_communicator_through_the_c_abi(dev):
+    import ctypes as C
+    from drnmf_amd import _capi, dp
+    L, h = _capi.lib(), _capi.handle(0)
+    r, w = C.c_int32(-1), C.c_int32(-1)
+    assert L.drnmf_comm_info(h, C.byref(r), C.byref(w)) == 0 and w.value == 1
+    flat = torch.arange(1, 1001, dtype=torch.float32, device=dev)
+    # no communicator yet: a loud error, not a silent no-op
+    rc = L.drnmf_allreduce_grads(h, _capi.ptr(flat), flat.numel(), None)
+    assert rc == -1 and b"no communicator" in L.drnmf_last_error(h)
+    assert dp.comm_init(dev, rank_=0, world_=1) == (0, 1)
+    want = flat.clone()
+    dp.allreduce_sum_(flat, force=True)
+    dp.broadcast_(flat, 0, force=True)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, want)                     # sum over one rank / broadcast from itself
+    big = torch.rand(3_000_001, device=dev)            # the C3 gradient size class (12 MB)
+    want = big.clone()
+    dp.allreduce_sum_(big, force=True)
+    torch.cuda.synchronize()
+    assert torch.equal(big, want)
+    rc = L.drnmf_broadcast_params(h, _capi.ptr(big), big.numel(), 3, None)
+    assert rc == -1 and b"root" in L.drnmf_last_error(h)
+    assert L.drnmf_comm_init(h, C.create_string_buffer(128), 0, 1) == -1   # already owns one
+    dp.comm_destroy(dev)
+    assert L.drnmf_comm_info(h, C.byref(r), C.byref(w)) == 0 and w.value == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+B_ALL, T, F, R, K = 17, 6, 33, 8, 3
+
+
+def _problem():
+    P = O.synth_problem(B_ALL, T, F, R, seed=21, ragged=True, density=0.15)
+    w = (P["X"] != -1.0).any(-1).astype(np.float32)
+    return P, w
+
+
+def _model(seed):
+    from drnmf_amd import layers
+    P, _ = _problem()
+    N = 2 * R
+    np.random.seed(seed)            # log_h0 draws from the global generator: differs per rank
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph"])
+    return layers.build_unfolded_snmf(p, device="cuda:0")
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DRNMF_DP_BACKEND"] = "torch"       # two ranks on one GPU: no RCCL
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from drnmf_amd import callbacks, dp
+    P, w = _problem()
+    model = _model(seed=100 + rank)
+    model.compile(lr=1e-2, loss_norm="keras204")
+    lo, hi = dp.shard(B_ALL)
+    ck = os.path.join(out_dir, "ck_rank%d.npz" % rank)
+    hist = model.fit(P["X"][lo:hi], P["Y"][lo:hi], sample_weight=w[lo:hi], batch_size=8, epochs=2,
+                     shuffle=False, validation_data=(P["X"][lo:hi], P["Y"][lo:hi], w[lo:hi]),
+                     callbacks=[callbacks.ModelCheckpoint(ck, save_weights_only=True)])
+    np.savez(os.path.join(out_dir, "w%d.npz" % rank), *model.get_weights(),
+             loss=np.array(hist["loss"]), val=np.array(hist["val_loss"]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_product_training_equals_single_process(dev, tmp_path):
+    port = _free_port()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z0, z1 = np.load(tmp_path / "w0.npz"), np.load(tmp_path / "w1.npz")
+    keys = [k for k in z0.files if k.startswith("arr_")]
+    for k in keys:
+        np.testing.assert_array_equal(z0[k], z1[k])         # replicas stay identical
+    np.testing.assert_array_equal(z0["loss"], z1["loss"])
+    np.testing.assert_array_equal(z0["val"], z1["val"])
+    assert os.path.exists(tmp_path / "ck_rank0.npz") and not os.path.exists(tmp_path / "ck_rank1.npz")
+
+    # one process, the same global batches: step 0 = sequences 0-7 (rank 0) + 9-16 (rank 1),
+    # step 1 = sequence 8 (+ rank 1's zero-weight filler), two epochs, rank 0's initial weights
+    P, w = _problem()
+    model = _model(seed=100)
+    model.compile(lr=1e-2, loss_norm="keras204")
+    g0 = list(range(0, 8)) + list(range(9, 17))
+    losses = []
+    for _ in range(2):
+        a = model.train_on_batch(P["X"][g0], P["Y"][g0], w[g0])
+        # the filler rows count as frames of the batch (p = valid / frames)
+        g1 = [8] + list(range(9, 17))
+        w1 = np.concatenate([w[[8]], np.zeros((8, T), np.float32)])
+        b = model.train_on_batch(P["X"][g1], P["Y"][g1], w1)
+        losses.append(0.5 * (a + b))
+    for k, ref in zip(keys, model.get_weights()):
+        got = z0[k]
+        err = np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-30)
+        assert err <= 2e-5, (k, err)
+    np.testing.assert_allclose(z0["loss"], losses, rtol=2e-5)
+
+
+def test_keras204_loss_normalisation_matches_oracle(dev):
+    """loss_norm='keras204' = the oracle's 'keras_mask_and_weight' (weighted_masked_objective with
+    a propagated mask, [K2.0.4-memory]); 'masked_mean' = its default.  Same masks, two scalings."""
+    P, w = _problem()
+    model = _model(seed=3)
+    x = P["X"][:5]
+    mask = model.predict_on_batch(x)
+    for norm, onorm in (("masked_mean", "masked_mean"), ("keras204", "keras_mask_and_weight")):
+        model.compile(lr=1e-3, loss_norm=norm)
+        got = model.test_on_batch(x, P["Y"][:5], w[:5])
+        want = O.loss_mse_of_masked(x.astype(np.float64), mask.astype(np.float64),
+                                    P["Y"][:5].astype(np.float64), w[:5], norm=onorm)
+        assert abs(got - want) <= 1e-5 * abs(want), (norm, got, want)
+        got_tr = model.train_on_batch(x, P["Y"][:5], w[:5])        # loss before the update
+        assert abs(got_tr - want) <= 1e-5 * abs(want), (norm, got_tr, want)

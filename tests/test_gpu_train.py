@@ -85,8 +85,8 @@ def test_gradients_match_autograd(dev, cfg):
     torch.cuda.synchronize()
     ref_loss, ref, cnt = _autograd(model, P, wmask, K, square)
     big = cfg["B"] * cfg["r"] >= 100000
-    assert abs(float(flat[-2]) - ref_loss) <= (5e-5 if big else 1e-5) * abs(ref_loss) + 1e-9
-    assert float(flat[-1]) == cnt
+    assert abs(float(flat[-3]) - ref_loss) <= (5e-5 if big else 1e-5) * abs(ref_loss) + 1e-9
+    assert float(flat[-2]) == cnt
     name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
     checked = 0
     for n, _ in model._train_items:
@@ -156,8 +156,8 @@ def test_snmf_cost_pretraining_gradients_and_fit(dev, cfg):
     flat = pre.loss_and_grads(t(P["X"]), t(P["X"]), t(wmask)).clone()
     torch.cuda.synchronize()
     ref_loss, ref, cnt = _autograd(model, P, wmask, K, False, snmf_cost_l1_weight=lam1 * N / F)
-    assert abs(float(flat[-2]) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-9
-    assert float(flat[-1]) == cnt
+    assert abs(float(flat[-3]) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-9
+    assert float(flat[-2]) == cnt
     name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
     for n, _ in pre._train_items:
         g = pre._gview[n].cpu().numpy()
@@ -237,7 +237,7 @@ def test_full_size_training_step_properties(dev):
     f1 = model.loss_and_grads(x, y, w).clone()
     f2 = model.loss_and_grads(x, y, w).clone()
     assert torch.equal(f1, f2)
-    assert bool(torch.isfinite(f1).all()) and float(f1[-1]) == float(w.sum())
+    assert bool(torch.isfinite(f1).all()) and float(f1[-2]) == float(w.sum())
 
     # linearity of the BPTT in d_out
     cell = model.cell
@@ -260,7 +260,7 @@ def test_full_size_training_step_properties(dev):
     model.loss_and_grads(x, y, w)
     gD = {n: model._gview[n].clone() for n in names}
     gnorm = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in gD.values())))
-    L0 = float(f1[-2])
+    L0 = float(f1[-3])
     # (measured at this shape: steps of 5e-3 / 1.2e-3 / 3e-4 / 8e-5 of the loss give 0.4601 /
     # 0.4822 / 0.4836 / 0.4838 against |g|^2 = 0.4837 -- third-order terms, not the gradient)
     eps = 3e-4 * L0 / gnorm ** 2

@@ -278,3 +278,31 @@ def test_header_is_plain_c_and_lists_every_export():
         pytest.skip("no gcc")
     subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
                     "-I" + os.path.join(ROOT, "include"), src], check=True)
+
+
+def test_early_stopping_min_delta_and_rank0_callbacks():
+    """Keras 2.0.4 EarlyStopping: in 'min' mode an epoch counts as an improvement only if it beats
+    the best by MORE than min_delta; file-writing callbacks are flagged for rank 0."""
+    from drnmf_amd import callbacks
+
+    class M(object):
+        stop_training = False
+    es = callbacks.EarlyStopping(monitor="val_loss", min_delta=0.1, patience=1)
+    es.set_model(M())
+    es.on_train_begin()
+    es.on_epoch_end(0, {"val_loss": 1.00})
+    es.on_epoch_end(1, {"val_loss": 0.95})        # better by less than min_delta: no improvement
+    assert es.best == 1.00 and es.wait == 1 and not es.model.stop_training
+    es.on_epoch_end(2, {"val_loss": 0.85})        # better by more than min_delta
+    assert es.best == 0.85 and es.wait == 0
+    es.on_epoch_end(3, {"val_loss": 0.80})
+    es.on_epoch_end(4, {"val_loss": 0.80})
+    assert es.model.stop_training and es.stopped_epoch == 4
+    mx = callbacks.EarlyStopping(monitor="val_acc", min_delta=0.1, patience=0)
+    mx.set_model(M())
+    mx.on_train_begin()
+    mx.on_epoch_end(0, {"val_acc": 0.5})
+    mx.on_epoch_end(1, {"val_acc": 0.55})
+    assert mx.best == 0.5 and mx.model.stop_training
+    assert callbacks.ModelCheckpoint.rank0_only and callbacks.LossHistory.rank0_only
+    assert not getattr(callbacks.EarlyStopping, "rank0_only", False)

@@ -10,4 +10,4 @@ B, T, F, r, K = [int(v) for v in sys.argv[1:6]]
 steps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 dev = torch.device('cuda:0')
 import __graft_entry__ as G; G.build()
-print(bm.train_bench(torch, dev, steps=steps, shape=(B, T, F, r, K), ragged=False))
+print(bm.train_bench(torch, dev, steps=steps, warmup=1, shape=(B, T, F, r, K), ragged=len(sys.argv) <= 7))
