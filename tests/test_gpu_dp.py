@@ -148,9 +148,9 @@ def test_keras204_loss_normalisation_matches_oracle(dev):
     P, w = _problem()
     model = _model(seed=3)
     x = P["X"][:5]
-    mask = model.predict_on_batch(x)
     for norm, onorm in (("masked_mean", "masked_mean"), ("keras204", "keras_mask_and_weight")):
         model.compile(lr=1e-3, loss_norm=norm)
+        mask = model.predict_on_batch(x)              # (the training step below moves the weights)
         got = model.test_on_batch(x, P["Y"][:5], w[:5])
         want = O.loss_mse_of_masked(x.astype(np.float64), mask.astype(np.float64),
                                     P["Y"][:5].astype(np.float64), w[:5], norm=onorm)
