@@ -42,6 +42,8 @@ static inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * 
 // tile along F), atoms to 32 (one workgroup's atom block)
 static inline int pad_b(int B) { return round_up(B, 16); }
 static inline int pad_f(int F) { return round_up(F, 16); }
+// fp16-operand mode contracts 32 bins per MFMA (v_mfma_f32_16x16x32_f16): whole 32-bin chunks
+static inline int pad_f_mode(int F, bool half) { return round_up(F, half ? 32 : 16); }
 static inline int pad_n(int N) { return round_up(N, 32); }
 
 struct GraphEntry {
@@ -100,10 +102,19 @@ constexpr int MAX_TAIL = 2;   // STFT sizes are 2^k + 1: the odd bin(s) must not
 
 using f16 = _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+// v_mfma_f32_16x16x32_f16 (gfx950): D[i][j] += sum_{k<32} A[i][k] B[k][j]; lane l supplies the 8
+// k-slots (q = l>>4, e = 0..7) of row i = l&15 of A and of column j = l&15 of B -- slot (q, e) of A
+// meets slot (q, e) of B, which is all the packings below rely on; D as in mfma16.
+__device__ __forceinline__ f32x4 mfma32h(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 // params block layout (see drnmf_prepare_params).  off_dn: per stored layer either the fp32
 // tile-packed dictionary Dp[ft][ac][f%16][n%16] or, with operand_f16, two fp16 packings of the same
-// bytes in total (cell_a's, then cell_b's; params.hip).  off_tail: fp32 rows of the tail bins
+// bytes in total (cell_a's, then cell_b's; params.hip; Fp is then a multiple of 32).  off_tail: fp32 rows of the tail bins
 // [n_D][MAX_TAIL][Np] (fp16-rounded values in operand_f16 mode).  off_dnA (fp32 mode only): a
 // second packing of the dictionary for cell_a / bwd_a, whose lanes need 2 atoms x 4 bins per chunk:
 // DpA[ft][n/32][s/2][q][j][s%2][a] = Dn[16 ft + 4s + q][32 (n/32) + 2j + a], so that the operand
@@ -115,7 +126,7 @@ struct ParamsLayout {
 };
 static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     ParamsLayout L;
-    L.Fp = pad_f(d->F);
+    L.Fp = pad_f_mode(d->F, d->operand_f16 != 0);
     L.Np = pad_n(d->N);
     size_t o = 0;
     L.off_dn = o;        o += (size_t)d->n_D * L.Fp * L.Np * sizeof(float);

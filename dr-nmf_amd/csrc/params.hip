@@ -120,17 +120,21 @@ extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
 // One thread per (stored layer, atom column): pass 1 accumulates sum_f exp(log_D)^2 in f order,
 // pass 2 writes exp(log_D)/sqrt(sum) -- enhance.py:177-178 / 190-191 -- into the TILE-PACKED
 // dictionary (1 KB blocks of 16 bins x 16 atoms; see cell_forward.hip).  Padded rows/columns are
-// written as zeros.  HALF = false: fp32 Dp[ft][ac][f%16][n%16].  HALF = true: two fp16 packings,
-//   A (cell_a, contracts bins):  DpA[ft][n/32][q][j][a][e] = Dn[16 ft + 4e + q][32 (n/32) + 2j + a]
-//                                (MFMA k = 4q+e; a lane's two atoms are one 16-byte load)
-//   B (cell_b, contracts atoms): DpB[ft][ac][q][f%16][e] = Dn[f][16 ac + 4q + e]
-// each Fp*Np halves; lane l = q*16 + (j | f%16) reads at l * (16 | 8) bytes of its block.
+// written as zeros.  HALF = false: fp32 Dp[ft][ac][f%16][n%16].  HALF = true: two fp16 packings for
+// v_mfma_f32_16x16x32_f16 (a lane's operand = 8 k-slots (q, e) = 16 bytes; Fp % 32 == 0), 1 KB
+// blocks of 512 halves, lane l = q*16 + j reads at l*16 bytes:
+//   A (cell_a, contracts bins):  block (f/32, n/16): [q][j = n%16][e] = Dn[32 (f/32) + 16 (e/4) +
+//                                4 (e%4) + q][n] -- the bins of slot (q, e) are those of the fp32
+//                                residual / input blocks 2(f/32) + e/4, element s = e%4 of lane q
+//   B (cell_b, contracts atoms): block (f/16, n/32): [q][j = f%16][e] = Dn[f][32 (n/32) + 8q + e]
+// each Fp*Np halves.  With HALF the bins from 16*(F/16) up when F % 16 <= MAX_TAIL (the odd bins
+// handled outside the matrix cores) are ZERO in packing A and B.
 // tail[layer][i][n] = Dn[16*(F/16) + i][n] for the (at most MAX_TAIL) bins past the last full tile.
 template <bool HALF>
 __global__ void __launch_bounds__(256)
 prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
                  float* __restrict__ colnorm, float* __restrict__ tail, float* __restrict__ DnA_,
-                 int F, int N, int Fp, int Np) {
+                 int F, int N, int Fp, int Np, int f_mfma) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int layer = blockIdx.y;
     if (n >= Np) return;
@@ -143,7 +147,7 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
     f16* dA = (f16*)Dn_ + (size_t)layer * 2 * lstride;
     f16* dB = dA + lstride;
     float* dnA = HALF ? nullptr : DnA_ + (size_t)layer * lstride;
-    auto put = [&](int f, float v) {
+    auto put = [&](int f, float v) {   // (v by value: zeroed past f_mfma in the fp16 packings)
         if (!HALF) {
             dn[(size_t)(f >> 4) * NAC * 256 + (f & 15) * 4] = v;
             // cell_a packing (common.h): block (ft, n/32), s = fi/4, q = fi%4, j = (n%32)/2, a = n%2
@@ -151,14 +155,14 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
             dnA[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + (fi >> 3) * 256 +
                 ((fi & 3) * 16 + (n32 >> 1)) * 4 + ((fi >> 2) & 1) * 2 + (n32 & 1)] = v;
         } else {
-            const int fi = f & 15, n32 = n & 31;
-            // A: block (ft, n/32) of 512 halves, lane l = q*16 + j (q = fi%4, j = (n%32)/2) holds
-            //    its 8 halves {a = 0: e = 0..3, a = 1: e = 0..3} (e = fi/4) at l*16 bytes
-            dA[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + ((fi & 3) * 16 + (n32 >> 1)) * 8 +
-               (n32 & 1) * 4 + (fi >> 2)] = (f16)v;
-            // B: block (ft, ac) of 256 halves, lane l = q*16 + f%16 holds atoms 4q..4q+3 at l*8 bytes
-            dB[((size_t)(f >> 4) * NAC + (n >> 4)) * 256 + (((n & 15) >> 2) * 16 + fi) * 4 + (n & 3)] =
-                (f16)v;
+            if (f >= f_mfma) v = 0.f;      // odd bins: outside the matrix cores (tail rows below)
+            const int fi = f & 31, n32 = n & 31;
+            // A: block (f/32, n/16): slot q = fi%4, e = 4*(fi/16) + (fi%16)/4
+            dA[((size_t)(f >> 5) * NAC + (n >> 4)) * 512 + ((fi & 3) * 16 + (n & 15)) * 8 +
+               (fi >> 4) * 4 + ((fi & 15) >> 2)] = (f16)v;
+            // B: block (f/16, n/32): slot q = n32/8, e = n32%8
+            dB[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + ((n32 >> 3) * 16 + (f & 15)) * 8 +
+               (n32 & 7)] = (f16)v;
         }
     };
     const int t0 = (F / 16) * 16;
