@@ -47,6 +47,7 @@ struct CellAArgs {
     const float* rsrc;       // first layer: xp [T][Bp][Fp]; else rpart [KS][Bp][Fp]
     const float* h_in;       // [Bp][Np]  previous layer's h (first layer: the state p)
     float* h_out;            // [Bp][Np]  this layer's h (last layer: the state)
+    f16* h16_out;            // fp16 mode: the same h as Hp16, cell_b's MFMA operand (cell_shared.h)
     float* state;            // [Bp][Np]
     float* rs_part;          // [2][numA][Bp] row sums of the state per atom block, by frame parity
     float* psum;             // [Bp]  sum(p) of the current frame
@@ -65,13 +66,16 @@ struct CellAArgs {
     float* xtail;            // [MAX_TAIL][Bp] tail bins of x_t (published by the first layer)
     float* xcur;             // [Bp][Fp] packed x_t, republished by the first layer for cell_b
     int B, T, N, Bp, Fp, Np, numA, nchunks, KS, ntail;
+    int tail_tile;           // 16-bin tile index of the odd bins (= MFMA tiles of 16 bins)
     int out_width, out_off, write_out;
 };
 
 // G = operand slots (16-bin chunks in flight per wave, prefetch distance G-1).  RB = 16-row blocks per
 // workgroup (see cell_b_kernel): every dictionary operand feeds RB row blocks.
-// HALF: residual and dictionary enter the matrix cores as fp16 (v_mfma_f32_16x16x16_f16: two MFMAs
-// per 16-bin chunk instead of eight), fp32 accumulation; everything else stays fp32.
+// HALF: residual and dictionary are stored as fp16 and enter the matrix cores through
+// v_mfma_f32_16x16x32_f16 (two MFMAs per 32-bin chunk, 16-byte operands per lane; KS = 1; the
+// first layer converts x_t from the fp32 input blocks), fp32 accumulation; state, sums, update and
+// the odd bins stay fp32; h goes out in fp32 (next epilogue) AND as fp16 (cell_b's operand).
 // What the operand addresses need is passed as leading scalar arguments (preloaded into SGPRs by
 // the command processor, see cell_b_kernel); the rest of the struct is fetched by scalar loads that
 // are not on the path to the first operand load.
@@ -119,9 +123,12 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // B: blocks (c, ac0 | ac0+1) of Dp, rows 4s+q, atoms 2j, 2j+1 of the 32
     // fp32: the cell_a packing (common.h): block (c, ab) of 512 floats, lane l reads 2 x 16 bytes
     const float* brow = (const float*)a.Dn + (size_t)ab * 512 + l * 4;
-    // fp16: DpA block (c, ab) of 512 halves, lane's 8 halves = atoms 2j, 2j+1 x k = 4q..4q+3
-    const f16* brow16 = (const f16*)a.Dn + (size_t)ab * 512 + l * 8;
-    const size_t bstep = (size_t)NAC * 256;                                        // per chunk c
+    // fp16: blocks (c, 2ab | 2ab+1) of 512 halves of the A packing (params.hip), 16 bytes per lane
+    const f16* brow16 = (const f16*)a.Dn + (size_t)ab * 1024 + l * 8;
+    const size_t bstep = HALF ? (size_t)NAC * 512 : (size_t)NAC * 256;             // per chunk c
+    // fp16 residual Rp16 (cell_shared.h): block (mb, c) of 512 halves
+    const f16* arow16 = (const f16*)rsrc + (size_t)mb0 * (Fp / 32) * 512 + l * 8;
+    const size_t astep16 = (size_t)(Fp / 32) * 512;
 
     // ---- GEMM operands first (critical path), wave w takes chunks c = w (mod 4) -------------
     // Loads are branch-free (out-of-range chunks are clamped to the last chunk and their A
@@ -130,25 +137,40 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     f32x4 acc[RB][2];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc[rb][0] = acc[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (fp16 mode: a.nchunks counts 32-bin chunks)
     const int per_wave = (a.nchunks - w + NW_A - 1) / NW_A;   // chunks owned by this wave (>= 0)
     const int clast = a.nchunks - 1;
-    constexpr int NP = IS_FIRST ? 1 : KS;
+    // fp32: KS residual partials per chunk (x_t: one).  fp16: the first layer reads the two fp32
+    // input blocks of its 32-bin chunk, the others one fp16 block (ah)
+    constexpr int NP = HALF ? (IS_FIRST ? 2 : 1) : (IS_FIRST ? 1 : KS);
+    constexpr bool A16 = HALF && !IS_FIRST;
 
-    f32x4 av[G][RB][NP];
-    f32x4 bv[G][2];      // {s = 2i: atoms a0 a1, s = 2i+1: a0 a1} for i = 0, 1
-    f16x4 bh[G][2];
+    f32x4 av[A16 ? 1 : G][RB][NP];
+    f32x4 bv[HALF ? 1 : G][2];      // {s = 2i: atoms a0 a1, s = 2i+1: a0 a1} for i = 0, 1
+    f16x8 ah[A16 ? G : 1][RB];
+    f16x8 bh[HALF ? G : 1][2];
     auto load_chunk = [&](int i, int g) {      // chunk i of this wave -> slot g
         int c = w + NW_A * i;
         c = c > clast ? clast : c;
+        if (A16) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * c);
+        } else if (HALF) {          // first layer: fp32 blocks 2c, 2c+1 of the packed input
 #pragma unroll
-            for (int ks = 0; ks < NP; ++ks)
-                av[g][rb][ks] = *(const f32x4*)(arow + rb * astep + 256 * c + (size_t)ks * pstride);
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+                    av[g][rb][hb] = *(const f32x4*)(arow + rb * astep + 256 * (2 * c + hb));
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int ks = 0; ks < NP; ++ks)
+                    av[g][rb][ks] = *(const f32x4*)(arow + rb * astep + 256 * c + (size_t)ks * pstride);
+        }
         if (HALF) {
-            const f16x4* bp = (const f16x4*)(brow16 + (size_t)c * bstep);
-            bh[g][0] = bp[0];
-            bh[g][1] = bp[1];
+            bh[g][0] = *(const f16x8*)(brow16 + (size_t)c * bstep);
+            bh[g][1] = *(const f16x8*)(brow16 + (size_t)c * bstep + 512);
         } else {
             bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
             bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
@@ -164,12 +186,15 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // pattern in 32 does).
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        bv[g][0] = bv[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bh[g][0] = bh[g][1] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (!HALF) bv[g][0] = bv[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (HALF) bh[g][0] = bh[g][1] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
+            if (A16) ah[g][rb] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < NP; ++ks) av[g][rb][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < NP; ++ks)
+                if (!A16) av[g][rb][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(g, g);
@@ -238,7 +263,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             if (i >= a.ntail) continue;
             if (IS_FIRST) {
                 // packed input: bin 16*nchunks + i sits in tile nchunks
-                xt[rb][i] = rsrc[((size_t)(mb0 + rb) * nft + a.nchunks) * 256 + rp_pos(erow, i)];
+                xt[rb][i] = rsrc[((size_t)(mb0 + rb) * nft + a.tail_tile) * 256 + rp_pos(erow, i)];
             } else {
                 xt[rb][i] = a.xtail[(size_t)i * a.Bp + rg];
                 const float* qp = a.q_in + ((size_t)i * a.Bp + rg) * a.numA;
@@ -255,6 +280,30 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // ---- GEMM:  g[16*RB x 32] = r[16*RB x F] . Dn[F x 32] ---------------------------------------
     auto compute_chunk = [&](int base, int g) {
         const bool ok = base + g < per_wave;
+        if (HALF) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                f16x8 a8;
+                if (A16) {
+                    a8 = ah[g][rb];
+                } else {
+                    const f32x4 lo = av[g][rb][0], hi = av[g][rb][1];
+                    if (ab_raw == 0 && ok) {
+                        // republish this row tile's x_t chunk at a frame-independent address
+                        const int c = w + NW_A * (base + g);
+                        float* xc = a.xcur + (size_t)(mb0 + rb) * nft * 256 + 512 * c + l * 4;
+                        *(f32x4*)xc = lo;
+                        *(f32x4*)(xc + 256) = hi;
+                    }
+                    a8 = f16x8{(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3],
+                               (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+                }
+                if (!ok) a8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                acc[rb][0] = mfma32h(a8, bh[g][0], acc[rb][0]);
+                acc[rb][1] = mfma32h(a8, bh[g][1], acc[rb][1]);
+            }
+            return;
+        }
         f32x4 r4[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -268,15 +317,6 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 *(f32x4*)(a.xcur + (size_t)(mb0 + rb) * nft * 256 + 256 * c + l * 4) = r4[rb];
             }
             if (!ok) r4[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (HALF) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const f16x4 rh = {(f16)r4[rb][0], (f16)r4[rb][1], (f16)r4[rb][2], (f16)r4[rb][3]};
-                acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(rh, bh[g][0], acc[rb][0], 0, 0, 0);
-                acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(rh, bh[g][1], acc[rb][1], 0, 0, 0);
-            }
-            return;
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -427,6 +467,9 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 a.rs_part[((size_t)((t + 1) & 1) * a.numA + ab) * a.Bp + rg] = s;
         } else {
             *(f32x2*)(a.h_out + hoff) = hn;
+            if (HALF)   // Hp16 block (mb, ab): slot q = ec/8, e = ec%8 (cell_shared.h)
+                *(f16x2*)(a.h16_out + ((size_t)(mb0 + rb) * (Np / 32) + ab) * 512 +
+                          ((ec >> 3) * 16 + erow) * 8 + (ec & 7)) = f16x2{(f16)hn[0], (f16)hn[1]};
             // tail bins of the next layer's x^: partial dot product over this block's 32 atoms
 #pragma unroll
             for (int i = 0; i < MAX_TAIL; ++i) {
@@ -554,6 +597,8 @@ template <int KS, int RB, bool AH, bool HALF>
 void* a_func_g(int per_wave, bool first, bool last) {
     // G operand slots; operand registers G * (4*KS*RB + 8)
     if (per_wave <= 2) return a_func<2, KS, RB, AH, HALF>(first, last);
+    if (HALF && RB == 1 && per_wave >= 8 && getenv("DRNMF_G8"))   // tuning aid: 8 operand slots
+        return a_func<8, KS, 1, AH, HALF>(first, last);
     // (8 slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch)
     // two groups per wave (F = 513), one row block, fp32: epilogue operand loads behind the first chunk
     bool late = RB == 1 && !HALF && per_wave > 4 && per_wave <= 8;
@@ -578,8 +623,10 @@ void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last) {
 
 void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_hidden, bool half) {
     const int per_wave = (nchunks + NW_A - 1) / NW_A;
-    if (half)   // forward only: the all-hidden output exists for the BPTT, which is fp32
-        return pick_a_func_ah<false, true>(per_wave, KS, RB, first, last);
+    if (half)   // forward only (the all-hidden output exists for the BPTT, which is fp32); KS = 1,
+                // nchunks counts 32-bin chunks
+        return RB == 2 ? a_func_g<1, 2, false, true>(per_wave, first, last)
+                       : a_func_g<1, 1, false, true>(per_wave, first, last);
     return all_hidden ? pick_a_func_ah<true, false>(per_wave, KS, RB, first, last)
                       : pick_a_func_ah<false, false>(per_wave, KS, RB, first, last);
 }
@@ -619,12 +666,15 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     unsigned char* valid = (unsigned char*)(ws + W.off_valid);
     float* rpart = (float*)(ws + W.off_rpart);
     float* hb[2] = {(float*)(ws + W.off_h0), (float*)(ws + W.off_h1)};
+    f16* hb16[2] = {(f16*)(ws + W.off_h16_0), (f16*)(ws + W.off_h16_1)};
+    f16* r16 = (f16*)(ws + W.off_r16);
     float* state = (float*)(ws + W.off_state);
     float* rs_part = (float*)(ws + W.off_rs);
     float* psum = (float*)(ws + W.off_psum);
     int* tA = (int*)(ws + W.off_t);      // frame index read by every kernel of a frame
     int* tB = tA + 16;                   // next frame index, published by the last kernel
     const int K = d->K;
+    const bool half = d->operand_f16 != 0;
 
     // ---- per-call prologue ------------------------------------------------------------------
     {
@@ -640,6 +690,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
                                rs_part, tA, d->N, W.Np, W.Bp, W.numA);
         DRNMF_HIP(h, hipGetLastError());
+        // fp16 mode: cell_b writes the MFMA bin tiles of Rp16 only; the padding of the last 32-bin
+        // chunk (and the odd-bin tile) must be finite: it meets zero dictionary slots
+        if (half) DRNMF_HIP(h, hipMemsetAsync(r16, 0, (size_t)W.Bp * W.Fp * 2, stream));
     }
 
     // ---- one frame = 2K-1 launches, as a cached hipGraph -------------------------------------
@@ -670,9 +723,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     if (fpg_max > d->T) fpg_max = d->T;
 
     const int numM = W.Bp / (ROWS * W.RB), nft = W.nft_main;   // MFMA bin tiles (tail bins handled apart)
-    const dim3 grid_a(8u * (unsigned)numM, (unsigned)(round_up(W.numA, 8) / 8));
+    const dim3 grid_a(8u * (unsigned)(W.Bp / (ROWS * W.RBa)), (unsigned)(round_up(W.numA, 8) / 8));
     const dim3 grid_b(8u * (unsigned)numM, (unsigned)(round_up(nft * W.KS, 8) / 8));
-    const bool half = d->operand_f16 != 0;
     // per stored layer Fp*Np*4 bytes: the fp32 packing, or the fp16 DpA packing followed by DpB
     const char* Dn_base = pb + L.off_dn;
     const size_t dstride = (size_t)L.Fp * L.Np * 4;
@@ -690,9 +742,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.Dn = DnA_of(k);
         a.inv_alpha = (const float*)(pb + L.off_inv_alpha) + (size_t)k * L.Np;
         a.bias = (const float*)(pb + L.off_bias) + (size_t)k * L.Np;
-        a.rsrc = (k == 0) ? xp : rpart;
+        a.rsrc = (k == 0) ? xp : (half ? (const float*)r16 : rpart);
         a.h_in = (k == 0) ? state : hb[(k - 1) & 1];
         a.h_out = (k == K - 1) ? state : hb[k & 1];
+        a.h16_out = hb16[k & 1];
         a.state = state;
         a.rs_part = rs_part;
         a.psum = psum;
@@ -708,7 +761,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         else { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
         a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
         a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
-        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS; a.ntail = W.ntail;
+        a.numA = W.numA; a.nchunks = half ? (nft + 1) / 2 : nft; a.KS = W.KS; a.ntail = W.ntail;
+        a.tail_tile = nft;
         a.Dtail = tail_of(k);
         a.Dtail_next = tail_of(k + 1 < K ? k + 1 : k);
         float* qp = (float*)(ws + W.off_qpart);
@@ -725,9 +779,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     auto make_b = [&](int k) {   // between layer k and k+1
         CellBArgs b;
         b.Dn_next = DnB_of(k + 1);
-        b.h = hb[k & 1];
+        b.h = half ? (const float*)hb16[k & 1] : hb[k & 1];
         b.xp = (const float*)(ws + W.off_xcur);
-        b.rpart = rpart;
+        b.rpart = half ? (float*)r16 : rpart;
         b.t_rd = tA;
         b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS;
         b.logKS = 0;
@@ -757,7 +811,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 CellAParams kpa(a);
                 void** kp = kpa.p;
                 DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
-                DRNMF_HIP(h, hipLaunchKernel(pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1,
+                DRNMF_HIP(h, hipLaunchKernel(pick_a_func(a.nchunks, W.KS, W.RBa, k == 0, k == K - 1,
                                                          d->return_all_hidden != 0, half),
                                              grid_a, dim3(64 * NW_A), kp, 0, stream));
                 if (k < K - 1) {
@@ -833,7 +887,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 CellAArgs a = make_a(k);
                 CellAParams ka_(a);
                 void** ka = ka_.p;
-                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(nft, W.KS, W.RB, k == 0, k == K - 1, d->return_all_hidden != 0, half), grid_a, 64 * NW_A, ka));
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(a.nchunks, W.KS, W.RBa, k == 0, k == K - 1, d->return_all_hidden != 0, half), grid_a, 64 * NW_A, ka));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB, half), grid_b, 64 * NW_B, CellBParams(b).p));
@@ -1001,7 +1055,7 @@ extern "C" int32_t drnmf_cell_forward_ista(drnmf_handle_t h, const drnmf_cell_de
         a.t_wr_add = 1;
         a.u0d = 0.f; a.u0o = 0.f; a.uko = 0.f;
         a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
-        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS; a.ntail = 0;
+        a.numA = W.numA; a.nchunks = nft; a.KS = W.KS; a.ntail = 0; a.tail_tile = nft;
         a.Dtail = tail_of(k);
         a.Dtail_next = tail_of(k);
         float* qp = (float*)(ws + W.off_qpart);

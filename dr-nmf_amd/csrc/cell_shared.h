@@ -14,7 +14,7 @@ constexpr int NW_A = 4;    // waves per cell_a workgroup (8 measured slower, twi
 
 struct CellBArgs {
     const void* Dn_next;     // packed dictionary of the next layer (fp32 Dp, or the fp16 DpB packing)
-    const float* h;          // [Bp][Np]  this layer's h
+    const float* h;          // [Bp][Np]  this layer's h (fp16 mode: the fp16 copy Hp16, see below)
     const float* xp;         // [Bp][Fp] packed x of the CURRENT frame (republished by layer 0's cell_a,
                              // so this kernel needs no frame index); NULL: rpart[ks] = +acc (backward)
     float* rpart;            // [KS][Bp][Fp]
@@ -27,8 +27,12 @@ struct CellBArgs {
 // GB = 16-atom chunks per wave per group.  RB = 16-row blocks per workgroup: large batches (the
 // reference predicts in slabs of 250 utterances, enhance.py:1189-1193) reuse every dictionary
 // operand for RB row blocks, which divides the operand traffic per flop by up to (1 + RB) / 2RB.
-// HALF: both operands enter the matrix cores as fp16 (v_mfma_f32_16x16x16_f16: one MFMA per
-// 16-atom chunk instead of four), fp32 accumulation.
+// HALF (BASELINE config 5): both operands are STORED as fp16 and enter the matrix cores through
+// v_mfma_f32_16x16x32_f16 -- one MFMA per 32-atom chunk, a lane's operand is one 16-byte load --
+// with fp32 accumulation; one atom range (KS = 1), the residual goes out as fp16 in cell_a's
+// operand order.  Tile-packed fp16 buffers (1 KB blocks of 512 halves, lane l = q*16 + row at l*16 B):
+//     Hp16[m][n/32][q][row][e]   atom 32 (n/32) + 8q + e          (cell_b's A operand)
+//     Rp16[m][f/32][q][row][e]   bin  32 (f/32) + 16 (e/4) + 4 (e%4) + q   (cell_a's A operand)
 // The arguments are passed as individual scalars (not as one struct) so that the command
 // processor can preload them into SGPRs (-amdgpu-kernarg-preload-count, build.py): the kernel
 // then starts without a dependent scalar load from the kernarg segment.
@@ -54,34 +58,42 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
     const int l = tid & 63, j = l & 15, q = l >> 4;
     const int Np = a.Np, Fp = a.Fp;
     const int cbase = ks * a.nch_ks;                       // first chunk of this atom range
-    int nch = a.Np / 16 - cbase;                           // chunks left in the matrix
+    int nch = a.Np / (HALF ? 32 : 16) - cbase;             // chunks left in the matrix
     if (nch > a.nch_ks) nch = a.nch_ks;
     if (nch < 1) nch = 1;                                  // (never: KS*nch_ks covers Np/16)
     int per_wave = (nch - w + NW - 1) / NW;
     const int clast = nch - 1;
 
-    const int NAC = Np / 16;
+    const int NAC = HALF ? Np / 32 : Np / 16;              // chunks per row of blocks
     // blocks (mb, cbase+c) of Hp and (ft, cbase+c) of Dp: lane (j, q) = lane q*16 + j reads the
     // float4 of atoms 16c + 4q + {0..3} of row / bin j at lane*16 bytes -> one contiguous 1 KB
-    // block per wave instruction, consecutive lanes on consecutive addresses
+    // block per wave instruction, consecutive lanes on consecutive addresses (fp16: 8 halves of the
+    // 32-atom chunk, same 16 bytes per lane)
     const float* arow = a.h + ((size_t)m * RB * NAC + cbase) * 256 + l * 4;              // + 256*c
     const size_t astep = (size_t)NAC * 256;                                              // per row block
     const float* brow = (const float*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + l * 4;   // [q][bin][e]
-    const f16* brow16 = (const f16*)a.Dn_next + ((size_t)ft * NAC + cbase) * 256 + l * 4;
+    const f16* arow16 = (const f16*)a.h + ((size_t)m * RB * NAC + cbase) * 512 + l * 8;
+    const size_t astep16 = (size_t)NAC * 512;
+    const f16* brow16 = (const f16*)a.Dn_next + ((size_t)ft * NAC + cbase) * 512 + l * 8;
 
     // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
-    f32x4 av[GB][RB], bv[GB];
-    f16x4 bh[GB];
+    f32x4 av[HALF ? 1 : GB][RB], bv[HALF ? 1 : GB];
+    f16x8 ah[HALF ? GB : 1][RB], bh[HALF ? GB : 1];
     auto load_chunk = [&](int base, int g) {
         int c = w + NW * (base + g);
         c = c > clast ? clast : c;
+        if (HALF) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) av[g][rb] = *(const f32x4*)(arow + rb * astep + 256 * c);
-        if (HALF) bh[g] = *(const f16x4*)(brow16 + 256 * c);
-        else bv[g] = *(const f32x4*)(brow + 256 * c);
+            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * c);
+            bh[g] = *(const f16x8*)(brow16 + 512 * c);
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) av[g][rb] = *(const f32x4*)(arow + rb * astep + 256 * c);
+            bv[g] = *(const f32x4*)(brow + 256 * c);
+        }
     };
     // software pipeline: loads run PF chunks ahead of the MFMAs (see cell_a_kernel)
-    constexpr int PF0 = RB > 1 ? 3 : 6;   // (8 = every chunk of the C2 shape up front: no gain)
+    constexpr int PF0 = HALF ? 7 : (RB > 1 ? 3 : 6);   // (8 = every chunk of the C2 shape up front: no gain)
     constexpr int PF = GB < PF0 ? GB : PF0;
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
@@ -110,10 +122,9 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
         if (HALF) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                f16x4 ah;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ah[e] = ok ? (f16)av[g][rb][e] : (f16)0.f;
-                acc[rb][g & 1] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh[g], acc[rb][g & 1], 0, 0, 0);
+                f16x8 a8 = ah[g][rb];
+                if (!ok) a8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                acc[rb][g & 1] = mfma32h(a8, bh[g], acc[rb][g & 1]);
             }
             return;
         }
@@ -126,6 +137,30 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
             }
         }
     };
+    if (HALF) {
+        // rotating operand slots (as cell_a_kernel): chunk i lives in slot i mod GB and its loads run
+        // GB-1 chunks ahead of its MFMA, so the stream never drains between groups -- the
+        // dictionary of this mode comes from HBM (K untied layers exceed the Infinity Cache)
+        auto load_slot = [&](int i, int g) {
+            int c = w + NW * i;
+            c = c > clast ? clast : c;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * c);
+            bh[g] = *(const f16x8*)(brow16 + 512 * c);
+        };
+        // (the prologue above filled slots 0 .. PF-1 = GB-1 or fewer; top up to GB-1)
+#pragma unroll
+        for (int g = PF; g < GB - 1; ++g) load_slot(g, g);
+        for (int base = 0; base < per_wave; base += GB) {
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                load_slot(base + g + GB - 1, (g + GB - 1) % GB);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_chunk(base, g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else
     for (int base = 0; base < per_wave; base += GB) {
         if (base > 0) {
 #pragma unroll
@@ -151,8 +186,15 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
         float s = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) s += red[((ww * RB + rb) * 16 + erow) * 17 + ecol];
-        if (live)
+        if (!live) continue;
+        if (HALF) {
+            // fp16 residual in cell_a's operand order: chunk ft/2, slot (q = bin%4, e = 4 (ft%2) + bin/4)
+            f16* r16 = (f16*)a.rpart + ((size_t)(m * RB + rb) * (Fp / 32) + (ft >> 1)) * 512 +
+                       ((ecol & 3) * 16 + erow) * 8 + (ft & 1) * 4 + (ecol >> 2);
+            *r16 = (f16)((a.xp != nullptr) ? xv[rb] - s : s);
+        } else {
             a.rpart[(size_t)ks * a.Bp * Fp + eoff + rb * estep] = (a.xp != nullptr) ? xv[rb] - s : s;
+        }
     }
 }
 
@@ -200,13 +242,17 @@ struct Workspace {
         off_psum, off_t, total;
     int Bp, Fp, Np, numA, KS, nch_ks;
     int RB;                // 16-row blocks per workgroup (1 or 2); Bp is a multiple of 16*RB
+    int RBa;               // the same for cell_a alone (= RB; the fp16 mode may block cell_a only)
     int nft_main, ntail;   // forward: bins 16*nft_main .. F-1 (at most MAX_TAIL) are handled outside the MFMA tiles
     size_t off_qpart, off_xtail, off_xcur;
+    size_t off_h16_0, off_h16_1, off_r16;   // fp16 operand mode: Hp16 ping-pong, Rp16 (cell_b_kernel)
+    bool half;
 };
 
 Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     Workspace W;
-    W.Fp = pad_f(d->F);
+    W.half = d->operand_f16 != 0;
+    W.Fp = pad_f_mode(d->F, W.half);
     W.Np = pad_n(d->N);
     W.numA = W.Np / ATOMS;
     // (the KL / beta cell applies a nonlinear map to the COMPLETE x^ of every bin: no odd-bin side
@@ -227,7 +273,19 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         const int v = atoi(e);
         if (v == 1 || v == 2) W.RB = v;
     }
-    W.Bp = round_up(d->B, ROWS * W.RB);
+    // fp16 operand mode: cell_b keeps one row block per workgroup (its 16 x 16 output tiles with
+    // the whole contraction are what fills the chip), cell_a may still carry two, which halves the
+    // number of times a dictionary slice is pulled out of the L2
+    W.RBa = W.RB;
+    if (W.half && W.RB == 1) {
+        const int groups = round_up(d->B, ROWS * 2) / (ROWS * 2);
+        (void)groups;   // measured at F=1025, N=8000, B=64: two row blocks 11.8 us per launch, one 11.0: off
+        if (const char* e = getenv("DRNMF_RBA")) {
+            const int v = atoi(e);
+            if (v == 1 || v == 2) W.RBa = v;
+        }
+    }
+    W.Bp = round_up(d->B, ROWS * (W.RBa > W.RB ? W.RBa : W.RB));
     // atom ranges per (row tile group, bin tile) in cell_b: enough workgroups to cover the 256
     // CUs (row-blocked kernels are instantiated for KS <= 2 only)
     const int tiles = (W.Bp / (ROWS * W.RB)) * W.nft_main;
@@ -244,8 +302,9 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         if ((v == 1 || v == 2 || v == 4 || v == 8) && (W.RB == 1 || v <= 2) && nchN / v >= 1) KS = v;
     }
     if (nonlin) KS = 1;
+    if (W.half) KS = 1;        // the fp16 residual is stored once, already rounded (cell_b_kernel)
     W.KS = KS;
-    W.nch_ks = (nchN + KS - 1) / KS;
+    W.nch_ks = W.half ? W.Np / 32 : (nchN + KS - 1) / KS;   // fp16: 32-atom chunks
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += round_up_sz(bytes, 256); return at; };
     W.off_xp = take((size_t)d->T * W.Bp * W.Fp * 4);
@@ -261,6 +320,9 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_qpart = take((size_t)2 * W.numA * MAX_TAIL * W.Bp * 4);
     W.off_xtail = take((size_t)MAX_TAIL * W.Bp * 4);
     W.off_xcur = take((size_t)W.Bp * W.Fp * 4);
+    W.off_h16_0 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
+    W.off_h16_1 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
+    W.off_r16 = take(W.half ? (size_t)W.Bp * W.Fp * 2 : 0);
     W.off_t = take(256);
     W.total = o;
     return W;
@@ -274,6 +336,7 @@ void* pick_b_func_rb(int nch_ks) {
     return (void*)&cell_b_kernel<8, RB, 8, HALF>;
 }
 void* pick_b_func(int nch_ks, int RB = 1, bool half = false) {
+    // fp16: nch_ks counts 32-atom chunks; eight rotating operand slots where a wave owns that many
     if (half) return RB == 2 ? pick_b_func_rb<2, true>(nch_ks) : pick_b_func_rb<1, true>(nch_ks);
     if (RB == 2) return pick_b_func_rb<2, false>(nch_ks);
     return pick_b_func_rb<1, false>(nch_ks);

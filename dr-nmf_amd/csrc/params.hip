@@ -123,9 +123,10 @@ extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
 // written as zeros.  HALF = false: fp32 Dp[ft][ac][f%16][n%16].  HALF = true: two fp16 packings for
 // v_mfma_f32_16x16x32_f16 (a lane's operand = 8 k-slots (q, e) = 16 bytes; Fp % 32 == 0), 1 KB
 // blocks of 512 halves, lane l = q*16 + j reads at l*16 bytes:
-//   A (cell_a, contracts bins):  block (f/32, n/16): [q][j = n%16][e] = Dn[32 (f/32) + 16 (e/4) +
-//                                4 (e%4) + q][n] -- the bins of slot (q, e) are those of the fp32
-//                                residual / input blocks 2(f/32) + e/4, element s = e%4 of lane q
+//   A (cell_a, contracts bins):  block (f/32, 2 (n/32) + a): [q][j][e] = Dn[32 (f/32) + 16 (e/4) +
+//                                4 (e%4) + q][32 (n/32) + 2j + a] -- the bins of slot (q, e) are
+//                                those of the fp32 residual / input blocks 2(f/32) + e/4, element
+//                                s = e%4 of lane q; a = 0 / 1: cell_a's two accumulators
 //   B (cell_b, contracts atoms): block (f/16, n/32): [q][j = f%16][e] = Dn[f][32 (n/32) + 8q + e]
 // each Fp*Np halves.  With HALF the bins from 16*(F/16) up when F % 16 <= MAX_TAIL (the odd bins
 // handled outside the matrix cores) are ZERO in packing A and B.
@@ -157,9 +158,10 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
         } else {
             if (f >= f_mfma) v = 0.f;      // odd bins: outside the matrix cores (tail rows below)
             const int fi = f & 31, n32 = n & 31;
-            // A: block (f/32, n/16): slot q = fi%4, e = 4*(fi/16) + (fi%16)/4
-            dA[((size_t)(f >> 5) * NAC + (n >> 4)) * 512 + ((fi & 3) * 16 + (n & 15)) * 8 +
-               (fi >> 4) * 4 + ((fi & 15) >> 2)] = (f16)v;
+            // A: block (f/32, 2 (n/32) + a), column j: atom n = 32 (n/32) + 2j + a (cell_a's two
+            //    accumulators hold the even / odd atoms of its 32); slot q = fi%4, e = 4*(fi/16) + (fi%16)/4
+            dA[((size_t)(f >> 5) * NAC + 2 * (n >> 5) + (n32 & 1)) * 512 +
+               ((fi & 3) * 16 + (n32 >> 1)) * 8 + (fi >> 4) * 4 + ((fi & 15) >> 2)] = (f16)v;
             // B: block (f/16, n/32): slot q = n32/8, e = n32%8
             dB[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + ((n32 >> 3) * 16 + (f & 15)) * 8 +
                (n32 & 7)] = (f16)v;
@@ -225,15 +227,21 @@ extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_
     const ParamsLayout L = params_layout(d);
     char* base = (char*)params;
     dim3 g1((L.Np + 255) / 256, d->n_D);
+    // bins from f_mfma up are the odd bins the cell keeps out of the matrix cores (workspace_layout:
+    // ntail): zero in the fp16 MFMA packings, present in the tail rows
+    const bool has_tail = d->divergence == DRNMF_DIV_ED && d->F % 16 != 0 &&
+                          d->F % 16 <= MAX_TAIL && d->F > 16;
+    const int f_mfma = has_tail ? (d->F / 16) * 16 : L.Fp;
     if (d->operand_f16)
         hipLaunchKernelGGL(prep_dict_kernel<true>, g1, dim3(256), 0, stream, log_D,
                            (void*)(base + L.off_dn), (float*)(base + L.off_colnorm),
-                           (float*)(base + L.off_tail), (float*)nullptr, d->F, d->N, L.Fp, L.Np);
+                           (float*)(base + L.off_tail), (float*)nullptr, d->F, d->N, L.Fp, L.Np,
+                           f_mfma);
     else
         hipLaunchKernelGGL(prep_dict_kernel<false>, g1, dim3(256), 0, stream, log_D,
                            (void*)(base + L.off_dn), (float*)(base + L.off_colnorm),
                            (float*)(base + L.off_tail), (float*)(base + L.off_dnA), d->F, d->N,
-                           L.Fp, L.Np);
+                           L.Fp, L.Np, f_mfma);
     dim3 g2((L.Np + 255) / 256, d->K);
     hipLaunchKernelGGL(prep_scalars_kernel, g2, dim3(256), 0, stream, log_alph, log_lam1,
                        (float*)(base + L.off_inv_alpha), (float*)(base + L.off_bias), d->N, L.Np,

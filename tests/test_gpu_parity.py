@@ -645,6 +645,10 @@ def test_c_abi_status_codes_and_messages(dev):
     dict(B=5, T=3, F=64, r=16, K=3, untied=()),                      # whole tiles only, tied
     dict(B=2, T=2, F=1025, r=4000, K=3, alph=1600.0),                # BASELINE config 5 width
     dict(B=250, T=2, F=513, r=1000, K=2, alph=400.0),                # row-blocked kernels
+    dict(B=20, T=6, F=49, r=24, K=4, ragged=True),    # odd count of 16-bin MFMA tiles + one odd bin:
+                                                      # the last 32-bin chunk straddles the tail tile
+    dict(B=4, T=3, F=34, r=40, K=3),                  # two odd bins
+    dict(B=16, T=2, F=1025, r=4000, K=50, alph=1600.0),              # BASELINE config 5 at its depth
 ])
 def test_cell_forward_fp16_operands(dev, cfg):
     """BASELINE config 5: fp16 MFMA operands, fp32 accumulate.  Against the oracle's emulation of
