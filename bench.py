@@ -176,7 +176,9 @@ def train_bench(torch, dev, steps=20, warmup=5, shape=(32, 500, 257, 1000, 5), r
     model.train_on_batch(x, y, w)
     bp, pe = model.backward_profile, model.phase_events
     fwd_ms = pe["cell_forward"][0].elapsed_time(pe["cell_forward"][1])
-    launches = T * (2 * K - 1) + bp["chain_launches"]
+    from drnmf_amd import ops as _ops
+    lpf = _ops.cell_launches_per_frame(model.cell._desc(B, T))     # 2K-1 factored, K-1 Gram form
+    launches = T * lpf + bp["chain_launches"]
     launch_us = (fwd_ms + bp["chain_ms"]) * 1e3 / launches
     valid = float(w.sum().item())
     flops = (12.0 * F * N * K - 2.0 * F * N) * B * T
@@ -189,6 +191,8 @@ def train_bench(torch, dev, steps=20, warmup=5, shape=(32, 500, 257, 1000, 5), r
             "valid_frames_per_s": valid / sec, "tflops": flops / sec / 1e12,
             "frac_of_f32_mfma_peak": flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "chain_launches_per_step": launches, "chain_launch_us": launch_us,
+            "form": "gram (one B x N x N contraction per layer-step)" if lpf == K - 1
+                    else "factored (two B x F x N contractions per layer-step)",
             "cell_forward_ms": fwd_ms, "bptt_sequential_ms": bp["chain_ms"],
             "bptt_time_batched_ms": bp["batched_ms"], "steps": steps, "warmup": warmup,
             "timing": "HIP events",
@@ -814,6 +818,9 @@ def main():
             del X
             torch.cuda.empty_cache()
             extra["train_step_configs2"] = safe(train_bench, torch, dev)
+            # the other shipped dictionary size (params_unfolded_snmf_ea1e7d48: r = 100, K = 5)
+            extra["train_step_configs2_r100"] = safe(train_bench, torch, dev,
+                                                     shape=(32, 500, 257, 100, 5))
     out["extra"] = extra
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

@@ -40,6 +40,7 @@ SIGNATURES = {
     "drnmf_params_bytes": (_sz, [_DP]),
     "drnmf_prepare_params": (_i32, [_vp, _DP, _vp, _vp, _vp, _vp, _vp]),
     "drnmf_cell_workspace_bytes": (_sz, [_DP]),
+    "drnmf_cell_launches_per_frame": (_i32, [_DP]),
     "drnmf_cell_forward": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _sz,
                                   _vp]),
     "drnmf_cell_forward_stateful": (_i32, [_vp, _DP, _vp, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp,

@@ -14,6 +14,7 @@
 // log_h0.  Masked steps follow K.rnn: no gradient enters a masked frame; the gradient of its
 // (repeated) output is handed to the last valid frame and the state gradient passes through.
 #include "cell_shared.h"
+#include "cell_gram.h"
 #include "gemm_nt.h"
 #include "gemm_tn.h"
 
@@ -60,6 +61,8 @@ struct EdgeArgs {
     const float* Dtail_top;  // [MAX_TAIL][Np] of layer K-1
     float* dq_out;           // [MAX_TAIL][Bp][numA]
     int ntail;
+    int nparts, ppb;         // row-sum partials per row: numA (1 per 32-atom block), or in the Gram
+                             // form one per 16-atom output tile (2 per block)
 };
 
 __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
@@ -76,7 +79,7 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
     const int rg = m * ROWS + erow, n = ab * ATOMS + ec;
     const size_t hoff = ((size_t)m * NAC + ac0 + (ec >> 4)) * 256 + hp_pos(erow, ec & 15);
     const int KN = a.K * a.N;
-    const size_t pstride = (size_t)a.numA * a.Bp;
+    const size_t pstride = (size_t)a.nparts * a.Bp;
 
     f32x2 ds = *(const f32x2*)(a.dstate + hoff);
     if (c > 0) {
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
         const float* z0 = a.dz0s_part + par * pstride + rg;
         const float* dp_ = a.dps_part + par * pstride + rg;
         float s0 = 0.f, sp = 0.f;
-        for (int b2 = (tid & 15); b2 < a.numA; b2 += 16) {
+        for (int b2 = (tid & 15); b2 < a.nparts; b2 += 16) {
             s0 += z0[(size_t)b2 * a.Bp];
             sp += dp_[(size_t)b2 * a.Bp];
         }
@@ -131,7 +134,9 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
         float s = dz[0] + dz[1];
         s = row16_sum(s);
         if ((tid & 15) == 0) {
-            a.dps_part[par * pstride + (size_t)ab * a.Bp + rg] = 0.f;
+            for (int pp = 0; pp < a.ppb; ++pp)
+                if (ab * a.ppb + pp < a.nparts)
+                    a.dps_part[par * pstride + (size_t)(ab * a.ppb + pp) * a.Bp + rg] = 0.f;
             if (a.K == 1) a.dz0s_part[par * pstride + (size_t)ab * a.Bp + rg] = s;
         }
     } else {
@@ -411,6 +416,14 @@ struct EpiResid {   // R = X - H Dn^T
         R[row * ldr + col] = pv[0] - xh;
     }
 };
+struct EpiStore {   // C = acc
+    float* C;
+    int ldc;
+    __device__ f32x2 pre(int64_t, int) const { return f32x2{0.f, 0.f}; }
+    __device__ void operator()(int64_t row, int col, float acc, f32x2) const {
+        C[row * ldc + col] = acc;
+    }
+};
 struct EpiP1 {      // partial[split] = acc * ia[n]
     float* P;
     const float* ia;
@@ -582,7 +595,8 @@ dlogh0_kernel(const float* __restrict__ dh0_part, const float* __restrict__ log_
 
 struct BwdWs {
     size_t off_dstate, off_gq, off_dzp0, off_dzp1, off_dGp0, off_dGp1, off_drpart, off_z0s, off_dps,
-        off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_P, off_cr, off_dq, total;
+        off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_dnia, off_P, off_cr, off_dq,
+        total;
 };
 BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     BwdWs L;
@@ -593,15 +607,18 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     L.off_dstate = take(hp); L.off_gq = take(hp);
     L.off_dzp0 = take(hp); L.off_dzp1 = take(hp); L.off_dGp0 = take(hp); L.off_dGp1 = take(hp);
     L.off_drpart = take((size_t)MAX_KS * W.Bp * W.Fp * 4);
-    L.off_z0s = take((size_t)2 * W.numA * W.Bp * 4);
-    L.off_dps = take((size_t)2 * W.numA * W.Bp * 4);
+    const int nparts = W.gram ? W.numO : W.numA;
+    L.off_z0s = take((size_t)2 * nparts * W.Bp * 4);
+    L.off_dps = take((size_t)2 * nparts * W.Bp * 4);
     L.off_cnt = take(256);
     L.off_dh0 = take((size_t)(W.Bp / ROWS) * W.Np * 4);
     L.off_dzall = take((size_t)BT * d->K * d->N * 4);
-    L.off_dR = take((size_t)d->K * BT * W.Fp * 4);
+    // d r_k of every layer from the sequential pass; the Gram form recomputes one layer at a time
+    L.off_dR = take((size_t)(W.gram ? 1 : d->K) * BT * W.Fp * 4);
     L.off_xpad = take((size_t)BT * W.Fp * 4);
     L.off_R = take((size_t)BT * W.Fp * 4);
     L.off_dn = take((size_t)W.Fp * W.Np * 4);
+    L.off_dnia = take(W.gram ? (size_t)W.Fp * W.Np * 4 : 0);
     L.off_P = take((size_t)TN_SPLITS * W.Fp * W.Np * 4);
     L.off_cr = take((size_t)CR_SPLITS * 2 * W.Np * 4);
     L.off_dq = take((size_t)2 * MAX_TAIL * W.Bp * W.numA * 4);
@@ -707,7 +724,27 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     const size_t dqstride = (size_t)MAX_TAIL * W.Bp * W.numA;
     ea.Dtail_top = tail_of(K - 1);
     ea.dq_out = dq + (size_t)((K - 1) & 1) * dqstride;   // partials of layer k live in buffer k & 1
-    ea.ntail = W.ntail;
+    ea.ntail = W.gram ? 0 : W.ntail;
+    ea.nparts = W.gram ? W.numO : W.numA;
+    ea.ppb = W.gram ? 2 : 1;
+    auto make_g = [&](int k) {       // Gram form: one launch per layer-step (cell_gram.h)
+        GramBwdArgs g;
+        memset(&g, 0, sizeof(g));
+        g.G = (const float*)(pb + PL.off_gram) + (d->n_D == 1 ? 0 : (size_t)k * PL.Np * PL.Np);
+        g.dGp_in = dGp[k & 1];
+        g.dzp_in = dzp[k & 1];
+        g.ia_prev = ia_of(k - 1);
+        g.dzp_out = dzp[(k - 1) & 1];
+        g.dGp_out = dGp[(k - 1) & 1];
+        g.hall = hall; g.dz_all = dz_all;
+        g.dz0s_part = z0s; g.dps_part = dps;
+        g.c_rd = cA;
+        g.c_wr = (k == 1) ? cB : nullptr;
+        g.uko = uk_off;
+        g.k = k; g.B = B; g.T = T; g.N = N; g.K = K; g.Bp = W.Bp; g.Np = W.Np; g.numO = W.numO;
+        return g;
+    };
+    const dim3 grid_g(8u * (unsigned)numM, (unsigned)(round_up(W.numO, 8) / 8));
 
     auto make_b = [&](int k) {
         CellBArgs b;
@@ -745,7 +782,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         return a;
     };
 
-    std::vector<uint64_t> key = {0xB00Bull, (uint64_t)B, (uint64_t)T, (uint64_t)F, (uint64_t)N,
+    std::vector<uint64_t> key = {W.gram ? 0xB00Cull : 0xB00Bull, (uint64_t)B, (uint64_t)T, (uint64_t)F, (uint64_t)N,
                                  (uint64_t)K, (uint64_t)d->n_D, (uint64_t)(uintptr_t)params,
                                  (uint64_t)(uintptr_t)hall, (uint64_t)(uintptr_t)d_out,
                                  (uint64_t)(uintptr_t)fwd_workspace,
@@ -789,6 +826,12 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
             void* ke[1] = {&ea};
             DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, ke));
             for (int k = K - 1; k >= 1; --k) {
+                if (W.gram) {
+                    GramBwdArgs g = make_g(k);
+                    void* kg[1] = {&g};
+                    DRNMF_HIP(h, add(pick_gram_bwd(W.Np / 16), grid_g, 64 * NW_G, kg));
+                    continue;
+                }
                 CellBArgs b = make_b(k);
                 DRNMF_HIP(h, add(pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, CellBParams(b).p));
                 BwdAArgs a = make_a(k);
@@ -848,8 +891,18 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         const int nsplit = tn_splits(W.Fp, N, BT);
         DRNMF_HIP(h, gemm_tn::launch(t1, EpiP1{P, ia_of(k), W.Np, pstr}, nsplit, stream));
         if (k >= 1) {
-            gemm_tn::Operands t2{dR_all + (size_t)k * BT * W.Fp, hall + (size_t)(k - 1) * N, BT,
-                                 W.Fp, N, W.Fp, KN};
+            const float* dRk = dR_all + (size_t)k * BT * W.Fp;
+            if (W.gram) {
+                // the Gram chain never forms d r_k = (dz_k / alpha_k) Dn_k^T: one more frame-parallel
+                // product, against the dictionary scaled by 1/alpha_k
+                float* DnIa = (float*)(bw + L.off_dnia);
+                hipLaunchKernelGGL(unpack_scaled_kernel, dim3((unsigned)((tot + 255) / 256)),
+                                   dim3(256), 0, stream, Dp_of(k), ia_of(k), DnIa, W.Fp, W.Np);
+                gemm::Operands g2{dz_all + (size_t)k * N, DnIa, BT, W.Fp, N, KN, W.Np};
+                DRNMF_HIP(h, gemm::launch(g2, EpiStore{dR_all, W.Fp}, stream));
+                dRk = dR_all;
+            }
+            gemm_tn::Operands t2{dRk, hall + (size_t)(k - 1) * N, BT, W.Fp, N, W.Fp, KN};
             DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, nsplit, stream));
         }
         const int kd = d->n_D == 1 ? 0 : k;
@@ -875,7 +928,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         DRNMF_HIP(h, hipStreamSynchronize(stream));
         DRNMF_HIP(h, hipEventElapsedTime(&prof_ms[0], pev[0], pev[1]));
         DRNMF_HIP(h, hipEventElapsedTime(&prof_ms[1], pev[1], pev[2]));
-        prof_ms[2] = (float)T * (float)(2 * K - 1) + 1.f;   // launches of the sequential pass
+        prof_ms[2] = (float)T * (float)(W.gram ? K : 2 * K - 1) + 1.f;   // launches of the sequential pass
         for (auto& e : pev) (void)hipEventDestroy(e);
     }
     return DRNMF_OK;

@@ -35,6 +35,8 @@
 // they are not shared between the waves of a workgroup, so an LDS round trip would only add
 // latency; all of a wave's operand loads are issued before its first MFMA.
 #include "cell_shared.h"
+#include "cell_gram.h"
+#include "gemm_nt.h"
 
 #include <type_traits>
 
@@ -633,9 +635,191 @@ void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_h
 
 }  // namespace
 
+extern "C" int32_t drnmf_cell_launches_per_frame(const drnmf_cell_desc_t* d) {
+    if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    if (d->divergence != DRNMF_DIV_ED) return 3 * d->K;
+    return gram_wanted(d) ? d->K - 1 : 2 * d->K - 1;
+}
+
 extern "C" size_t drnmf_cell_workspace_bytes(const drnmf_cell_desc_t* d) {
     if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0) return 0;
     return workspace_layout(d).total;
+}
+
+// ---- Gram form (cell_gram.h): K-1 launches per frame --------------------------------------------
+static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                 float mask_value, const void* params, const float* log_h0,
+                                 float u0_diag, float u0_off, float uk_off, float* h_out,
+                                 void* workspace, hipStream_t stream, const float* initial_state) {
+    const Workspace W = workspace_layout(d);
+    const ParamsLayout L = params_layout(d);
+    char* ws = (char*)workspace;
+    const char* pb = (const char*)params;
+    const int K = d->K, NAC = W.Np / 16, numO = W.numO, numM = W.Bp / ROWS;
+    unsigned char* valid = (unsigned char*)(ws + W.off_valid);
+    float* hb[2] = {(float*)(ws + W.off_h0), (float*)(ws + W.off_h1)};
+    float* state = (float*)(ws + W.off_state);
+    float* rs_part = (float*)(ws + W.off_rs);
+    float* qb[2] = {(float*)(ws + W.off_q0), (float*)(ws + W.off_q1)};
+    float* Cp = (float*)(ws + W.off_cp);
+    float* xpad = (float*)(ws + W.off_xpad);
+    int* tA = (int*)(ws + W.off_t);
+    int* tB = tA + 16;
+    const size_t cstride = (size_t)W.Bp * W.Np;
+    auto ia_of = [&](int k) { return (const float*)(pb + L.off_inv_alpha) + (size_t)k * L.Np; };
+    auto b_of = [&](int k) { return (const float*)(pb + L.off_bias) + (size_t)k * L.Np; };
+    auto G_of = [&](int k) {
+        return (const float*)(pb + L.off_gram) + (d->n_D == 1 ? 0 : (size_t)k * L.Np * L.Np);
+    };
+    auto DnT_of = [&](int k) {
+        return (const float*)(pb + L.off_dnT) + (d->n_D == 1 ? 0 : (size_t)k * L.Np * L.Fp);
+    };
+    // ---- prologue: validity flags, initial state, c_k for every frame and layer -------------------
+    {
+        const size_t rows = (size_t)d->T * W.Bp;
+        hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                           stream, x, (float*)(ws + W.off_xp), valid, mask_value, d->B, d->T, d->F,
+                           W.Bp, W.Fp);
+        hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 255) / 256), dim3(256), 0, stream, valid,
+                           (unsigned char*)(ws + W.off_seen), d->T, W.Bp);
+        if (initial_state)
+            hipLaunchKernelGGL(load_state_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream,
+                               initial_state, state, rs_part, tA, d->B, d->N, W.Np, W.Bp,
+                               (numO + 1) / 2);
+        else
+            hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
+                               rs_part, tA, d->N, W.Np, W.Bp, (numO + 1) / 2);
+        DRNMF_HIP(h, hipGetLastError());
+        // padded batch rows of c are never produced by the GEMM: keep them finite
+        if (W.Bp != d->B)
+            DRNMF_HIP(h, hipMemsetAsync(Cp, 0, (size_t)2 * GRAM_TB * K * cstride * 4, stream));
+    }
+    // c_k of one block of GRAM_TB frames into its ring slot (stream-ordered behind the chain of the
+    // block that used the slot before)
+    auto compute_block = [&](int j) -> int32_t {
+        const int t0 = j * GRAM_TB;
+        if (t0 >= d->T) return DRNMF_OK;
+        const int tbc = d->T - t0 < GRAM_TB ? d->T - t0 : GRAM_TB;
+        const size_t tot = (size_t)d->B * tbc * W.Fp;
+        hipLaunchKernelGGL(gather_block_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                           stream, x, xpad, d->B, d->T, d->F, W.Fp, t0, tbc);
+        DRNMF_HIP(h, hipGetLastError());
+        float* slot = Cp + (size_t)(t0 & (2 * GRAM_TB - 1)) * K * cstride;
+        for (int k = 0; k < K; ++k) {
+            gemm::Operands g{xpad, DnT_of(k), (int64_t)d->B * tbc, W.Np, W.Fp, W.Fp, W.Fp};
+            EpiCPack epi{slot + (size_t)k * cstride, ia_of(k), b_of(k), tbc, K, NAC, cstride};
+            DRNMF_HIP(h, gemm::launch(g, epi, stream));
+        }
+        return DRNMF_OK;
+    };
+    {
+        int32_t rc = compute_block(0);
+        if (rc) return rc;
+        rc = compute_block(1);
+        if (rc) return rc;
+        const size_t tot = cstride;
+        hipLaunchKernelGGL(gram_init_q_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                           stream, state, Cp, qb[0], u0_diag, u0_off, tot);
+        DRNMF_HIP(h, hipGetLastError());
+    }
+    const dim3 grid(8u * (unsigned)numM, (unsigned)(round_up(numO, 8) / 8));
+    auto make = [&](int k, int par) {
+        GramFwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.G = G_of(k);
+        a.a_in = (k == 1) ? qb[par] : hb[(k - 1) & 1];
+        a.ia = ia_of(k);
+        a.Cp = Cp;
+        a.h_out = hb[k & 1];
+        a.state = state;
+        a.qnext = qb[par ^ 1];
+        a.rs_part = rs_part;
+        a.psum = (float*)(ws + W.off_psum);
+        a.psum_all = (float*)(ws + W.off_psum_all);
+        a.valid = valid;
+        a.out = h_out;
+        if (K == 2) {                    // one launch per frame: the two counters alternate
+            a.t_rd = par ? tB : tA; a.t_wr = par ? tA : tB; a.t_wr_add = 1;
+        } else if (k == 1) { a.t_rd = tB; a.t_wr = tA; a.t_wr_add = 0; }
+        else if (k == K - 1) { a.t_rd = tA; a.t_wr = tB; a.t_wr_add = 1; }
+        else { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
+        a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
+        a.B = d->B; a.T = d->T; a.N = d->N; a.K = K; a.k = k; a.Bp = W.Bp; a.Np = W.Np;
+        a.numO = numO;
+        a.out_width = d->return_all_hidden ? d->N * K : d->N;
+        a.all_hidden = d->return_all_hidden ? 1 : 0;
+        a.par = par;
+        return a;
+    };
+    std::vector<uint64_t> key = {
+        0x6A4Dull, (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N, (uint64_t)K,
+        (uint64_t)d->n_D, (uint64_t)d->return_all_hidden, (uint64_t)(uintptr_t)params,
+        (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace};
+    {
+        uint32_t b0, b1, b2;
+        memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
+        key.push_back(b0); key.push_back(b1); key.push_back(b2);
+    }
+    auto get_graph = [&](int frames, hipGraphExec_t* out) -> int32_t {
+        std::vector<uint64_t> gkey = key;
+        gkey.push_back((uint64_t)frames);
+        for (auto& g : h->graphs)
+            if (g.key == gkey) { g.last_stream = stream; *out = g.exec; return DRNMF_OK; }
+        const int32_t erc = graph_cache_make_room(h, stream, 24);
+        if (erc) return erc;
+        GraphEntry ge;
+        ge.key = gkey;
+        DRNMF_HIP(h, hipGraphCreate(&ge.graph, 0));
+        hipGraphNode_t last = nullptr;
+        for (int rep = 0; rep < frames; ++rep) {
+            for (int k = 1; k < K; ++k) {
+                GramFwdArgs a = make(k, rep & 1);
+                void* kp[1] = {&a};
+                hipKernelNodeParams p;
+                memset(&p, 0, sizeof(p));
+                p.func = pick_gram_fwd(NAC, k == 1, k == K - 1);
+                p.gridDim = grid;
+                p.blockDim = dim3(64 * NW_G);
+                p.kernelParams = kp;
+                hipGraphNode_t node;
+                DRNMF_HIP(h, hipGraphAddKernelNode(&node, ge.graph, last ? &last : nullptr,
+                                                   last ? 1 : 0, &p));
+                last = node;
+            }
+        }
+        DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+        ge.last_stream = stream;
+        h->graphs.push_back(ge);
+        *out = ge.exec;
+        return DRNMF_OK;
+    };
+    // an even number of frames per graph (the frame parity of every node is then static) that
+    // divides the block length
+    int fpg = 2;
+    while (fpg * 2 <= GRAM_TB && fpg * 2 * (K - 1) <= 800) fpg *= 2;
+    hipGraphExec_t ex = nullptr;
+    for (int j = 0; j * GRAM_TB < d->T; ++j) {
+        const int t1 = (j + 1) * GRAM_TB < d->T ? (j + 1) * GRAM_TB : d->T;
+        int t = j * GRAM_TB;
+        if (t1 - t >= fpg) {
+            int32_t rc = get_graph(fpg, &ex);
+            if (rc) return rc;
+            for (; t + fpg <= t1; t += fpg) DRNMF_HIP(h, hipGraphLaunch(ex, stream));
+        }
+        if (t1 - t >= 2) {
+            int32_t rc = get_graph(2, &ex);
+            if (rc) return rc;
+            for (; t + 2 <= t1; t += 2) DRNMF_HIP(h, hipGraphLaunch(ex, stream));
+        }
+        if (t < t1) {                    // (t is even here: a single frame of parity 0)
+            int32_t rc = get_graph(1, &ex);
+            if (rc) return rc;
+            DRNMF_HIP(h, hipGraphLaunch(ex, stream));
+        }
+        int32_t rc = compute_block(j + 2);
+        if (rc) return rc;
+    }
+    return DRNMF_OK;
 }
 
 static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
@@ -659,6 +843,13 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 255))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "workspace/params must be 256-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
+    if (W.gram) {
+        if (profile_frames > 0)
+            DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
+                       "cell_profile brackets the factored launches; this call takes the Gram form");
+        return cell_forward_gram(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off,
+                                 h_out, workspace, stream, initial_state);
+    }
     const ParamsLayout L = params_layout(d);
     char* ws = (char*)workspace;
     const char* pb = (const char*)params;

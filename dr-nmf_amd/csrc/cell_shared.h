@@ -237,6 +237,26 @@ pack_input_kernel(const float* __restrict__ x, float* __restrict__ xp,
 }
 
 
+// Whether a call takes the Gram form.  A Gram launch streams 8 * numM * Np^2 bytes from the L2
+// (every 16 x 16 output tile reads 16 rows of h and 16 rows of G); measured on MI355X
+// (tools/profile_shape.py with DRNMF_GRAM=0|1; F = 257, K = 5, B = 32; us per layer-step, factored
+// pair -> Gram launch): N = 200 6.0 -> 4.2, N = 512 6.1 -> 4.4, N = 1000 6.3 -> 5.7, N = 2000 7.7 ->
+// 8.9; N = 200 wins 1.5-1.6x at every batch from 1 to 250.  Rule: numM * Np^2 <= 3e6 (the crossover
+// sits near 25 MB of operand traffic per launch), independent of T and K.
+constexpr int64_t GRAM_MAX_WORK = 3000000;
+constexpr int GRAM_TB = 64;          // frames per block of the hoisted c_k products (ring of 2 blocks)
+static inline bool gram_wanted(const drnmf_cell_desc_t* d) {
+    if (!gram_eligible(d)) return false;
+    const int Np = pad_n(d->N), Bp = round_up(d->B, ROWS);
+    // (no dependence on T: a time prefix of a batch must take the same form)
+    bool want = (int64_t)(Bp / ROWS) * Np * Np <= GRAM_MAX_WORK;
+    if (const char* e = getenv("DRNMF_GRAM")) {            // tuning aid: force the choice
+        if (atoi(e) == 0) want = false;
+        if (atoi(e) == 1) want = true;
+    }
+    return want;
+}
+
 struct Workspace {
     size_t off_xp, off_valid, off_seen, off_psum_all, off_rpart, off_h0, off_h1, off_state, off_rs,
         off_psum, off_t, total;
@@ -247,10 +267,16 @@ struct Workspace {
     size_t off_qpart, off_xtail, off_xcur;
     size_t off_h16_0, off_h16_1, off_r16;   // fp16 operand mode: Hp16 ping-pong, Rp16 (cell_b_kernel)
     bool half;
+    // Gram form (cell_gram.h): packed c, ring of 2 x GRAM_TB frames [.][K][Bp][Np]; one block of x
+    // padded row-major [B][GRAM_TB][Fp]; q ping-pong
+    bool gram;
+    int numO;              // output tiles of 16 atoms (= row-sum partials per row)
+    size_t off_cp, off_xpad, off_q0, off_q1;
 };
 
 Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     Workspace W;
+    W.gram = gram_wanted(d);
     W.half = d->operand_f16 != 0;
     W.Fp = pad_f_mode(d->F, W.half);
     W.Np = pad_n(d->N);
@@ -273,6 +299,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         const int v = atoi(e);
         if (v == 1 || v == 2) W.RB = v;
     }
+    if (W.gram) W.RB = 1;   // (one row block per workgroup: gram_wanted() counts 16-row tiles)
     // fp16 operand mode: cell_b keeps one row block per workgroup (its 16 x 16 output tiles with
     // the whole contraction are what fills the chip), cell_a may still carry two, which halves the
     // number of times a dictionary slice is pulled out of the L2
@@ -315,7 +342,8 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_h0 = take((size_t)W.Bp * W.Np * 4);
     W.off_h1 = take((size_t)W.Bp * W.Np * 4);
     W.off_state = take((size_t)W.Bp * W.Np * 4);
-    W.off_rs = take((size_t)2 * W.numA * W.Bp * 4);
+    W.numO = W.Np / 16;
+    W.off_rs = take((size_t)2 * (W.gram ? W.numO : W.numA) * W.Bp * 4);
     W.off_psum = take((size_t)W.Bp * 4);
     W.off_qpart = take((size_t)2 * W.numA * MAX_TAIL * W.Bp * 4);
     W.off_xtail = take((size_t)MAX_TAIL * W.Bp * 4);
@@ -323,6 +351,10 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_h16_0 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_h16_1 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_r16 = take(W.half ? (size_t)W.Bp * W.Fp * 2 : 0);
+    W.off_cp = take(W.gram ? (size_t)2 * GRAM_TB * d->K * W.Bp * W.Np * 4 : 0);
+    W.off_xpad = take(W.gram ? (size_t)d->B * GRAM_TB * W.Fp * 4 : 0);
+    W.off_q0 = take(W.gram ? (size_t)W.Bp * W.Np * 4 : 0);
+    W.off_q1 = take(W.gram ? (size_t)W.Bp * W.Np * 4 : 0);
     W.off_t = take(256);
     W.total = o;
     return W;

@@ -120,9 +120,24 @@ __device__ __forceinline__ f32x4 mfma32h(f16x8 a, f16x8 b, f32x4 c) {
 // DpA[ft][n/32][s/2][q][j][s%2][a] = Dn[16 ft + 4s + q][32 (n/32) + 2j + a], so that the operand
 // comes in two 16-byte loads per lane over contiguous 1 KB (8-byte loads run at half the
 // texture-path rate).
+// Gram form of the cell (cell_gram.h): h S_k with S_k = I - G_k diag(1/alpha_k), G_k = Dn_k^T Dn_k
+// -- the matrix the reference itself materialises (enhance.py:172-181) -- is ONE launch per
+// layer-step instead of the factored pair.  Worth it when the batch is small (each launch is
+// latency, not work) and N x N per stored layer is affordable; the prepared block then also holds
+//   off_gram: G packed as cell_b's operand, [n_D][Np/16][Np/16][q][o%16][e] = G[o][16 ac + 4q + e]
+//   off_dnT:  Dn^T row-major [n_D][Np][Fp] (operand of the frame-parallel x Dn_k product)
+//   off_dn_rm: scratch, one layer of Dn row-major [Fp][Np]
+// for fp32 Euclidean descriptors with N <= GRAM_MAX_N (a property of the descriptor's F, N, K only:
+// the same block serves every batch size).
+constexpr int GRAM_MAX_N = 4096;
+static inline bool gram_eligible(const drnmf_cell_desc_t* d) {
+    return !d->operand_f16 && d->divergence == DRNMF_DIV_ED && d->N <= GRAM_MAX_N && d->K >= 2;
+}
+
 struct ParamsLayout {
     int Fp, Np;
     size_t off_dn, off_colnorm, off_inv_alpha, off_bias, off_tail, off_dnA, total;
+    size_t off_gram, off_dnT, off_dn_rm;   // (0 unless gram_eligible)
 };
 static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     ParamsLayout L;
@@ -136,6 +151,12 @@ static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     L.off_tail = o;      o += round_up_sz((size_t)d->n_D * MAX_TAIL * L.Np * sizeof(float), 256);
     L.off_dnA = o;
     if (!d->operand_f16) o += (size_t)d->n_D * L.Fp * L.Np * sizeof(float);
+    L.off_gram = L.off_dnT = L.off_dn_rm = 0;
+    if (gram_eligible(d)) {
+        L.off_gram = o;  o += (size_t)d->n_D * L.Np * L.Np * sizeof(float);
+        L.off_dnT = o;   o += (size_t)d->n_D * L.Np * L.Fp * sizeof(float);
+        L.off_dn_rm = o; o += (size_t)L.Fp * L.Np * sizeof(float);
+    }
     L.total = o;
     return L;
 }

@@ -2,6 +2,7 @@
 // Reference: build_alt's maps_from_alt (enhance.py:161-204), evaluated in
 // SimpleDeepRNN.build (custom_layers.py:234-287).
 #include "common.h"
+#include "gemm_tn.h"
 
 char g_create_err[512] = {0};
 
@@ -111,6 +112,29 @@ int validate_cell_desc(drnmf_handle_t h, const drnmf_cell_desc_t* d) {
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "output tensor too large");
     return DRNMF_OK;
 }
+
+// Dp (cell_b's fp32 packing) -> Dn row-major [Fp][Np] and its transpose [Np][Fp]
+__global__ void __launch_bounds__(256)
+unpack_both_kernel(const float* __restrict__ Dp, float* __restrict__ Dn_rm,
+                   float* __restrict__ DnT, int Fp, int Np) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Fp * Np) return;
+    const int f = (int)(i / Np), n = (int)(i % Np);
+    const float v = Dp[((size_t)(f >> 4) * (Np / 16) + (n >> 4)) * 256 +
+                       (((n & 15) >> 2) * 16 + (f & 15)) * 4 + (n & 3)];
+    Dn_rm[i] = v;
+    DnT[(size_t)n * Fp + f] = v;
+}
+
+struct EpiGramPack {   // G[o][i] = sum_f Dn[f][o] Dn[f][i] -> cell_b operand packing (common.h)
+    float* Gp;
+    int NAC;
+    __device__ float pre(int, int, int) const { return 0.f; }
+    __device__ void operator()(int, int o, int i, float acc, float) const {
+        Gp[((size_t)(o >> 4) * NAC + (i >> 4)) * 256 + (((i & 15) >> 2) * 16 + (o & 15)) * 4 +
+           (i & 3)] = acc;
+    }
+};
 
 extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
     if (!d || d->F <= 0 || d->N <= 0 || d->K <= 0 || d->n_D <= 0) return 0;
@@ -247,5 +271,19 @@ extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_
                        (float*)(base + L.off_inv_alpha), (float*)(base + L.off_bias), d->N, L.Np,
                        d->n_alph, d->alph_len, d->n_lam);
     DRNMF_HIP(h, hipGetLastError());
+    if (gram_eligible(d)) {
+        // G_k = Dn_k^T Dn_k per stored layer (2 N^2 F flops each) + the transposed dictionary
+        const size_t lstride = (size_t)L.Fp * L.Np;
+        float* Dn_rm = (float*)(base + L.off_dn_rm);
+        for (int k = 0; k < d->n_D; ++k) {
+            hipLaunchKernelGGL(unpack_both_kernel, dim3((unsigned)((lstride + 255) / 256)),
+                               dim3(256), 0, stream,
+                               (const float*)(base + L.off_dn) + (size_t)k * lstride, Dn_rm,
+                               (float*)(base + L.off_dnT) + (size_t)k * lstride, L.Fp, L.Np);
+            gemm_tn::Operands g{Dn_rm, Dn_rm, L.Fp, L.Np, L.Np, L.Np, L.Np};
+            EpiGramPack epi{(float*)(base + L.off_gram) + (size_t)k * L.Np * L.Np, L.Np / 16};
+            DRNMF_HIP(h, gemm_tn::launch(g, epi, 1, stream));
+        }
+    }
     return DRNMF_OK;
 }

@@ -81,6 +81,11 @@ def unpack_params(block, desc):
     return Dn, colnorm, inv_alpha, bias
 
 
+def cell_launches_per_frame(desc):
+    """Chain launches per frame of the forward for this descriptor (2K-1 factored, K-1 Gram form)."""
+    return int(_capi.lib().drnmf_cell_launches_per_frame(C.byref(desc)))
+
+
 def cell_workspace(desc, device):
     nbytes = _capi.lib().drnmf_cell_workspace_bytes(C.byref(desc))
     return torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -96,6 +96,12 @@ int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_t* d, const
  *   h_out  [B][T][N]   (or [B][T][K*N] with return_all_hidden)
  *   workspace          >= drnmf_cell_workspace_bytes(d), 256-byte aligned, contents scratch */
 size_t drnmf_cell_workspace_bytes(const drnmf_cell_desc_t* d);
+/* Kernel launches of the sequential chain per frame for this descriptor: 2K-1 in the factored form
+ * (two dependent B x F x N contractions per layer-step), K-1 in the Gram form (one B x N x N
+ * contraction per layer-step against the G_k = Dn_k^T Dn_k that drnmf_prepare_params builds; taken
+ * for small dictionaries, csrc/cell_gram.h), 3K for the KL / beta cell.  The BPTT adds one launch
+ * per frame to the same count. */
+int32_t drnmf_cell_launches_per_frame(const drnmf_cell_desc_t* d);
 int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
                            float mask_value, const void* params, const float* log_h0,
                            float u0_diag, float u0_off, float uk_off, float* h_out,

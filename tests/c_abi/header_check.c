@@ -24,5 +24,5 @@ fn_t drnmf_all_exports[] = {
     REF(drnmf_loss_forward), REF(drnmf_wav_int16_workspace_bytes), REF(drnmf_wav_int16),
     REF(drnmf_cell_backward_profile), REF(drnmf_comm_unique_id), REF(drnmf_comm_init),
     REF(drnmf_comm_destroy), REF(drnmf_comm_info), REF(drnmf_allreduce_grads),
-    REF(drnmf_broadcast_params),
+    REF(drnmf_broadcast_params), REF(drnmf_cell_launches_per_frame),
 };

@@ -16,3 +16,16 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_numpy_golden.npz"))
+
+
+@pytest.fixture
+def cell_form(request, monkeypatch):
+    """The recurrent cell has two forms (csrc/cell_gram.h): the factored pair of contractions and,
+    for small dictionaries, the Gram form.  'auto' leaves the library's rule in charge; 'factored'
+    forces the factored kernels (DRNMF_GRAM=0, read by libdrnmf at every call) so that the small
+    parity shapes keep exercising them too."""
+    if request.param == "factored":
+        monkeypatch.setenv("DRNMF_GRAM", "0")
+    else:
+        monkeypatch.delenv("DRNMF_GRAM", raising=False)
+    return request.param

@@ -157,3 +157,36 @@ def test_keras204_loss_normalisation_matches_oracle(dev):
         assert abs(got - want) <= 1e-5 * abs(want), (norm, got, want)
         got_tr = model.train_on_batch(x, P["Y"][:5], w[:5])        # loss before the update
         assert abs(got_tr - want) <= 1e-5 * abs(want), (norm, got_tr, want)
+
+
+def test_gram_and_factored_forms_agree(dev, monkeypatch):
+    """csrc/cell_gram.h: the Gram form (one B x N x N contraction per layer-step, hoisted x Dn_k
+    products, layer 0 folded into the first launch) against the factored kernels on the same
+    inputs -- forward, every hidden layer, and the BPTT gradients; both within fp32 rounding of each
+    other (they are checked against the fp64 oracle separately)."""
+    from drnmf_amd import layers, ops
+    P = O.synth_problem(37, 131, 65, 40, seed=8, ragged=True, density=0.1)   # > 2 ring blocks of frames
+    N, K = 80, 4
+    p = dict(input_dim=65, hidden_dim=N, output_dim=65, mask_value=-1., maxseq=131, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph", "log_lam1"])
+    w = (P["X"] != -1.0).any(-1).astype(np.float32)
+    res = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("DRNMF_GRAM", form)
+        np.random.seed(5)
+        model = layers.build_unfolded_snmf(p, device=dev)
+        desc = model.cell._desc(37, 131)
+        assert ops.cell_launches_per_frame(desc) == (K - 1 if form == "1" else 2 * K - 1)
+        model.compile(lr=1e-3)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        flat = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(w)).clone()
+        hall = model.cell.forward_train(t(P["X"]), mask_value=-1.).clone()
+        res[form] = (flat.cpu().numpy(), hall.cpu().numpy(), model.predict_on_batch(P["X"]))
+    f0, h0, m0 = res["0"]
+    f1, h1, m1 = res["1"]
+    assert np.max(np.abs(h0 - h1)) <= 2e-5 * np.max(np.abs(h0))
+    assert np.mean((m0 - m1) ** 2) <= 1e-12
+    assert f0[-2] == f1[-2] and abs(f0[-3] - f1[-3]) <= 1e-5 * abs(f0[-3])
+    g0, g1 = f0[:-3], f1[:-3]
+    assert np.max(np.abs(g0 - g1)) <= 2e-4 * np.max(np.abs(g0))

@@ -15,7 +15,8 @@ import test_gpu_parity as TP      # noqa: E402
 import test_gpu_train as TT       # noqa: E402
 from oracle import drnmf_oracle as O   # noqa: E402
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cell_form"),
+              pytest.mark.parametrize("cell_form", ["auto", "factored"], indirect=True)]
 
 
 @pytest.fixture(scope="module")

@@ -10,7 +10,8 @@ import torch
 
 from oracle import drnmf_oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cell_form"),
+              pytest.mark.parametrize("cell_form", ["auto", "factored"], indirect=True)]
 
 H_TOL = 1e-4
 MASK_MSE_TOL = 1e-8

@@ -9,7 +9,8 @@ import torch
 from oracle import drnmf_oracle as O
 from oracle import drnmf_torch_ref as TR
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cell_form"),
+              pytest.mark.parametrize("cell_form", ["auto", "factored"], indirect=True)]
 G_TOL = 2e-3
 
 
