@@ -128,16 +128,42 @@ __global__ void __launch_bounds__(64 * NW_G) gram_fwd_kernel(const GramFwdArgs a
     const int t = *a.t_rd;
     if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
 
+    // Epilogue operands: nothing the update needs may wait for the contraction to finish.  What
+    // does not depend on the frame index is loaded first (ahead of the MFMA operands: the in-order
+    // vmcnt wait of the first MFMA then covers a handful of small loads more); what does (c_k[t],
+    // the validity flag) is loaded in `mid`, behind the first operand loads, when the scalar load
+    // of t has long returned.
+    const bool ethr = tid < 256;
+    const int erow = (tid & 255) >> 4, ecol = tid & 15;
+    const int rg = m * 16 + erow, n = ot * 16 + ecol;
+    const size_t hoff = ((size_t)m * NAC + ot) * 256 + hp_pos(erow, ecol);
+    const size_t cstride = (size_t)a.Bp * a.Np;                       // one (t, k) slice of Cp
+    constexpr int RING = 2 * GRAM_TB;
+    float hraw = 0.f, iav = 0.f, psl = 0.f, st_old = 0.f, ck = 0.f, cnext = 0.f;
+    bool vld = true;
     // sum(p) of the 16 rows (first launch of a frame): the row sums left per output tile by the
-    // previous frame's last layer, added in a fixed order (deterministic).  The loads go out ahead
-    // of the operand loads, the reduction runs behind them (gram_contract's `mid`).
+    // previous frame's last layer, added in a fixed order (deterministic); reduced in `mid`.
     float rsum = 0.f;
     if (FIRST) {
         const int row = tid & 15, pt = tid >> 4;            // 32 parts
         const float* rp = a.rs_part + (size_t)a.par * a.numO * a.Bp + m * 16 + row;
         for (int b2 = pt; b2 < a.numO; b2 += 32) rsum += rp[(size_t)b2 * a.Bp];
     }
+    if (ethr) {
+        hraw = a.a_in[hoff];
+        iav = a.ia[n];
+        if (!FIRST) psl = a.psum[rg];
+        if (LAST) st_old = a.state[hoff];
+    }
     auto mid = [&]() {
+        if (ethr) {
+            ck = a.Cp[((size_t)(t & (RING - 1)) * a.K + a.k) * cstride + hoff];
+            vld = a.valid[(size_t)t * a.Bp + rg] != 0;
+            if (LAST) {
+                const int tn = t + 1 < a.T ? t + 1 : t;
+                cnext = a.Cp[((size_t)(tn & (RING - 1)) * a.K) * cstride + hoff];
+            }
+        }
         if (!FIRST) return;
         part[tid >> 4][tid & 15] = rsum;
         __syncthreads();
@@ -151,24 +177,17 @@ __global__ void __launch_bounds__(64 * NW_G) gram_fwd_kernel(const GramFwdArgs a
         __syncthreads();
     };
     const float s = gram_contract<GS, FIRST>(a.G, a.a_in, ps16, m, ot, NAC, red, mid);
-    if (tid >= 256) return;
+    if (!ethr) return;
 
-    const int erow = tid >> 4, ecol = tid & 15;
-    const int rg = m * 16 + erow, n = ot * 16 + ecol;
-    const size_t hoff = ((size_t)m * NAC + ot) * 256 + hp_pos(erow, ecol);
-    const size_t cstride = (size_t)a.Bp * a.Np;                       // one (t, k) slice of Cp
-    const float ps = FIRST ? psv[erow] : a.psum[rg];
+    const float ps = FIRST ? psv[erow] : psl;
     if (FIRST && ot_raw == 0 && ecol == 0) {
         a.psum[rg] = ps;
         a.psum_all[(size_t)t * a.Bp + rg] = ps;
     }
-    float hprev = a.a_in[hoff];
+    float hprev = hraw;
     if (FIRST) hprev = fmaxf(hprev + a.u0o * ps, 0.f);                // h_0
-    constexpr int RING = 2 * GRAM_TB;
-    const float ck = a.Cp[((size_t)(t & (RING - 1)) * a.K + a.k) * cstride + hoff];
-    const float pre = hprev - s * a.ia[n] + ck + a.uko * ps;
+    const float pre = hprev - s * iav + ck + a.uko * ps;
     const float hn = fmaxf(pre, 0.f);
-    const bool vld = a.valid[(size_t)t * a.Bp + rg] != 0;
     if (live && rg < a.B && n < a.N) {
         // K.rnn masking: a masked step repeats the previous output (zeros before the first valid)
         float* orow = a.out + ((size_t)rg * a.T + t) * a.out_width;
@@ -190,14 +209,12 @@ __global__ void __launch_bounds__(64 * NW_G) gram_fwd_kernel(const GramFwdArgs a
     }
     if (!live) return;
     if (LAST) {
-        const float st = vld ? hn : a.state[hoff];                    // a masked step keeps the state
+        const float st = vld ? hn : st_old;                           // a masked step keeps the state
         a.state[hoff] = st;
         const float rs = row16_sum(st);
         if (ecol == 0) a.rs_part[((size_t)(a.par ^ 1) * a.numO + ot) * a.Bp + rg] = rs;
         // q of the next frame: everything of its layer 0 except u0o * sum(p)
-        const int tn = t + 1 < a.T ? t + 1 : t;
-        a.qnext[hoff] = (a.u0d - a.u0o) * st +
-                        a.Cp[((size_t)(tn & (RING - 1)) * a.K) * cstride + hoff];
+        a.qnext[hoff] = (a.u0d - a.u0o) * st + cnext;
     } else {
         a.h_out[hoff] = hn;
     }
@@ -269,20 +286,29 @@ __global__ void __launch_bounds__(64 * NW_G) gram_bwd_kernel(const GramBwdArgs a
     const int NAC = a.Np / 16;
     const int cnt = *a.c_rd;
     if (a.c_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.c_wr = cnt + 1;
-    const float s = gram_contract<GS, false>(a.G, a.dGp_in, nullptr, m, ot, NAC, red, []() {});
-    if (tid >= 256 || !live) return;
-    const int t = a.T - 1 - cnt;
-    const int erow = tid >> 4, ecol = tid & 15;
+    // (epilogue operands early, as in gram_fwd_kernel)
+    const bool ethr = tid < 256;
+    const int erow = (tid & 255) >> 4, ecol = tid & 15;
     const int rg = m * 16 + erow, n = ot * 16 + ecol;
     const size_t hoff = ((size_t)m * NAC + ot) * 256 + hp_pos(erow, ecol);
     const int KN = a.K * a.N;
-    const float dzk = a.dzp_in[hoff];
     const bool in = rg < a.B && n < a.N;
-    const float hprev = in ? a.hall[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n] : 0.f;
+    float dzk = 0.f, iap = 0.f, hprev = 0.f;
+    if (ethr) {
+        dzk = a.dzp_in[hoff];
+        iap = a.ia_prev[n];
+    }
+    auto mid = [&]() {
+        const int t_ = a.T - 1 - cnt;
+        if (ethr && in) hprev = a.hall[((size_t)rg * a.T + t_) * KN + (size_t)(a.k - 1) * a.N + n];
+    };
+    const float s = gram_contract<GS, false>(a.G, a.dGp_in, nullptr, m, ot, NAC, red, mid);
+    if (!ethr || !live) return;
+    const int t = a.T - 1 - cnt;
     const float dzn = hprev > 0.f ? dzk - s : 0.f;
     if (in) a.dz_all[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n] = dzn;
     a.dzp_out[hoff] = dzn;
-    a.dGp_out[hoff] = dzn * a.ia_prev[n];
+    a.dGp_out[hoff] = dzn * iap;
     const float sk = row16_sum(dzk), s0 = row16_sum(dzn);
     if (ecol == 0) {
         const size_t po = ((size_t)(cnt & 1) * a.numO + ot) * a.Bp + rg;
