@@ -644,8 +644,9 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;
-    if (d->operand_f16)
-        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "cell_backward: operand_f16 is a forward-only mode");
+    // operand_f16: the forward ran on fp16 matrix-core operands; its BPTT is computed in fp32 from
+    // the stored hiddens and the fp32 dictionary packings kept in the same prepared block
+    // (rounding treated as the identity: mixed-precision training)
     if (d->divergence != DRNMF_DIV_ED)
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "cell_backward: the KL / beta cell is forward only");
     if (!d->return_all_hidden)
@@ -670,8 +671,10 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     const int64_t BT = (int64_t)B * T;
     // MFMA bin tiles: the odd bins of a 2^k+1 STFT are handled by rank-1 terms, as in the forward
     const int numM = W.Bp / ROWS, nft = W.nft_main;
-    const float* Dp_base = (const float*)(pb + PL.off_dn);
+    const bool half = d->operand_f16 != 0;
+    const float* Dp_base = (const float*)(pb + (half ? PL.off_dn32 : PL.off_dn));
     const size_t dstride = (size_t)PL.Fp * PL.Np;
+    const float* DpA_base = half ? Dp_base + (size_t)d->n_D * dstride : (const float*)(pb + PL.off_dnA);
     auto Dp_of = [&](int k) { return Dp_base + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
     auto ia_of = [&](int k) { return (const float*)(pb + PL.off_inv_alpha) + (size_t)k * PL.Np; };
     auto b_of = [&](int k) { return (const float*)(pb + PL.off_bias) + (size_t)k * PL.Np; };
@@ -746,6 +749,8 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     };
     const dim3 grid_g(8u * (unsigned)numM, (unsigned)(round_up(W.numO, 8) / 8));
 
+    // (the fp16-operand forward counts 32-atom chunks; the fp32 kernels of this pass 16-atom ones)
+    const int nch_ks_b = half ? W.Np / 16 : W.nch_ks;
     auto make_b = [&](int k) {
         CellBArgs b;
         b.Dn_next = Dp_of(k);
@@ -753,14 +758,14 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         b.xp = nullptr;
         b.rpart = drpart;
         b.t_rd = cA;
-        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS; b.nch_ks = W.nch_ks;
+        b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS; b.nch_ks = nch_ks_b;
         b.logKS = 0;
         while ((1 << b.logKS) < W.KS) ++b.logKS;
         return b;
     };
     auto make_a = [&](int k) {
         BwdAArgs a;
-        a.Dn = (const float*)(pb + PL.off_dnA) + (d->n_D == 1 ? 0 : (size_t)k * dstride);
+        a.Dn = DpA_base + (d->n_D == 1 ? 0 : (size_t)k * dstride);
         a.ia_prev = ia_of(k - 1);
         a.drpart = drpart;
         a.dzp_in = dzp[k & 1];
@@ -833,7 +838,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                     continue;
                 }
                 CellBArgs b = make_b(k);
-                DRNMF_HIP(h, add(pick_b_func(W.nch_ks, W.RB), grid_b, 64 * NW_B, CellBParams(b).p));
+                DRNMF_HIP(h, add(pick_b_func(nch_ks_b, W.RB), grid_b, 64 * NW_B, CellBParams(b).p));
                 BwdAArgs a = make_a(k);
                 DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, BwdAParams(a).p));
             }

@@ -625,10 +625,13 @@ void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last) {
 
 void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_hidden, bool half) {
     const int per_wave = (nchunks + NW_A - 1) / NW_A;
-    if (half)   // forward only (the all-hidden output exists for the BPTT, which is fp32); KS = 1,
-                // nchunks counts 32-bin chunks
+    if (half) {   // KS = 1, nchunks counts 32-bin chunks
+        if (all_hidden)   // (training: every hidden layer goes out in fp32 for the fp32 BPTT)
+            return RB == 2 ? a_func_g<1, 2, true, true>(per_wave, first, last)
+                           : a_func_g<1, 1, true, true>(per_wave, first, last);
         return RB == 2 ? a_func_g<1, 2, false, true>(per_wave, first, last)
                        : a_func_g<1, 1, false, true>(per_wave, first, last);
+    }
     return all_hidden ? pick_a_func_ah<true, false>(per_wave, KS, RB, first, last)
                       : pick_a_func_ah<false, false>(per_wave, KS, RB, first, last);
 }

@@ -138,6 +138,9 @@ struct ParamsLayout {
     int Fp, Np;
     size_t off_dn, off_colnorm, off_inv_alpha, off_bias, off_tail, off_dnA, total;
     size_t off_gram, off_dnT, off_dn_rm;   // (0 unless gram_eligible)
+    size_t off_dn32;      // operand_f16 only: the fp32 cell_b packing followed by the fp32 cell_a
+                          // packing of every stored layer -- the BPTT of a model whose FORWARD
+                          // runs on fp16 operands is computed in fp32 (mixed-precision training)
 };
 static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     ParamsLayout L;
@@ -151,6 +154,11 @@ static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     L.off_tail = o;      o += round_up_sz((size_t)d->n_D * MAX_TAIL * L.Np * sizeof(float), 256);
     L.off_dnA = o;
     if (!d->operand_f16) o += (size_t)d->n_D * L.Fp * L.Np * sizeof(float);
+    L.off_dn32 = 0;
+    if (d->operand_f16) {
+        L.off_dn32 = o;
+        o += (size_t)2 * d->n_D * L.Fp * L.Np * sizeof(float);
+    }
     L.off_gram = L.off_dnT = L.off_dn_rm = 0;
     if (gram_eligible(d)) {
         L.off_gram = o;  o += (size_t)d->n_D * L.Np * L.Np * sizeof(float);

@@ -105,9 +105,6 @@ int validate_cell_desc(drnmf_handle_t h, const drnmf_cell_desc_t* d) {
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "divergence must be DRNMF_DIV_ED, _KL or _BETA");
     if (d->divergence != DRNMF_DIV_ED && d->operand_f16)
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "the KL / beta cell runs on fp32 operands");
-    if (d->operand_f16 && d->return_all_hidden)
-        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
-                   "operand_f16 is a forward-only mode (return_all_hidden feeds the fp32 BPTT)");
     if ((int64_t)d->B * d->T * (int64_t)d->N * (d->return_all_hidden ? d->K : 1) >= (1ll << 40))
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "output tensor too large");
     return DRNMF_OK;
@@ -256,12 +253,18 @@ extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_
     const bool has_tail = d->divergence == DRNMF_DIV_ED && d->F % 16 != 0 &&
                           d->F % 16 <= MAX_TAIL && d->F > 16;
     const int f_mfma = has_tail ? (d->F / 16) * 16 : L.Fp;
-    if (d->operand_f16)
+    if (d->operand_f16) {
+        // the fp32 packings first (they write the unrounded tail rows, which the fp16 pass then
+        // replaces by the fp16-rounded values the forward kernels use)
+        float* dn32 = (float*)(base + L.off_dn32);
+        hipLaunchKernelGGL(prep_dict_kernel<false>, g1, dim3(256), 0, stream, log_D, (void*)dn32,
+                           (float*)(base + L.off_colnorm), (float*)(base + L.off_tail),
+                           dn32 + (size_t)d->n_D * L.Fp * L.Np, d->F, d->N, L.Fp, L.Np, f_mfma);
         hipLaunchKernelGGL(prep_dict_kernel<true>, g1, dim3(256), 0, stream, log_D,
                            (void*)(base + L.off_dn), (float*)(base + L.off_colnorm),
                            (float*)(base + L.off_tail), (float*)nullptr, d->F, d->N, L.Fp, L.Np,
                            f_mfma);
-    else
+    } else
         hipLaunchKernelGGL(prep_dict_kernel<false>, g1, dim3(256), 0, stream, log_D,
                            (void*)(base + L.off_dn), (float*)(base + L.off_colnorm),
                            (float*)(base + L.off_tail), (float*)(base + L.off_dnA), d->F, d->N,

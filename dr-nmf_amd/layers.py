@@ -271,7 +271,8 @@ class SimpleDeepRNN(_Layer):
             raise ValueError("divergence must be 'ed', 'kl' or 'beta'")
         self.divergence, self.beta = divergence, float(beta)
         # extension (BASELINE config 5): 'float16' rounds dictionary and activations to fp16 where
-        # they enter the matrix cores (fp32 accumulation and state); inference only
+        # they enter the matrix cores (fp32 accumulation and state); training then runs this forward
+        # and an fp32 BPTT (mixed precision)
         if operand_dtype not in ('float32', 'float16'):
             raise ValueError("operand_dtype must be 'float32' or 'float16'")
         self.operand_dtype = operand_dtype
@@ -570,9 +571,6 @@ class SimpleDeepRNN(_Layer):
     def forward_train(self, x, mask_value=None):
         """Forward that keeps every layer's hidden state: returns hall [B,T,K*N] (the last N
         columns are the layer output) and leaves the workspace ready for `backward`."""
-        if self.operand_dtype != 'float32':
-            raise NotImplementedError("training runs on fp32 operands (operand_dtype='float16' is "
-                                      "an inference mode)")
         if self.divergence != 'ed':
             raise NotImplementedError("the KL / beta variant of the cell is forward only")
         if self._dense_now or self._train_blockers:
@@ -589,8 +587,11 @@ class SimpleDeepRNN(_Layer):
         _, nD = self._stacked_meta('log_D')
         _, nA = self._stacked_meta('log_alph')
         _, nL = self._stacked_meta('log_lam1')
+        # operand_dtype='float16': the forward runs on fp16 matrix-core operands, the BPTT in fp32
+        # from the stored hiddens (mixed precision; the rounding is treated as the identity)
         desc = ops.make_desc(B, T, self.input_dim, self.output_dim, self.K_layers, nD, nA,
-                             int(self._alt[lab['log_alph'][0]].numel()), nL, True)
+                             int(self._alt[lab['log_alph'][0]].numel()), nL, True,
+                             operand_f16=self.operand_dtype == 'float16')
         key = ('train', B, T)
         if key not in self._ws:
             self._ws.clear()

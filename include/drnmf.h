@@ -56,10 +56,12 @@ typedef struct drnmf_cell_desc {
     int32_t alph_len;       /* 1 (scalar alph) or N (untie_alph, enhance.py:225-226)           */
     int32_t n_lam;          /* 1 or K                                                          */
     int32_t return_all_hidden; /* flag_return_all_hidden (custom_layers.py:344-346,371-372)    */
-    int32_t operand_f16;       /* 0: fp32 MFMA operands (the reference's float32).  1: dictionary
-                                * and activations rounded to fp16 where they enter the matrix
-                                * cores, fp32 accumulation and state (BASELINE config 5; forward
-                                * only -- drnmf_cell_backward returns DRNMF_ERR_UNSUPPORTED)      */
+    int32_t operand_f16;       /* 0: fp32 MFMA operands (the reference's float32).  1: dictionary,
+                                * hidden state and residual stored as fp16 and contracted with
+                                * v_mfma_f32_16x16x32_f16, fp32 accumulation, state and update
+                                * (BASELINE config 5).  drnmf_cell_backward on such a descriptor
+                                * is the fp32 BPTT of that forward (mixed precision: the prepared
+                                * block carries fp32 packings beside the fp16 ones)            */
     int32_t divergence;        /* DRNMF_DIV_ED (0): the reference's cell.  DRNMF_DIV_KL / _BETA: the
                                 * warm-started ISTA cell of drnmf_cell_forward_ista (extension,
                                 * forward only)                                                  */

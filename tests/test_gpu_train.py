@@ -281,3 +281,39 @@ def test_full_size_training_step_properties(dev):
 
     losses = [model.train_on_batch(x, y, w) for _ in range(6)]
     assert losses[-1] < losses[0], losses
+
+
+def test_mixed_precision_training_fp16_forward_fp32_bptt(dev):
+    """operand_dtype='float16' (BASELINE config 5 mode) under compile(): the forward runs on fp16
+    matrix-core operands, the BPTT in fp32 from the stored hiddens with the rounding treated as the
+    identity.  Gradients stay within fp16-rounding distance of the all-fp32 gradients (and of the
+    fp64 autograd of the exact model), and training decreases the loss."""
+    from drnmf_amd import layers
+    cfg = dict(B=6, T=7, F=49, r=24, K=3, untied=("log_D", "log_alph"))
+    model32, P, wmask = _setup(**cfg)
+    np.random.seed(cfg.get("seed", 5))
+    N = 2 * cfg["r"]
+    p = dict(input_dim=cfg["F"], hidden_dim=N, output_dim=cfg["F"], mask_value=-1., maxseq=cfg["T"],
+             K_layers=cfg["K"], W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=list(cfg["untied"]),
+             params_trainable=["log_D", "log_alph"], operand_dtype="float16")
+    model16 = layers.build_unfolded_snmf(p)
+    model16.set_weights(model32.get_weights())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    x, y, w = t(P["X"]), t(P["Y"]), t(wmask)
+    model32.compile(lr=1e-3)
+    model16.compile(lr=1e-3)
+    f32 = model32.loss_and_grads(x, y, w).clone()
+    f16 = model16.loss_and_grads(x, y, w).clone()
+    torch.cuda.synchronize()
+    assert float(f16[-2]) == float(f32[-2])
+    assert abs(float(f16[-3]) - float(f32[-3])) <= 5e-3 * abs(float(f32[-3]))
+    ref_loss, ref, cnt = _autograd(model32, P, wmask, cfg["K"], False)
+    name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
+    for n, _ in model16._train_items:
+        g16, g32 = model16._gview[n].cpu().numpy(), model32._gview[n].cpu().numpy()
+        scale = max(np.max(np.abs(g32)), 1e-30)
+        assert np.max(np.abs(g16 - g32)) / scale <= 3e-2, n
+        r_ = ref[name_map.get(n, n)]
+        assert np.max(np.abs(g16 - r_)) / max(np.max(np.abs(r_)), 1e-30) <= 3e-2, n
+    losses = [model16.train_on_batch(x, y, w) for _ in range(8)]
+    assert losses[-1] < losses[0], losses
