@@ -886,7 +886,10 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         hipLaunchKernelGGL(unpack_dn_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                            stream, Dp_of(k), Dn_rm, W.Fp, W.Np);
         const float* Aop = xpad;
-        if (k >= 1) {
+        if (k >= 1 && W.off_rsave != 0) {
+            // the forward left r_k of every frame in its workspace (cell_a_kernel, Rsave)
+            Aop = (const float*)(fw + W.off_rsave) + (size_t)(k - 1) * BT * W.Fp;
+        } else if (k >= 1) {
             gemm::Operands g1{hall + (size_t)(k - 1) * N, Dn_rm, BT, F, N, KN, W.Np};
             DRNMF_HIP(h, gemm::launch(g1, EpiResid{x, Rk, F, W.Fp}, stream));
             Aop = Rk;

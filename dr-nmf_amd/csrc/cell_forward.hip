@@ -69,6 +69,9 @@ struct CellAArgs {
     float* xcur;             // [Bp][Fp] packed x_t, republished by the first layer for cell_b
     int B, T, N, Bp, Fp, Np, numA, nchunks, KS, ntail;
     int tail_tile;           // 16-bin tile index of the odd bins (= MFMA tiles of 16 bins)
+    float* Rsave;            // training (all-hidden, fp32, k >= 1): this layer's residual r_k of every
+                             // frame, row-major [B*T][Fp], for the weight gradients of the BPTT
+                             // (saves its recomputation as a frame-parallel GEMM); else NULL
     int out_width, out_off, write_out;
 };
 
@@ -391,6 +394,29 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
         if (exact) last_group(base);
     }
 
+    // training: the summed residual of this row tile goes out row-major for the BPTT's weight
+    // gradients.  Every workgroup of the row tile holds all of it; chunk c is stored by atom block
+    // c mod numA, by the wave that owns it (re-read: cache hits), outside the MFMA loop -- as
+    // bwd_a_kernel does for d r (cell_backward.hip)
+    if (ALL_HIDDEN && !IS_FIRST && !HALF && a.Rsave != nullptr && live) {
+        for (int c = ab; c < a.nchunks; c += a.numA) {
+            if ((c & (NW_A - 1)) != w) continue;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float* src = arow + rb * astep + 256 * c;
+                f32x4 r4 = *(const f32x4*)src;
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks) r4 += *(const f32x4*)(src + (size_t)ks * pstride);
+                const int row = (mb0 + rb) * ROWS + j;
+                if (row < a.B) {
+                    float* dst = a.Rsave + ((size_t)row * a.T + t) * Fp + 16 * c + q;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dst[4 * s] = r4[s];
+                }
+            }
+        }
+    }
+
     // ---- cross-wave reduction of the 4 F-splits through LDS --------------------------------
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -427,6 +453,9 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                     sq += qp[b2];
                 sq = row16_sum(sq);
                 rt -= sq;
+                if (ALL_HIDDEN && !HALF && a.Rsave != nullptr && ab_raw == 0 && (tid & 15) == 0 &&
+                    rg < a.B)
+                    a.Rsave[((size_t)rg * a.T + t) * Fp + 16 * a.tail_tile + i] = rt;
             }
             gsum[0] = fmaf(rt, dt[i][0], gsum[0]);
             gsum[1] = fmaf(rt, dt[i][1], gsum[1]);
@@ -887,6 +916,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         // fp16 mode: cell_b writes the MFMA bin tiles of Rp16 only; the padding of the last 32-bin
         // chunk (and the odd-bin tile) must be finite: it meets zero dictionary slots
         if (half) DRNMF_HIP(h, hipMemsetAsync(r16, 0, (size_t)W.Bp * W.Fp * 2, stream));
+        // training: the saved residuals' padding bins (past the odd bins) are never written
+        if (W.off_rsave != 0 && W.ntail > 0)
+            DRNMF_HIP(h, hipMemsetAsync(ws + W.off_rsave, 0,
+                                        (size_t)(K - 1) * d->B * d->T * W.Fp * 4, stream));
     }
 
     // ---- one frame = 2K-1 launches, as a cached hipGraph -------------------------------------
@@ -968,6 +1001,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
         a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
+        a.Rsave = (W.off_rsave != 0 && k >= 1)
+                      ? (float*)(ws + W.off_rsave) + (size_t)(k - 1) * d->B * d->T * W.Fp : nullptr;
         return a;
     };
     auto make_b = [&](int k) {   // between layer k and k+1

@@ -272,6 +272,8 @@ struct Workspace {
     bool gram;
     int numO;              // output tiles of 16 atoms (= row-sum partials per row)
     size_t off_cp, off_xpad, off_q0, off_q1;
+    size_t off_rsave;      // training forward (all hidden layers, fp32, factored): residuals r_k, k >= 1,
+                           // row-major [K-1][B*T][Fp] for the BPTT's weight gradients; 0 = absent
 };
 
 Workspace workspace_layout(const drnmf_cell_desc_t* d) {
@@ -355,6 +357,12 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_xpad = take(W.gram ? (size_t)d->B * GRAM_TB * W.Fp * 4 : 0);
     W.off_q0 = take(W.gram ? (size_t)W.Bp * W.Np * 4 : 0);
     W.off_q1 = take(W.gram ? (size_t)W.Bp * W.Np * 4 : 0);
+    W.off_rsave = 0;
+    if (d->return_all_hidden && !W.half && !W.gram && d->divergence == DRNMF_DIV_ED && d->K >= 2) {
+        // (the padding bins of every row must read as zero in the gradient GEMMs: when Fp > F the
+        // forward clears the buffer once per call)
+        W.off_rsave = take((size_t)(d->K - 1) * d->B * d->T * W.Fp * 4);
+    }
     W.off_t = take(256);
     W.total = o;
     return W;
