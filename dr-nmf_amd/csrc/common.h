@@ -61,6 +61,9 @@ struct drnmf_handle_s {
     // were retired has completed (graph_cache_insert, no device-wide synchronisation)
     struct Retired { GraphEntry g; hipEvent_t done; };
     std::vector<Retired> retired;
+    // STFT window / twiddle tables (stft.hip): filled once per FFT size 2^6 .. 2^12
+    bool fft_ready[7] = {false, false, false, false, false, false, false};
+    hipEvent_t fft_event[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // RCCL communicator (comm.hip): one rank per handle / GPU
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;

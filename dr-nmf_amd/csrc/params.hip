@@ -57,6 +57,8 @@ extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
+    for (auto& e : h->fft_event)
+        if (e) (void)hipEventDestroy(e);
     delete h;
     return DRNMF_OK;
 }

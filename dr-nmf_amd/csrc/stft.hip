@@ -118,6 +118,161 @@ stft_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int N, i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fast path for the sizes the reference uses (N = 512 shipped, N = 1024 in BASELINE): the input is
+// real, so a frame is ONE complex FFT of M = N/2 points, z[n] = x[2n] + i x[2n+1], followed by the
+// split X[k] = (Z[k] + conj Z[M-k]) / 2 - i e^{-2 pi i k / N} (Z[k] - conj Z[M-k]) / 2.  The M-point
+// FFT is a Stockham autosort of radix-R passes (R = 8 for M = 512, R = 4 for M = 256) with the R
+// points of a butterfly in registers: M / R = 64 butterflies = ONE WAVE per frame, so the passes
+// exchange through a wave-private LDS slice with no workgroup barrier; a 256-thread workgroup
+// carries 4 frames.  Against the radix-2 kernel above (one workgroup per frame, a complex FFT twice
+// the size, a barrier every two stages) it moves the front end from LDS latency towards HBM.
+template <int R>
+__device__ __forceinline__ void dft_r(float2 (&v)[R]);
+
+template <>
+__device__ __forceinline__ void dft_r<4>(float2 (&v)[4]) {
+    const float2 a = make_float2(v[0].x + v[2].x, v[0].y + v[2].y);
+    const float2 b = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
+    const float2 c = make_float2(v[1].x + v[3].x, v[1].y + v[3].y);
+    const float2 d = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
+    v[0] = make_float2(a.x + c.x, a.y + c.y);
+    v[2] = make_float2(a.x - c.x, a.y - c.y);
+    v[1] = make_float2(b.x + d.y, b.y - d.x);      // b - i d
+    v[3] = make_float2(b.x - d.y, b.y + d.x);      // b + i d
+}
+
+template <>
+__device__ __forceinline__ void dft_r<8>(float2 (&v)[8]) {
+    float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    dft_r<4>(e);
+    dft_r<4>(o);
+    const float h = 0.70710678118654752440f;
+    // o[r] *= e^{-2 pi i r / 8}
+    o[1] = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+    o[2] = make_float2(o[2].y, -o[2].x);
+    o[3] = make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = make_float2(e[r].x + o[r].x, e[r].y + o[r].y);
+        v[r + 4] = make_float2(e[r].x - o[r].x, e[r].y - o[r].y);
+    }
+}
+
+template <int R, int P>       // M = R^P complex points, N = 2M real samples
+__global__ void __launch_bounds__(256)
+stft_real_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int logN, int hop,
+                 int nf, float* __restrict__ mag, float* __restrict__ re, float* __restrict__ im) {
+    constexpr int M = (R == 8 ? (P == 3 ? 512 : 64) : (P == 4 ? 256 : 64)), N = 2 * M;
+    __shared__ float2 tw[N / 2];              // e^{-2 pi i k / N}, k < N/2
+    // per wave: ping-pong.  Index i lives at i + i/8: the Stockham scatter of the early passes
+    // (stride R, then R*R) would otherwise put 8-16 lanes on one bank
+    constexpr int MP = M + M / 8;
+    __shared__ float2 bufs[4][2][MP];
+    auto pad = [](int i) { return i + (i >> 3); };
+    const int tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
+    const int frame = blockIdx.x * 4 + wv, sig = blockIdx.y;
+    for (int k = tid; k < N / 2; k += 256) tw[k] = g_twiddle[logN - TAB_LOG_MIN][k];
+    __syncthreads();
+    if (frame >= nf) return;                  // (whole waves: no barrier below)
+    const float* __restrict__ win = g_window[logN - TAB_LOG_MIN];
+    auto twid = [&](int idx) {                // e^{-2 pi i idx / N}, 0 <= idx < N
+        const float2 t = tw[idx & (N / 2 - 1)];
+        return idx >= N / 2 ? make_float2(-t.x, -t.y) : t;
+    };
+    // pass 0 input straight from the signal: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1]), n = j + r M/R
+    const int64_t base = (int64_t)frame * hop - N;       // first sample of the frame (N leading zeros)
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = j + r * (M / R);
+        const int64_t i0 = base + 2 * n;
+        float x0 = 0.f, x1 = 0.f;
+        if (is_int16) {
+            const short* p = (const short*)pcm + (size_t)sig * nsampl;
+            if (i0 >= 0 && i0 < nsampl) x0 = (float)p[i0] / 32768.0f;
+            if (i0 + 1 >= 0 && i0 + 1 < nsampl) x1 = (float)p[i0 + 1] / 32768.0f;
+        } else {
+            const float* p = (const float*)pcm + (size_t)sig * nsampl;
+            if (i0 >= 0 && i0 < nsampl) x0 = p[i0];
+            if (i0 + 1 >= 0 && i0 + 1 < nsampl) x1 = p[i0 + 1];
+        }
+        const float2 w2 = *(const float2*)(win + 2 * n);
+        v[r] = make_float2(x0 * w2.x, x1 * w2.y);
+    }
+    float2* cur = bufs[wv][0];
+    float2* nxt = bufs[wv][1];
+    int Ns = 1;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (p > 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = cur[pad(j + r * (M / R))];
+        }
+        const int k = j & (Ns - 1);
+        if (p > 0) {                          // twiddles e^{-2 pi i k r / (Ns R)} (pass 0: k = 0)
+            const int step = k * (N / (Ns * R));
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], twid(step * r));
+        }
+        dft_r<R>(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) nxt[pad(j0 + r * Ns)] = v[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float2* t_ = cur; cur = nxt; nxt = t_;
+        Ns *= R;
+    }
+    // split + output: k = j + 64 i, i < M/64, and k = M
+    const size_t o = ((size_t)sig * nf + frame) * (M + 1);
+    auto emit = [&](int k) {
+        const float2 zk = cur[pad(k & (M - 1))];
+        const float2 zc = cur[pad((M - k) & (M - 1))];     // Z[M-k] (Z[M] = Z[0])
+        const float2 a = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));   // (Z_k + conj Z_{M-k}) / 2
+        const float2 b = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));   // (Z_k - conj Z_{M-k}) / 2
+        const float2 w = k == M ? make_float2(-1.f, 0.f) : tw[k];
+        const float2 wb = cmul(b, w);                       // X = a - i w b
+        const float xr = a.x + wb.y, xi = a.y - wb.x;
+        if (mag) mag[o + k] = sqrtf(xr * xr + xi * xi);
+        if (re) re[o + k] = xr;
+        if (im) im[o + k] = -xi;      // librosa 0.5.1 conjugates the spectrum (util.py:195 via stft)
+    };
+#pragma unroll
+    for (int i = 0; i < M / 64; ++i) emit(j + 64 * i);
+    if (j == 0) emit(M);
+}
+
+static bool stft_fast(int N) { return N == 512 || N == 1024; }
+
+// The window / twiddle tables of a size are filled once per handle (= per device); later calls on
+// any stream only wait for the event recorded behind that fill.
+static int32_t ensure_fft_tables(drnmf_handle_t h, int N, int logN, hipStream_t stream) {
+    const int slot = logN - TAB_LOG_MIN;
+    if (!h->fft_ready[slot]) {
+        hipLaunchKernelGGL(fft_tables_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+                           stream, N, logN);
+        DRNMF_HIP(h, hipGetLastError());
+        DRNMF_HIP(h, hipEventCreateWithFlags(&h->fft_event[slot], hipEventDisableTiming));
+        DRNMF_HIP(h, hipEventRecord(h->fft_event[slot], stream));
+        h->fft_ready[slot] = true;
+    } else {
+        DRNMF_HIP(h, hipStreamWaitEvent(stream, h->fft_event[slot], 0));
+    }
+    return DRNMF_OK;
+}
+static void launch_stft_real(int N, int logN, const void* pcm, int is_int16, int64_t nsampl, int hop,
+                             int nf, int n_sig, float* mag, float* re, float* im, hipStream_t st) {
+    const dim3 grid((unsigned)((nf + 3) / 4), (unsigned)n_sig);
+    if (N == 1024)
+        hipLaunchKernelGGL((stft_real_kernel<8, 3>), grid, dim3(256), 0, st, pcm, is_int16, nsampl,
+                           logN, hop, nf, mag, re, im);
+    else
+        hipLaunchKernelGGL((stft_real_kernel<4, 4>), grid, dim3(256), 0, st, pcm, is_int16, nsampl,
+                           logN, hop, nf, mag, re, im);
+}
+
 // one workgroup per (signal, frame): masked spectrum -> Hermitian extension -> inverse FFT -> real
 // part * window * 2/(N/hop)  (util.py:48-169 istft_noDiv with center=False)
 __global__ void __launch_bounds__(256)
@@ -220,11 +375,17 @@ extern "C" int32_t drnmf_stft_mag(drnmf_handle_t h, int32_t n_sig, int64_t nsamp
     while ((1 << logN) < N) ++logN;
     const int nf = drnmf_stft_frames(nsampl, N, hop);
     const size_t shmem = (size_t)(N + N / 2) * sizeof(float2);
-    hipLaunchKernelGGL(fft_tables_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream_, N, logN);
-    hipLaunchKernelGGL(stft_kernel, dim3((unsigned)nf, (unsigned)n_sig), dim3(256), shmem,
-                       (hipStream_t)stream_, pcm, is_int16, nsampl, N, logN, hop, nf, mag,
-                       (float*)nullptr, (float*)nullptr);
+    {
+        const int32_t trc = ensure_fft_tables(h, N, logN, (hipStream_t)stream_);
+        if (trc) return trc;
+    }
+    if (stft_fast(N))
+        launch_stft_real(N, logN, pcm, is_int16, nsampl, hop, nf, n_sig, mag, nullptr, nullptr,
+                         (hipStream_t)stream_);
+    else
+        hipLaunchKernelGGL(stft_kernel, dim3((unsigned)nf, (unsigned)n_sig), dim3(256), shmem,
+                           (hipStream_t)stream_, pcm, is_int16, nsampl, N, logN, hop, nf, mag,
+                           (float*)nullptr, (float*)nullptr);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }
@@ -247,10 +408,17 @@ extern "C" int32_t drnmf_stft(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, i
     while ((1 << logN) < N) ++logN;
     const int nf = drnmf_stft_frames(nsampl, N, hop);
     const size_t shmem = (size_t)(N + N / 2) * sizeof(float2);
-    hipLaunchKernelGGL(fft_tables_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream_, N, logN);
-    hipLaunchKernelGGL(stft_kernel, dim3((unsigned)nf, (unsigned)n_sig), dim3(256), shmem,
-                       (hipStream_t)stream_, pcm, is_int16, nsampl, N, logN, hop, nf, mag, re, im);
+    {
+        const int32_t trc = ensure_fft_tables(h, N, logN, (hipStream_t)stream_);
+        if (trc) return trc;
+    }
+    if (stft_fast(N))
+        launch_stft_real(N, logN, pcm, is_int16, nsampl, hop, nf, n_sig, mag, re, im,
+                         (hipStream_t)stream_);
+    else
+        hipLaunchKernelGGL(stft_kernel, dim3((unsigned)nf, (unsigned)n_sig), dim3(256), shmem,
+                           (hipStream_t)stream_, pcm, is_int16, nsampl, N, logN, hop, nf, mag, re,
+                           im);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }
@@ -276,8 +444,10 @@ extern "C" int32_t drnmf_istft_masked(drnmf_handle_t h, int32_t n_sig, int32_t n
     hipStream_t stream = (hipStream_t)stream_;
     float* frames = (float*)workspace;
     const size_t shmem = (size_t)(N + N / 2) * sizeof(float2);
-    hipLaunchKernelGGL(fft_tables_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N,
-                       logN);
+    {
+        const int32_t trc = ensure_fft_tables(h, N, logN, stream);
+        if (trc) return trc;
+    }
     hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)n_frames, (unsigned)n_sig), dim3(256),
                        shmem, stream, re, im, mask, N, logN, hop, n_frames, frames);
     hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((nsampl + 255) / 256), (unsigned)n_sig),
