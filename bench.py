@@ -255,12 +255,15 @@ def config5_bench(torch, dev, frames=64, B=64):
             ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
         step()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        step()
-        e1.record()
-        torch.cuda.synchronize()
-        sec = e0.elapsed_time(e1) * 1e-3
+        secs = []
+        for _ in range(3):                    # best of three single passes (one pass is ~70-120 ms)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            torch.cuda.synchronize()
+            secs.append(e0.elapsed_time(e1) * 1e-3)
+        sec = min(secs)
         tf = B * frames * 4.0 * F * N * K / sec / 1e12
         launch_us = sec / (frames * (2 * K - 1)) * 1e6
         # HBM-bound at this shape (K = 50 untied dictionaries = 1.6 GB fp16 / 3.3 GB fp32, past the
