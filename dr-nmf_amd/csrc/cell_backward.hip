@@ -173,13 +173,14 @@ struct BwdAArgs {
     // result, it is copied into dR, and the partials of layer k-1 are produced for the next launch
     const float* Dtail;      // [MAX_TAIL][Np] of layer k
     const float* Dtail_prev; // of layer k-1
-    const float* dq_in;      // [MAX_TAIL][Bp][numA]
-    float* dq_out;
+    const float* dq_in;      // qred = 0: [MAX_TAIL][Bp][numA] partials of layer k (numA <= 64, added here);
+                             // qred = 1: [MAX_TAIL][Bp], summed by the cell_b launch in between
+    float* dq_out;           // [MAX_TAIL][Bp][numA] partials of layer k-1
     int ntail;
 };
 
 // (leading scalar arguments: preloaded into SGPRs, see cell_b_kernel)
-template <int G, int KS>
+template <int G, int KS, bool QRED = false>
 __global__ void __launch_bounds__(256)
 bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, int Fp_, int Np_,
              int numA_, int nchunks_, const BwdAArgs a_in) {
@@ -246,19 +247,24 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
             hprev[e] = a.hall[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n + e];
 
     f32x2 dt[MAX_TAIL], dtp[MAX_TAIL];
-    float qv[MAX_TAIL][4];
+    float qs[MAX_TAIL], qv[MAX_TAIL][4];
 #pragma unroll
     for (int i = 0; i < MAX_TAIL; ++i) {
         dt[i] = *(const f32x2*)(a.Dtail + (size_t)i * Np + n);
         dtp[i] = *(const f32x2*)(a.Dtail_prev + (size_t)i * Np + n);
+        qs[i] = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) qv[i][u] = 0.f;
         if (i >= a.ntail) continue;
-        const float* qp = a.dq_in + ((size_t)i * a.Bp + rg) * a.numA;
+        if (QRED) {
+            qs[i] = a.dq_in[(size_t)i * a.Bp + rg];
+        } else {
+            const float* qp = a.dq_in + ((size_t)i * a.Bp + rg) * a.numA;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int b2 = (tid & 15) + 16 * u;
-            if (b2 < a.numA) qv[i][u] = qp[b2];
+            for (int u = 0; u < 4; ++u) {
+                const int b2 = (tid & 15) + 16 * u;
+                if (b2 < a.numA) qv[i][u] = qp[b2];
+            }
         }
     }
 
@@ -334,10 +340,13 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
 #pragma unroll
     for (int i = 0; i < MAX_TAIL; ++i) {
         if (i >= a.ntail) continue;
-        float sq = (qv[i][0] + qv[i][1]) + (qv[i][2] + qv[i][3]);
-        const float* qp = a.dq_in + ((size_t)i * a.Bp + rg) * a.numA;
-        for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16) sq += qp[b2];      // numA > 64 only
-        sq = row16_sum(sq);                                   // d r_tail[row] of layer k
+        float sq = qs[i];                                     // d r_tail[row] of layer k
+        if (!QRED) {
+            sq = (qv[i][0] + qv[i][1]) + (qv[i][2] + qv[i][3]);
+            const float* qp = a.dq_in + ((size_t)i * a.Bp + rg) * a.numA;
+            for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16) sq += qp[b2];
+            sq = row16_sum(sq);
+        }
         gsum[0] = fmaf(sq, dt[i][0], gsum[0]);
         gsum[1] = fmaf(sq, dt[i][1], gsum[1]);
         if (ab_raw == 0 && (tid & 15) == 0 && rg < a.B)
@@ -383,17 +392,18 @@ struct BwdAParams {
 };
 
 template <int KS>
-void* bwd_a_func(int per_wave) {
+void* bwd_a_func(int per_wave, bool qred) {
+    if (qred) return per_wave <= 2 ? (void*)&bwd_a_kernel<2, KS, true> : (void*)&bwd_a_kernel<4, KS, true>;
     if (per_wave <= 2) return (void*)&bwd_a_kernel<2, KS>;
     return (void*)&bwd_a_kernel<4, KS>;
 }
-void* pick_bwd_a(int nchunks, int KS) {
+void* pick_bwd_a(int nchunks, int KS, bool qred = false) {
     const int per_wave = (nchunks + 3) / 4;
     switch (KS) {
-        case 1: return bwd_a_func<1>(per_wave);
-        case 2: return bwd_a_func<2>(per_wave);
-        case 4: return bwd_a_func<4>(per_wave);
-        default: return bwd_a_func<8>(per_wave);
+        case 1: return bwd_a_func<1>(per_wave, qred);
+        case 2: return bwd_a_func<2>(per_wave, qred);
+        case 4: return bwd_a_func<4>(per_wave, qred);
+        default: return bwd_a_func<8>(per_wave, qred);
     }
 }
 
@@ -596,7 +606,7 @@ dlogh0_kernel(const float* __restrict__ dh0_part, const float* __restrict__ log_
 struct BwdWs {
     size_t off_dstate, off_gq, off_dzp0, off_dzp1, off_dGp0, off_dGp1, off_drpart, off_z0s, off_dps,
         off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_dnia, off_P, off_cr, off_dq,
-        total;
+        off_dqsum, total;
 };
 BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     BwdWs L;
@@ -622,6 +632,7 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     L.off_P = take((size_t)TN_SPLITS * W.Fp * W.Np * 4);
     L.off_cr = take((size_t)CR_SPLITS * 2 * W.Np * 4);
     L.off_dq = take((size_t)2 * MAX_TAIL * W.Bp * W.numA * 4);
+    L.off_dqsum = take((size_t)MAX_TAIL * W.Bp * 4);
     L.total = o;
     return L;
 }
@@ -751,6 +762,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
 
     // (the fp16-operand forward counts 32-atom chunks; the fp32 kernels of this pass 16-atom ones)
     const int nch_ks_b = half ? W.Np / 16 : W.nch_ks;
+    const bool qred = qred_wanted(W.numA, W.ntail, nft, W.KS, W.RB);
     auto make_b = [&](int k) {
         CellBArgs b;
         b.Dn_next = Dp_of(k);
@@ -759,6 +771,9 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         b.rpart = drpart;
         b.t_rd = cA;
         b.Bp = W.Bp; b.Fp = W.Fp; b.Np = W.Np; b.nft = nft; b.KS = W.KS; b.nch_ks = nch_ks_b;
+        b.q_in = dq + (size_t)(k & 1) * dqstride;          // partials of layer k (bwd_edge / bwd_a)
+        b.qsum = (float*)(bw + L.off_dqsum);
+        b.numA = W.numA; b.ntail = W.ntail;
         b.logKS = 0;
         while ((1 << b.logKS) < W.KS) ++b.logKS;
         return b;
@@ -781,7 +796,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         a.numA = W.numA; a.nchunks = nft;
         a.Dtail = tail_of(k);
         a.Dtail_prev = tail_of(k - 1);
-        a.dq_in = dq + (size_t)(k & 1) * dqstride;
+        a.dq_in = qred ? (const float*)(bw + L.off_dqsum) : dq + (size_t)(k & 1) * dqstride;
         a.dq_out = dq + (size_t)((k - 1) & 1) * dqstride;
         a.ntail = W.ntail;
         return a;
@@ -838,9 +853,9 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                     continue;
                 }
                 CellBArgs b = make_b(k);
-                DRNMF_HIP(h, add(pick_b_func(nch_ks_b, W.RB), grid_b, 64 * NW_B, CellBParams(b).p));
+                DRNMF_HIP(h, add(pick_b_func(nch_ks_b, W.RB, false, qred), grid_b, 64 * NW_B, CellBParams(b).p));
                 BwdAArgs a = make_a(k);
-                DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS), grid_a, 256, BwdAParams(a).p));
+                DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS, qred), grid_a, 256, BwdAParams(a).p));
             }
             if (K == 1) {
                 int* cp = cA;

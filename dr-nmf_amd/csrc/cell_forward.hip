@@ -62,13 +62,16 @@ struct CellAArgs {
     float u0d, u0o, uko;
     const float* Dtail;      // [MAX_TAIL][Np] tail-bin rows of this layer's dictionary
     const float* Dtail_next; // the same of layer k+1 (for the next x^ tail partials)
-    const float* q_in;       // [MAX_TAIL][Bp][numA] tail-bin x^ partials of the previous layer (one
-                             // row's partials are contiguous: the 16 lanes that add them load 64 B)
+    const float* q_in;       // tail-bin x^ of the previous layer.  qred = 0: its per-atom-block partials
+                             // [MAX_TAIL][Bp][numA] (numA <= 64: four per lane, added here);
+                             // qred = 1: [MAX_TAIL][Bp], summed by the cell_b launch in between
     float* q_out;            // same, produced for the next layer
     float* xtail;            // [MAX_TAIL][Bp] tail bins of x_t (published by the first layer)
     float* xcur;             // [Bp][Fp] packed x_t, republished by the first layer for cell_b
     int B, T, N, Bp, Fp, Np, numA, nchunks, KS, ntail;
     int tail_tile;           // 16-bin tile index of the odd bins (= MFMA tiles of 16 bins)
+    int ablate;              // measurement aid (DRNMF_ABLATE_A): bit 0 = dictionary loads read chunk 0,
+                             // bit 1 = residual loads read chunk 0 (fp16 mode; results are garbage)
     float* Rsave;            // training (all-hidden, fp32, k >= 1): this layer's residual r_k of every
                              // frame, row-major [B*T][Fp], for the weight gradients of the BPTT
                              // (saves its recomputation as a frame-parallel GEMM); else NULL
@@ -84,8 +87,11 @@ struct CellAArgs {
 // What the operand addresses need is passed as leading scalar arguments (preloaded into SGPRs by
 // the command processor, see cell_b_kernel); the rest of the struct is fetched by scalar loads that
 // are not on the path to the first operand load.
+// QRED: the odd-bin x^ of the previous layer arrives already summed (cell_b, more than 64 atom blocks);
+// a template parameter, not a runtime switch: the epilogue-operand block of the headline
+// instantiation is sensitive to every extra register and branch (a runtime `if` cost 3 % there).
 template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN, bool HALF = false,
-          bool LATE = false>
+          bool LATE = false, bool QRED = false>
 __global__ void __launch_bounds__(64 * NW_A)
 cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, int Fp_, int Np_,
               int numA_, int nchunks_, const CellAArgs a_in) {
@@ -157,9 +163,11 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     auto load_chunk = [&](int i, int g) {      // chunk i of this wave -> slot g
         int c = w + NW_A * i;
         c = c > clast ? clast : c;
+        const int cb = (HALF && (a.ablate & 1)) ? 0 : c;
         if (A16) {
+            const int ca = (a.ablate & 2) ? 0 : c;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * c);
+            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
         } else if (HALF) {          // first layer: fp32 blocks 2c, 2c+1 of the packed input
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -174,8 +182,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                     av[g][rb][ks] = *(const f32x4*)(arow + rb * astep + 256 * c + (size_t)ks * pstride);
         }
         if (HALF) {
-            bh[g][0] = *(const f16x8*)(brow16 + (size_t)c * bstep);
-            bh[g][1] = *(const f16x8*)(brow16 + (size_t)c * bstep + 512);
+            bh[g][0] = *(const f16x8*)(brow16 + (size_t)cb * bstep);
+            bh[g][1] = *(const f16x8*)(brow16 + (size_t)cb * bstep + 512);
         } else {
             bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
             bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
@@ -224,7 +232,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // reduced after the MFMA loop (consuming them earlier would force an in-order vmcnt wait on
     // every operand load issued so far).
     float xt[RB][MAX_TAIL];
-    float qv[RB][MAX_TAIL][4];
+    float qs[QRED ? RB : 1][MAX_TAIL];
+    float qv[QRED ? 1 : RB][MAX_TAIL][4];
     f32x2 dt[MAX_TAIL], dtn[MAX_TAIL];   // tail rows of this layer's and the next layer's dictionary
     auto load_epilogue_operands = [&]() {
     ia = *(const f32x2*)(a.inv_alpha + n);
@@ -263,19 +272,22 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
 #pragma unroll
         for (int i = 0; i < MAX_TAIL; ++i) {
             xt[rb][i] = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) qv[rb][i][u] = 0.f;
+            if (QRED) qs[rb][i] = 0.f;
             if (i >= a.ntail) continue;
             if (IS_FIRST) {
                 // packed input: bin 16*nchunks + i sits in tile nchunks
                 xt[rb][i] = rsrc[((size_t)(mb0 + rb) * nft + a.tail_tile) * 256 + rp_pos(erow, i)];
             } else {
                 xt[rb][i] = a.xtail[(size_t)i * a.Bp + rg];
-                const float* qp = a.q_in + ((size_t)i * a.Bp + rg) * a.numA;
+                if (QRED) {
+                    qs[rb][i] = a.q_in[(size_t)i * a.Bp + rg];
+                } else {
+                    const float* qp = a.q_in + ((size_t)i * a.Bp + rg) * a.numA;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {   // atom blocks (tid&15) + 16u: covers numA <= 64 here
-                    const int b2 = (tid & 15) + 16 * u;
-                    if (b2 < a.numA) qv[rb][i][u] = qp[b2];
+                    for (int u = 0; u < 4; ++u) {   // atom blocks (tid&15) + 16u: numA <= 64 here
+                        const int b2 = (tid & 15) + 16 * u;
+                        qv[rb][i][u] = b2 < a.numA ? qp[b2] : 0.f;
+                    }
                 }
             }
         }
@@ -447,12 +459,15 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             if (IS_FIRST) {
                 if (ab_raw == 0 && (tid & 15) == 0) a.xtail[(size_t)i * a.Bp + rg] = xt[rb][i];
             } else {
-                float sq = (qv[rb][i][0] + qv[rb][i][1]) + (qv[rb][i][2] + qv[rb][i][3]);
-                const float* qp = a.q_in + ((size_t)i * a.Bp + rg) * a.numA;
-                for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16)      // numA > 64 only
-                    sq += qp[b2];
-                sq = row16_sum(sq);
-                rt -= sq;
+                if (QRED) {
+                    rt -= qs[rb][i];
+                } else {
+                    float sq = (qv[rb][i][0] + qv[rb][i][1]) + (qv[rb][i][2] + qv[rb][i][3]);
+                    const float* qp = a.q_in + ((size_t)i * a.Bp + rg) * a.numA;
+                    for (int b2 = (tid & 15) + 64; b2 < a.numA; b2 += 16)   // (numA > 64 with too few
+                        sq += qp[b2];                                       // cell_b workgroups: rare)
+                    rt -= row16_sum(sq);
+                }
                 if (ALL_HIDDEN && !HALF && a.Rsave != nullptr && ab_raw == 0 && (tid & 15) == 0 &&
                     rg < a.B)
                     a.Rsave[((size_t)rg * a.T + t) * Fp + 16 * a.tail_tile + i] = rt;
@@ -617,7 +632,11 @@ resid_div_kernel(const float* __restrict__ xp, float* __restrict__ r, const int*
 }
 
 template <int G, int KS, int RB, bool AH, bool HALF, bool LATE = false>
-void* a_func(bool first, bool last) {
+void* a_func(bool first, bool last, bool qred = false) {
+    if (qred && !LATE) {        // (first layers never read the previous layer's odd bins)
+        if (last) return (void*)&cell_a_kernel<G, KS, RB, false, true, AH, HALF, false, true>;
+        if (!first) return (void*)&cell_a_kernel<G, KS, RB, false, false, AH, HALF, false, true>;
+    }
     if (first && last) return (void*)&cell_a_kernel<G, KS, RB, true, true, AH, HALF, LATE>;
     if (first) return (void*)&cell_a_kernel<G, KS, RB, true, false, AH, HALF, LATE>;
     if (last) return (void*)&cell_a_kernel<G, KS, RB, false, true, AH, HALF, LATE>;
@@ -625,44 +644,46 @@ void* a_func(bool first, bool last) {
 }
 
 template <int KS, int RB, bool AH, bool HALF>
-void* a_func_g(int per_wave, bool first, bool last) {
+void* a_func_g(int per_wave, bool first, bool last, bool qred = false) {
     // G operand slots; operand registers G * (4*KS*RB + 8)
-    if (per_wave <= 2) return a_func<2, KS, RB, AH, HALF>(first, last);
-    if (HALF && RB == 1 && per_wave >= 8 && getenv("DRNMF_G8"))   // tuning aid: 8 operand slots
-        return a_func<8, KS, 1, AH, HALF>(first, last);
+    if (per_wave <= 2) return a_func<2, KS, RB, AH, HALF>(first, last, qred);
+    if (HALF && per_wave >= 8 && getenv("DRNMF_G8"))   // tuning aid: 8 operand slots
+        return a_func<8, KS, RB, AH, HALF>(first, last, qred);
     // (8 slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch)
     // two groups per wave (F = 513), one row block, fp32: epilogue operand loads behind the first chunk
     bool late = RB == 1 && !HALF && per_wave > 4 && per_wave <= 8;
     if (const char* e = getenv("DRNMF_LATE"))   // tuning aid: 0 = never, 2 = whenever instantiated
         late = atoi(e) == 2 ? (RB == 1 && !HALF && per_wave > 2) : (late && atoi(e) != 0);
-    if (late) return a_func<4, KS, RB, AH, HALF, (RB == 1 && !HALF)>(first, last);
-    return a_func<4, KS, RB, AH, HALF>(first, last);
+    if (late && !qred) return a_func<4, KS, RB, AH, HALF, (RB == 1 && !HALF)>(first, last);
+    return a_func<4, KS, RB, AH, HALF>(first, last, qred);
 }
 
 template <bool AH, bool HALF>
-void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last) {
+void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last, bool qred) {
     // row-blocked variants exist for KS <= 2 (workspace_layout never pairs RB > 1 with more)
-    if (RB == 2) return KS == 1 ? a_func_g<1, 2, AH, HALF>(per_wave, first, last)
-                                : a_func_g<2, 2, AH, HALF>(per_wave, first, last);
+    if (RB == 2) return KS == 1 ? a_func_g<1, 2, AH, HALF>(per_wave, first, last, qred)
+                                : a_func_g<2, 2, AH, HALF>(per_wave, first, last, qred);
     switch (KS) {
-        case 1: return a_func_g<1, 1, AH, HALF>(per_wave, first, last);
-        case 2: return a_func_g<2, 1, AH, HALF>(per_wave, first, last);
-        case 4: return a_func_g<4, 1, AH, HALF>(per_wave, first, last);
-        default: return a_func_g<8, 1, AH, HALF>(per_wave, first, last);
+        case 1: return a_func_g<1, 1, AH, HALF>(per_wave, first, last, qred);
+        case 2: return a_func_g<2, 1, AH, HALF>(per_wave, first, last, qred);
+        case 4: return a_func_g<4, 1, AH, HALF>(per_wave, first, last, qred);
+        default: return a_func_g<8, 1, AH, HALF>(per_wave, first, last, qred);
     }
 }
 
-void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_hidden, bool half) {
+void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_hidden, bool half,
+                  bool qred = false) {
     const int per_wave = (nchunks + NW_A - 1) / NW_A;
     if (half) {   // KS = 1, nchunks counts 32-bin chunks
         if (all_hidden)   // (training: every hidden layer goes out in fp32 for the fp32 BPTT)
-            return RB == 2 ? a_func_g<1, 2, true, true>(per_wave, first, last)
-                           : a_func_g<1, 1, true, true>(per_wave, first, last);
-        return RB == 2 ? a_func_g<1, 2, false, true>(per_wave, first, last)
-                       : a_func_g<1, 1, false, true>(per_wave, first, last);
+            return RB == 2 ? a_func_g<1, 2, true, true>(per_wave, first, last, qred)
+                           : a_func_g<1, 1, true, true>(per_wave, first, last, qred);
+        if (RB == 4) return a_func_g<1, 4, false, true>(per_wave, first, last, qred);
+        return RB == 2 ? a_func_g<1, 2, false, true>(per_wave, first, last, qred)
+                       : a_func_g<1, 1, false, true>(per_wave, first, last, qred);
     }
-    return all_hidden ? pick_a_func_ah<true, false>(per_wave, KS, RB, first, last)
-                      : pick_a_func_ah<false, false>(per_wave, KS, RB, first, last);
+    return all_hidden ? pick_a_func_ah<true, false>(per_wave, KS, RB, first, last, qred)
+                      : pick_a_func_ah<false, false>(per_wave, KS, RB, first, last, qred);
 }
 
 }  // namespace
@@ -952,6 +973,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     const int numM = W.Bp / (ROWS * W.RB), nft = W.nft_main;   // MFMA bin tiles (tail bins handled apart)
     const dim3 grid_a(8u * (unsigned)(W.Bp / (ROWS * W.RBa)), (unsigned)(round_up(W.numA, 8) / 8));
     const dim3 grid_b(8u * (unsigned)numM, (unsigned)(round_up(nft * W.KS, 8) / 8));
+    const bool qred = qred_wanted(W.numA, W.ntail, nft, W.KS, W.RB);
     // per stored layer Fp*Np*4 bytes: the fp32 packing, or the fp16 DpA packing followed by DpB
     const char* Dn_base = pb + L.off_dn;
     const size_t dstride = (size_t)L.Fp * L.Np * 4;
@@ -994,13 +1016,15 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.Dtail_next = tail_of(k + 1 < K ? k + 1 : k);
         float* qp = (float*)(ws + W.off_qpart);
         const size_t qstride = (size_t)W.numA * MAX_TAIL * W.Bp;
-        a.q_in = qp + (size_t)((k + 1) & 1) * qstride;    // written by layer k-1
+        a.q_in = qred ? (const float*)(ws + W.off_qsum)   // layer k-1's partials, summed by cell_b
+                      : qp + (size_t)((k + 1) & 1) * qstride;
         a.q_out = qp + (size_t)(k & 1) * qstride;
         a.xtail = (float*)(ws + W.off_xtail);
         a.xcur = (float*)(ws + W.off_xcur);
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
         a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
+        a.ablate = getenv("DRNMF_ABLATE_A") ? atoi(getenv("DRNMF_ABLATE_A")) : 0;
         a.Rsave = (W.off_rsave != 0 && k >= 1)
                       ? (float*)(ws + W.off_rsave) + (size_t)(k - 1) * d->B * d->T * W.Fp : nullptr;
         return a;
@@ -1016,6 +1040,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         b.logKS = 0;
         while ((1 << b.logKS) < W.KS) ++b.logKS;
         b.nch_ks = W.nch_ks;
+        b.ablate = getenv("DRNMF_ABLATE_B") ? atoi(getenv("DRNMF_ABLATE_B")) : 0;
+        b.q_in = (const float*)(ws + W.off_qpart) + (size_t)(k & 1) * W.numA * MAX_TAIL * W.Bp;
+        b.qsum = (float*)(ws + W.off_qsum);
+        b.numA = W.numA; b.ntail = W.ntail;
         return b;
     };
 
@@ -1041,13 +1069,13 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 void** kp = kpa.p;
                 DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
                 DRNMF_HIP(h, hipLaunchKernel(pick_a_func(a.nchunks, W.KS, W.RBa, k == 0, k == K - 1,
-                                                         d->return_all_hidden != 0, half),
+                                                         d->return_all_hidden != 0, half, qred),
                                              grid_a, dim3(64 * NW_A), kp, 0, stream));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     CellBParams kb(b);
                     DRNMF_HIP(h, mark(1));
-                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks, W.RB, half), grid_b, dim3(64 * NW_B), kb.p, 0,
+                    DRNMF_HIP(h, hipLaunchKernel(pick_b_func(W.nch_ks, W.RB, half, qred), grid_b, dim3(64 * NW_B), kb.p, 0,
                                                  stream));
                 }
             }
@@ -1116,10 +1144,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 CellAArgs a = make_a(k);
                 CellAParams ka_(a);
                 void** ka = ka_.p;
-                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(a.nchunks, W.KS, W.RBa, k == 0, k == K - 1, d->return_all_hidden != 0, half), grid_a, 64 * NW_A, ka));
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(a.nchunks, W.KS, W.RBa, k == 0, k == K - 1, d->return_all_hidden != 0, half, qred), grid_a, 64 * NW_A, ka));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
-                    DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB, half), grid_b, 64 * NW_B, CellBParams(b).p));
+                    DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB, half, qred), grid_b, 64 * NW_B, CellBParams(b).p));
                 }
             }
             if (K == 1) {

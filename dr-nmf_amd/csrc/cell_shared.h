@@ -20,6 +20,14 @@ struct CellBArgs {
     float* rpart;            // [KS][Bp][Fp]
     const int* t_rd;
     int Bp, Fp, Np, nft, KS, logKS, nch_ks;   // nch_ks = 16-atom chunks per atom range
+    int ablate = 0;          // measurement aid (DRNMF_ABLATE_B), see cell_b_kernel
+    // odd bins: the per-atom-block partial dot products the producing cell_a / bwd_a launch left
+    // ([MAX_TAIL][Bp][numA]) are summed HERE, by the first workgroup of every row tile group, into
+    // qsum [MAX_TAIL][Bp]: the consuming launch then loads one value per row instead of numA (at
+    // N = 8000, numA = 250, those loads were 1.7 us of texture-path time on the tail of every cell_a)
+    const float* q_in = nullptr;
+    float* qsum = nullptr;
+    int numA = 0, ntail = 0;
 };
 
 // x^ partial of one (row tile group, bin tile, atom range) and the residual partial
@@ -36,12 +44,16 @@ struct CellBArgs {
 // The arguments are passed as individual scalars (not as one struct) so that the command
 // processor can preload them into SGPRs (-amdgpu-kernarg-preload-count, build.py): the kernel
 // then starts without a dependent scalar load from the kernarg segment.
-template <int GB, int RB = 1, int NW = 8, bool HALF = false>
+template <int GB, int RB = 1, int NW = 8, bool HALF = false, bool QRED = false>
 __global__ void __launch_bounds__(64 * NW)
 cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rpart, int Fp_,
-              int Np_, int nft_, int KS_, int nch_ks_, int Bp_) {   // 14 dwords: all preloaded
+              int Np_, int nft_, int KS_, int nch_ks_, int Bp_, int ablate_,   // 15 dwords: preloaded
+              const float* q_in, float* qsum, int numA, int ntail) {
+    // (ablate_: measurement aid DRNMF_ABLATE_B, bit 0 = every dictionary load reads chunk 0, bit 1 =
+    // every activation load reads chunk 0 -- the stream in question then costs nothing; results are garbage)
     const CellBArgs a{Dn_next, h_in, xp, rpart, nullptr, Bp_, Fp_, Np_, nft_, KS_,
-                      __builtin_ctz((unsigned)KS_), nch_ks_};
+                      __builtin_ctz((unsigned)KS_), nch_ks_, ablate_, q_in, qsum, numA, ntail};
+    __shared__ float qred[MAX_TAIL][NW];
     __shared__ __attribute__((aligned(16))) float red[NW * RB * 16 * 17];   // row stride 17: the
     // epilogue threads read (row, bin 4s+q) with row fastest -- stride 16 would be an 8-way bank conflict
     // 2-D grid (x = 8 * row tile group + XCD slot, y = octet of (bin tile, atom range)): see
@@ -77,15 +89,23 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
     const f16* brow16 = (const f16*)a.Dn_next + ((size_t)ft * NAC + cbase) * 512 + l * 8;
 
     // branch-free operand loads (clamped chunk index, zeroed A operand when out of range)
+    // ALLB (fp16, GB = 32: long contractions, F = 1025 / N = 8000): every dictionary operand of the
+    // wave -- the stream that comes from HBM -- is requested before the first MFMA (32 x 4 VGPRs),
+    // the activations (L2) follow in a rotating window of AW slots.  With both streams in one
+    // rotating window the wave stalled on each HBM round trip with its L1 path idle: the two
+    // latencies added up instead of overlapping.
+    constexpr bool ALLB = HALF && GB == 32;
+    constexpr int AW = 8;
     f32x4 av[HALF ? 1 : GB][RB], bv[HALF ? 1 : GB];
-    f16x8 ah[HALF ? GB : 1][RB], bh[HALF ? GB : 1];
+    f16x8 ah[HALF ? (ALLB ? AW : GB) : 1][RB], bh[HALF ? GB : 1];
     auto load_chunk = [&](int base, int g) {
         int c = w + NW * (base + g);
         c = c > clast ? clast : c;
         if (HALF) {
+            const int ca = (ablate_ & 2) ? 0 : c, cb = (ablate_ & 1) ? 0 : c;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * c);
-            bh[g] = *(const f16x8*)(brow16 + 512 * c);
+            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
+            bh[g] = *(const f16x8*)(brow16 + 512 * cb);
         } else {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) av[g][rb] = *(const f32x4*)(arow + rb * astep + 256 * c);
@@ -93,11 +113,27 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
         }
     };
     // software pipeline: loads run PF chunks ahead of the MFMAs (see cell_a_kernel)
-    constexpr int PF0 = HALF ? 7 : (RB > 1 ? 3 : 6);   // (8 = every chunk of the C2 shape up front: no gain)
+    constexpr int PF0 = HALF ? AW - 1 : (RB > 1 ? 3 : 6);   // (8 = every chunk of the C2 shape up front: no gain)
     constexpr int PF = GB < PF0 ? GB : PF0;
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(0, g);
 
+    // odd-bin partials (see CellBArgs): workgroup r < 16*RB of a row tile group sums the numA
+    // partials of its row r.  Issued behind the first operand loads (the arguments involved are not
+    // among the preloaded ones: nothing ahead of the operand loads may wait for the kernarg fetch),
+    // one load per thread, summed after the MFMA loop.
+    // QRED is instantiated for numA > 64 only (N > 2048; such shapes have >= 16*RB workgroups per
+    // row tile group): below that the consumer adds its 4 prefetched partials itself and this
+    // kernel is exactly the one measured before (the extra arguments are then never fetched).
+    const bool qwg = QRED && a.ntail > 0 && rest_raw < 16 * RB;      // (workgroup-uniform)
+    const int rgq = (m * RB + (rest_raw >> 4)) * 16 + (rest_raw & 15);
+    float qv1[MAX_TAIL];
+#pragma unroll
+    for (int i = 0; i < MAX_TAIL; ++i) {
+        qv1[i] = 0.f;
+        if (QRED && qwg && i < a.ntail && tid < a.numA)
+            qv1[i] = a.q_in[((size_t)i * a.Bp + rgq) * a.numA + tid];
+    }
     // x_t element for the epilogue: issued behind the operand loads, consumed at the very end
     // thread p of the first 256 owns the element at position p of the output block (rp_pos order:
     // p = (q*16 + row)*4 + s <-> bin 4s + q), so that the x_t load and the store are contiguous
@@ -137,16 +173,45 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
             }
         }
     };
-    if (HALF) {
+    if (ALLB) {
+        // (the prologue filled A and B slots 0 .. AW-2; the rest of the dictionary operands now)
+#pragma unroll
+        for (int g = AW - 1; g < GB; ++g) {
+            int c = w + NW * g;
+            c = c > clast ? clast : c;
+            bh[g] = *(const f16x8*)(brow16 + 512 * ((ablate_ & 1) ? 0 : c));
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            {
+                int c = w + NW * (i + AW - 1);
+                c = c > clast ? clast : c;
+                const int ca = (ablate_ & 2) ? 0 : c;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    ah[(i + AW - 1) % AW][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool ok = i < per_wave;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                f16x8 a8 = ah[i % AW][rb];
+                if (!ok) a8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                acc[rb][i & 1] = mfma32h(a8, bh[i], acc[rb][i & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (HALF) {
         // rotating operand slots (as cell_a_kernel): chunk i lives in slot i mod GB and its loads run
         // GB-1 chunks ahead of its MFMA, so the stream never drains between groups -- the
         // dictionary of this mode comes from HBM (K untied layers exceed the Infinity Cache)
         auto load_slot = [&](int i, int g) {
             int c = w + NW * i;
             c = c > clast ? clast : c;
+            const int ca = (ablate_ & 2) ? 0 : c, cb = (ablate_ & 1) ? 0 : c;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * c);
-            bh[g] = *(const f16x8*)(brow16 + 512 * c);
+            for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
+            bh[g] = *(const f16x8*)(brow16 + 512 * cb);
         };
         // (the prologue above filled slots 0 .. PF-1 = GB-1 or fewer; top up to GB-1)
 #pragma unroll
@@ -179,7 +244,26 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
 #pragma unroll
         for (int v = 0; v < 4; ++v)
             red[((w * RB + rb) * 16 + 4 * q + v) * 17 + j] = acc[rb][0][v] + acc[rb][1][v];
+    if (QRED && qwg) {
+#pragma unroll
+        for (int i = 0; i < MAX_TAIL; ++i) {
+            float sq = qv1[i];
+            if (i < a.ntail)
+                for (int b2 = tid + 64 * NW; b2 < a.numA; b2 += 64 * NW)     // numA > 64 NW only
+                    sq += a.q_in[((size_t)i * a.Bp + rgq) * a.numA + b2];
+            sq = row16_sum(sq);                       // fixed reduction tree: deterministic
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (l == 0) qred[i][w] = sq;
+        }
+    }
     __syncthreads();
+    if (QRED && qwg && tid < a.ntail) {
+        float tot = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) tot += qred[tid][ww];
+        a.qsum[(size_t)tid * a.Bp + rgq] = tot;
+    }
     if (tid >= 256) return;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -200,9 +284,10 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
 
 // kernelParams array of cell_b_kernel for hipLaunchKernel / hipGraphAddKernelNode
 struct CellBParams {
-    void* p[10];
+    void* p[15];
     explicit CellBParams(CellBArgs& b)
-        : p{&b.Dn_next, &b.h, &b.xp, &b.rpart, &b.Fp, &b.Np, &b.nft, &b.KS, &b.nch_ks, &b.Bp} {}
+        : p{&b.Dn_next, &b.h, &b.xp, &b.rpart, &b.Fp, &b.Np, &b.nft, &b.KS, &b.nch_ks, &b.Bp,
+            &b.ablate, &b.q_in, &b.qsum, &b.numA, &b.ntail} {}
 };
 
 __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
@@ -264,7 +349,7 @@ struct Workspace {
     int RB;                // 16-row blocks per workgroup (1 or 2); Bp is a multiple of 16*RB
     int RBa;               // the same for cell_a alone (= RB; the fp16 mode may block cell_a only)
     int nft_main, ntail;   // forward: bins 16*nft_main .. F-1 (at most MAX_TAIL) are handled outside the MFMA tiles
-    size_t off_qpart, off_xtail, off_xcur;
+    size_t off_qpart, off_xtail, off_xcur, off_qsum;
     size_t off_h16_0, off_h16_1, off_r16;   // fp16 operand mode: Hp16 ping-pong, Rp16 (cell_b_kernel)
     bool half;
     // Gram form (cell_gram.h): packed c, ring of 2 x GRAM_TB frames [.][K][Bp][Np]; one block of x
@@ -308,10 +393,12 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.RBa = W.RB;
     if (W.half && W.RB == 1) {
         const int groups = round_up(d->B, ROWS * 2) / (ROWS * 2);
-        (void)groups;   // measured at F=1025, N=8000, B=64: two row blocks 11.8 us per launch, one 11.0: off
+        // measured at F=1025, N=8000, B=64 (once the odd-bin partials were out of cell_a's tail): one row
+        // block 10.4 us per launch, two 9.6, four 10.0
+        if (groups * W.numA >= 256) W.RBa = 2;
         if (const char* e = getenv("DRNMF_RBA")) {
             const int v = atoi(e);
-            if (v == 1 || v == 2) W.RBa = v;
+            if (v == 1 || v == 2 || (v == 4 && !d->return_all_hidden)) W.RBa = v;
         }
     }
     W.Bp = round_up(d->B, ROWS * (W.RBa > W.RB ? W.RBa : W.RB));
@@ -349,6 +436,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_psum = take((size_t)W.Bp * 4);
     W.off_qpart = take((size_t)2 * W.numA * MAX_TAIL * W.Bp * 4);
     W.off_xtail = take((size_t)MAX_TAIL * W.Bp * 4);
+    W.off_qsum = take((size_t)MAX_TAIL * W.Bp * 4);
     W.off_xcur = take((size_t)W.Bp * W.Fp * 4);
     W.off_h16_0 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_h16_1 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
@@ -368,18 +456,33 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     return W;
 }
 
-template <int RB, bool HALF>
+// The consumer of cell_b's odd-bin sums (cell_a / bwd_a) and cell_b itself must agree on who adds
+// the partials: cell_b when there are more than 64 atom blocks and enough workgroups to cover the
+// 16*RB rows of a tile group.
+static inline bool qred_wanted(int numA, int ntail, int nft, int KS, int RB) {
+    return ntail > 0 && numA > 64 && nft * KS >= 16 * RB;
+}
+
+template <int RB, bool HALF, bool QRED>
 void* pick_b_func_rb(int nch_ks) {
     const int per_wave = (nch_ks + 7) / 8;
-    if (per_wave <= 2) return (void*)&cell_b_kernel<2, RB, 8, HALF>;
-    if (per_wave <= 4) return (void*)&cell_b_kernel<4, RB, 8, HALF>;
-    return (void*)&cell_b_kernel<8, RB, 8, HALF>;
+    if (per_wave <= 2) return (void*)&cell_b_kernel<2, RB, 8, HALF, QRED>;
+    if (per_wave <= 4) return (void*)&cell_b_kernel<4, RB, 8, HALF, QRED>;
+    if constexpr (HALF && RB == 1) {
+        if (per_wave > 8 && per_wave <= 32 && !getenv("DRNMF_NO_ALLB"))
+            return (void*)&cell_b_kernel<32, 1, 8, true, QRED>;     // all dictionary operands up front
+    }
+    return (void*)&cell_b_kernel<8, RB, 8, HALF, QRED>;
 }
-void* pick_b_func(int nch_ks, int RB = 1, bool half = false) {
+void* pick_b_func(int nch_ks, int RB = 1, bool half = false, bool qred = false) {
     // fp16: nch_ks counts 32-atom chunks; eight rotating operand slots where a wave owns that many
-    if (half) return RB == 2 ? pick_b_func_rb<2, true>(nch_ks) : pick_b_func_rb<1, true>(nch_ks);
-    if (RB == 2) return pick_b_func_rb<2, false>(nch_ks);
-    return pick_b_func_rb<1, false>(nch_ks);
+    if (qred) {
+        if (half) return RB == 2 ? pick_b_func_rb<2, true, true>(nch_ks) : pick_b_func_rb<1, true, true>(nch_ks);
+        return RB == 2 ? pick_b_func_rb<2, false, true>(nch_ks) : pick_b_func_rb<1, false, true>(nch_ks);
+    }
+    if (half) return RB == 2 ? pick_b_func_rb<2, true, false>(nch_ks) : pick_b_func_rb<1, true, false>(nch_ks);
+    if (RB == 2) return pick_b_func_rb<2, false, false>(nch_ks);
+    return pick_b_func_rb<1, false, false>(nch_ks);
 }
 
 }  // namespace
