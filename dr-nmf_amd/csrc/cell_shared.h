@@ -469,6 +469,8 @@ void* pick_b_func_rb(int nch_ks) {
     if (per_wave <= 2) return (void*)&cell_b_kernel<2, RB, 8, HALF, QRED>;
     if (per_wave <= 4) return (void*)&cell_b_kernel<4, RB, 8, HALF, QRED>;
     if constexpr (HALF && RB == 1) {
+        // (a deeper rotating window for BOTH streams is slower: 16 slots 11.3, 24 slots 13.7 us per
+        // cell_b launch against 10.4 with 8 and 9.8 with the dictionary operands up front)
         if (per_wave > 8 && per_wave <= 32 && !getenv("DRNMF_NO_ALLB"))
             return (void*)&cell_b_kernel<32, 1, 8, true, QRED>;     // all dictionary operands up front
     }
