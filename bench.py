@@ -653,6 +653,7 @@ def main():
     # ---------------- headline: forward + loss + BPTT + Adam (the metric's "fwd+bwd") ----------
     out = {}
     train = None
+    collective = None
     if not a.forward_only:
         def on_timeout():
             # a collective that never comes back: say so and leave with a failure code (the
@@ -662,6 +663,29 @@ def main():
                                   "error": "training step timed out (collective?)",
                                   "n_gpus": world}), flush=True)
             os._exit(3)
+
+        if world > 1:
+            # the gradient all-reduce goes through libdrnmf's RCCL communicator (C ABI).  Should its
+            # creation fail on this node the measurement is still taken -- through
+            # torch.distributed's all-reduce -- and the JSON line says so, loudly.
+            from drnmf_amd import dp
+            if os.environ.get("DRNMF_DP_BACKEND", "rccl") == "torch":
+                collective = "torch.distributed all-reduce (DRNMF_DP_BACKEND=torch)"
+            else:
+                try:
+                    dp.comm_init(dev)
+                    collective = "drnmf_allreduce_grads (RCCL communicator owned by the library handle)"
+                except Exception as e:       # noqa: BLE001
+                    os.environ["DRNMF_DP_BACKEND"] = "torch"
+                    collective = ("FALLBACK to torch.distributed all-reduce: drnmf_comm_init failed: "
+                                  + repr(e)[:200])
+                # every rank must take the same path
+                flag = torch.tensor([1.0 if collective.startswith("FALLBACK") else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if float(flag.item()) > 0 and not collective.startswith("FALLBACK"):
+                    dp.comm_destroy()
+                    os.environ["DRNMF_DP_BACKEND"] = "torch"
+                    collective = "FALLBACK to torch.distributed all-reduce: drnmf_comm_init failed on another rank"
 
         def headline():
             model.compile(lr=1e-3)
@@ -698,7 +722,8 @@ def main():
                                    (K, F, N, "tied" if a.tied else "untied", B, T,
                                     ", one RCCL all-reduce of the flat gradient per step"
                                     if world > 1 else ""),
-                       "B_per_gpu": B, "T": T, "F": F, "N": N, "K": K, "untied": not a.tied},
+                       "B_per_gpu": B, "T": T, "F": F, "N": N, "K": K, "untied": not a.tied,
+                       "collective": collective},
             "roofline": {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": traffic_src,
