@@ -36,7 +36,7 @@ static int tn_splits(int M, int N, int64_t Kdim) {
     }
     return best;
 }
-constexpr int CR_SPLITS = 64;
+constexpr int CR_SPLITS = 256;
 
 struct EdgeArgs {
     const float* hall;       // [B][T][K*N]
@@ -557,6 +557,21 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const ColRedArgs a) {
     a.part[((size_t)sp * 2 + 1) * a.Np + n] = sg;
 }
 
+// stage 1 of the scalar gradients: the CR_SPLITS partial sums of every atom, added in split order
+// (one thread per atom; slot 0 of `part` receives the totals)
+__global__ void __launch_bounds__(256)
+colreduce_fold_kernel(float* __restrict__ part, int N, int Np) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float sb = 0.f, sg = 0.f;
+    for (int s = 0; s < CR_SPLITS; ++s) {
+        sb += part[((size_t)s * 2 + 0) * Np + n];
+        sg += part[((size_t)s * 2 + 1) * Np + n];
+    }
+    part[n] = sb;
+    part[(size_t)Np + n] = sg;
+}
+
 // d log_alph / d log_lam1 of layer k from the per-atom sums: ia = exp(-log_alph), b = -lam * ia
 //   d log_alph[n] = -Sgi[n] - b[n] Sb[n];   d log_lam1 = sum_n b[n] Sb[n]
 __global__ void __launch_bounds__(256)
@@ -566,11 +581,7 @@ scalar_grads_kernel(const float* __restrict__ part, const float* __restrict__ bi
     __shared__ float sa[256], sl[256];
     float ta = 0.f, tl = 0.f;
     for (int n = threadIdx.x; n < N; n += 256) {
-        float sb = 0.f, sg = 0.f;
-        for (int s = 0; s < CR_SPLITS; ++s) {
-            sb += part[((size_t)s * 2 + 0) * Np + n];
-            sg += part[((size_t)s * 2 + 1) * Np + n];
-        }
+        const float sb = part[n], sg = part[(size_t)Np + n];      // folded by colreduce_fold_kernel
         const float b = bias[n];
         const float va = -sg - b * sb;
         tl += b * sb;
@@ -940,6 +951,8 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         hipLaunchKernelGGL(colreduce_kernel, dim3((N + 255) / 256, CR_SPLITS), dim3(256), 0, stream,
                            ca);
         const int ka = d->n_alph == 1 ? 0 : k, kl = d->n_lam == 1 ? 0 : k;
+        hipLaunchKernelGGL(colreduce_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, crp,
+                           N, W.Np);
         hipLaunchKernelGGL(scalar_grads_kernel, dim3(1), dim3(256), 0, stream, crp, b_of(k),
                            d_log_alph + (size_t)ka * d->alph_len, d_log_lam1 + kl, N, W.Np,
                            d->alph_len, (d->n_alph == 1 && k > 0) ? 1 : 0,
