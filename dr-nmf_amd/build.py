@@ -21,7 +21,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # the GEMMs against the generic target.  A process with XNACK enabled (HSA_XNACK=1) cannot load it:
 # set DRNMF_OFFLOAD_ARCH=gfx950 and rebuild.
 ARCH = ["--offload-arch=" + os.environ.get("DRNMF_OFFLOAD_ARCH", "gfx950:xnack-")]
-FLAGS = ARCH + ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# DRNMF_TIMELINE=1: measurement build with s_memtime stamps in the cell kernels (tools/timeline.py)
+FLAGS = ARCH + (["-DDRNMF_TIMELINE"] if os.environ.get("DRNMF_TIMELINE") else []) + ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          # scalar kernel arguments arrive preloaded in SGPRs (no kernarg load on the critical path)
          "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 

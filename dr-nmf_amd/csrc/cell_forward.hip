@@ -99,6 +99,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     a.rsrc = rsrc_; a.Dn = Dn_; a.t_rd = t_rd_; a.Bp = Bp_; a.Fp = Fp_; a.Np = Np_;
     a.numA = numA_; a.nchunks = nchunks_;
     constexpr bool WRITE_OUT = IS_LAST || ALL_HIDDEN;
+    DRNMF_STAMP(1, 0);
     __shared__ __attribute__((aligned(16))) float red[NW_A * RB * ROWS * ATOMS];   // [NW][RB][16][32]
 
     // 2-D grid (x = 8 * row tile group + XCD slot, y = atom block octet): workgroups are dealt
@@ -214,6 +215,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // everything below depends on struct fields that are still being fetched by scalar loads:
     // keep it (and the wait for those loads) behind the first operand loads
     __builtin_amdgcn_sched_barrier(0);
+    DRNMF_STAMP(1, 1);
 
     // ---- epilogue operands (tiny, needed last).  Their loads are issued behind the FIRST chunk's
     // MFMAs (load_epilogue_operands below): issued ahead of the GEMM loop they sat between the
@@ -430,6 +432,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     }
 
     // ---- cross-wave reduction of the 4 F-splits through LDS --------------------------------
+    DRNMF_STAMP(1, 3);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -438,6 +441,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             *(f32x2*)(red + ((w * RB + rb) * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
         }
     __syncthreads();
+    DRNMF_STAMP(1, 4);
     if (NW_A > 4 && tid >= 256) return;   // the elementwise epilogue is 256 threads wide
 
 #pragma unroll
@@ -452,6 +456,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             gsum[1] += p2[1];
         }
 
+        DRNMF_STAMP(1, 6);
 #pragma unroll
         for (int i = 0; i < MAX_TAIL; ++i) {   // rank-1 update per tail bin
             if (i >= a.ntail) continue;
@@ -476,6 +481,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             gsum[1] = fmaf(rt, dt[i][1], gsum[1]);
         }
 
+        DRNMF_STAMP(1, 7);
         // ---- fused update: soft-threshold / non-negativity projection ----------------------
         f32x2 hn;
 #pragma unroll
@@ -526,6 +532,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             }
         }
     }
+    DRNMF_STAMP(1, 5);
 }
 
 // kernelParams array of cell_a_kernel
@@ -687,6 +694,14 @@ void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_h
 }
 
 }  // namespace
+
+#ifdef DRNMF_TIMELINE
+extern "C" int32_t drnmf_debug_timeline(void* out_host, size_t bytes) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_timeline),
+                               bytes < sizeof(g_timeline) ? bytes : sizeof(g_timeline)) == hipSuccess
+               ? 0 : -3;
+}
+#endif
 
 extern "C" int32_t drnmf_cell_launches_per_frame(const drnmf_cell_desc_t* d) {
     if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0 || d->K <= 0) return 0;

@@ -4,6 +4,21 @@
 #pragma once
 #include "common.h"
 
+// Measurement aid, compiled only with -DDRNMF_TIMELINE (build.py: DRNMF_TIMELINE=1): s_memtime stamps
+// of wave 0 of every workgroup of the LAST launch of cell_b / cell_a, read back with
+// drnmf_debug_timeline (tools/timeline.py).
+#ifdef DRNMF_TIMELINE
+__device__ unsigned long long g_timeline[2][1024][8];
+#define DRNMF_STAMP(kid, slot)                                                               \
+    do {                                                                                     \
+        if (threadIdx.x == 0)                                                                \
+            g_timeline[kid][(blockIdx.y * gridDim.x + blockIdx.x) & 1023][slot] =           \
+                __builtin_amdgcn_s_memtime();                                                \
+    } while (0)
+#else
+#define DRNMF_STAMP(kid, slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
@@ -59,6 +74,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
     // 2-D grid (x = 8 * row tile group + XCD slot, y = octet of (bin tile, atom range)): see
     // cell_a_kernel.  KS is a power of two.  Padded blocks redo the last tile with the store
     // predicated off.
+    DRNMF_STAMP(0, 0);
     const int m = blockIdx.x >> 3;
     const int rest_raw = blockIdx.y * 8 + (blockIdx.x & 7);
     const bool live = rest_raw < a.nft * a.KS;
@@ -112,6 +128,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
             bv[g] = *(const f32x4*)(brow + 256 * c);
         }
     };
+    DRNMF_STAMP(0, 1);
     // software pipeline: loads run PF chunks ahead of the MFMAs (see cell_a_kernel)
     constexpr int PF0 = HALF ? AW - 1 : (RB > 1 ? 3 : 6);   // (8 = every chunk of the C2 shape up front: no gain)
     constexpr int PF = GB < PF0 ? GB : PF0;
@@ -200,7 +217,9 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
                 acc[rb][i & 1] = mfma32h(a8, bh[i], acc[rb][i & 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (i == 0) DRNMF_STAMP(0, 2);
         }
+        DRNMF_STAMP(0, 3);
     } else if (HALF) {
         // rotating operand slots (as cell_a_kernel): chunk i lives in slot i mod GB and its loads run
         // GB-1 chunks ahead of its MFMA, so the stream never drains between groups -- the
@@ -237,8 +256,10 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
             __builtin_amdgcn_sched_barrier(0);
             compute_chunk(base, g);
             __builtin_amdgcn_sched_barrier(0);
+            if (base == 0 && g == 0) DRNMF_STAMP(0, 2);
         }
     }
+    DRNMF_STAMP(0, 3);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -258,6 +279,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
         }
     }
     __syncthreads();
+    DRNMF_STAMP(0, 4);
     if (QRED && qwg && tid < a.ntail) {
         float tot = 0.f;
 #pragma unroll
@@ -280,6 +302,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
             a.rpart[(size_t)ks * a.Bp * Fp + eoff + rb * estep] = (a.xp != nullptr) ? xv[rb] - s : s;
         }
     }
+    DRNMF_STAMP(0, 5);
 }
 
 // kernelParams array of cell_b_kernel for hipLaunchKernel / hipGraphAddKernelNode
@@ -470,7 +493,9 @@ void* pick_b_func_rb(int nch_ks) {
     if (per_wave <= 4) return (void*)&cell_b_kernel<4, RB, 8, HALF, QRED>;
     if constexpr (HALF && RB == 1) {
         // (a deeper rotating window for BOTH streams is slower: 16 slots 11.3, 24 slots 13.7 us per
-        // cell_b launch against 10.4 with 8 and 9.8 with the dictionary operands up front)
+        // cell_b launch against 10.4 with 8 and 9.8 with the dictionary operands up front; 16 waves
+        // with every operand of every chunk requested up front: 19 us -- the per-CU miss path
+        // degrades when it is flooded)
         if (per_wave > 8 && per_wave <= 32 && !getenv("DRNMF_NO_ALLB"))
             return (void*)&cell_b_kernel<32, 1, 8, true, QRED>;     // all dictionary operands up front
     }
