@@ -26,6 +26,7 @@ struct Operands {
     int64_t M;
     int N, K;
     int64_t lda, ldb;
+    int ktail = 0;    // extra contraction columns K .. K+ktail-1 (<= 2), see below
 };
 
 // VEC: lda, ldb, K multiples of 4, base pointers 16-byte aligned -> one branch-free float4 load
@@ -52,12 +53,26 @@ __device__ __forceinline__ f32x4 load4(const float* base, int64_t row, int64_t n
     return v;
 }
 
-// Epi: struct with   f32x2 pre(int64_t row, int col) const        -- values the update needs from memory
+// Epi: struct with   f32x2 pre(int64_t row, int col) const   -- per-element values from memory (raw loads)
 //                    void operator()(int64_t row, int col, float acc, f32x2 pre) const
-// The epilogue first issues all 16 `pre` loads of a 32x32 tile, then applies: one memory round trip
-// per tile instead of one per element.
+// All of a workgroup's pre loads (its 128 x 128 outputs) are issued BEFORE the MFMAs of the last
+// k-tile and first consumed after them: the epilogue's memory round trip -- with the short
+// contractions here (K = 512: 16 k-tiles) a tenth of a workgroup's life when it was paid once per
+// 32 x 32 tile after the loop -- hides under matrix work.  `pre` therefore returns what it loaded
+// untouched (arithmetic on a loaded value would pull its wait in front of the MFMAs).
+// `static constexpr bool EARLY = false` in the functor keeps the per-tile order (register budget:
+// the kernel must stay at two waves per SIMD, a spilled loaded value waits for its load).
+//
+// Operands::ktail (0..2): contraction indices K .. K+ktail-1 are taken from the same arrays but
+// outside the k-tiles -- one extra MFMA step per output tile whose two k slots are those columns,
+// fragments fetched straight from global memory with the early loads.  This is how the odd bins of
+// a 2^k+1 STFT (K = 513 = 16 tiles + 1) ride along without a 17th, almost empty k-tile.
+template <class E, class = void> struct epi_early : std::true_type {};
+template <class E> struct epi_early<E, std::void_t<decltype(E::EARLY)>>
+    : std::integral_constant<bool, E::EARLY> {};
+
 template <class Epi, bool VEC>
-__global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Epi epi) {
+__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDS_LD];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
@@ -118,24 +133,33 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Ep
             *(f32x4*)(Bs + (srow + 32 * i) * LDS_LD + sk) = vb;
         }
     };
-
-    const int nkt = (g.K + BK - 1) / BK;
-    gload(0);
-    swrite(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) gload((kt + 1) * BK);   // in flight during this tile's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
+    // One k-tile = 4 chunks of 8 contraction slots = 64 MFMAs per wave.  Everything else a k-tile
+    // needs is pinned between them with sched_group_barrier (left to itself the compiler issued the
+    // LDS reads in bursts and waited for them in front of the MFMAs, twice per k-tile):
+    //   chunk 0: fragments of chunk 1 (one ds_read_b128 behind every 2nd MFMA), then the 8 global
+    //            loads of the NEXT k-tile (one behind every MFMA)
+    //   chunk 1, 2: fragments of the next chunk in the first half, 8 bare MFMAs for them to land
+    //   chunk 3: the 8 LDS writes of the next k-tile (global loads issued ~3000 cycles earlier)
+    // STAGE = false (last k-tile): reads and MFMAs only.
+    auto ktile = [&](int buf, auto stage_tag, int k_next) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
         const float* As = lds + buf * 2 * BM * LDS_LD + (wm * 64 + li) * LDS_LD + 4 * kk;
         const float* Bs = lds + buf * 2 * BM * LDS_LD + BM * LDS_LD + (wn * 64 + li) * LDS_LD +
                           4 * kk;
+        f32x4 fa0[2], fa1[2], fb0[2], fb1[2];
+        auto fetch = [&](int c) {
+            fa0[c & 1] = *(const f32x4*)(As + 8 * c);
+            fb0[c & 1] = *(const f32x4*)(Bs + 8 * c);
+            fa1[c & 1] = *(const f32x4*)(As + 32 * LDS_LD + 8 * c);
+            fb1[c & 1] = *(const f32x4*)(Bs + 32 * LDS_LD + 8 * c);
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAGE) gload(k_next);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f32x4 a0 = *(const f32x4*)(As + 8 * c);
-            const f32x4 a1 = *(const f32x4*)(As + 32 * LDS_LD + 8 * c);
-            const f32x4 b0 = *(const f32x4*)(Bs + 8 * c);
-            const f32x4 b1 = *(const f32x4*)(Bs + 32 * LDS_LD + 8 * c);
+            if (c < 3) fetch(c + 1);
+            const f32x4 a0 = fa0[c & 1], a1 = fa1[c & 1], b0 = fb0[c & 1], b1 = fb1[c & 1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
@@ -144,39 +168,120 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const Operands g, const Ep
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
             }
         }
+        if (STAGE) swrite(buf ^ 1, k_next);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // 2 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 LDS read of the next chunk
+            }
+            if (STAGE && c == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 global load
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);       // reads land under these
+            }
+        }
+        if (STAGE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // 1 LDS write
+            }
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nkt) swrite(buf ^ 1, (kt + 1) * BK);
+    };
+
+    const int nkt = (g.K + BK - 1) / BK;
+    gload(0);
+    swrite(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < nkt; ++kt) {
+        ktile(kt & 1, std::true_type{}, (kt + 1) * BK);
         __syncthreads();
     }
 
-    // epilogue: register v of lane l holds row (v&3) + 8*(v>>2) + 4*(l>>5), column l&31.
-    // Row indices are formed in 32 bits (launch() refuses M >= 2^31): the functors' row * ld then
-    // is one 32 x 32 -> 64-bit multiply-add instead of a 64 x 32-bit product per element.
+    // Last k-tile and epilogue.  Register v of lane l holds row (v&3) + 8*(v>>2) + 4*(l>>5),
+    // column l&31.  Row indices are formed in 32 bits (launch() refuses M >= 2^31): the functors'
+    // row * ld then is one 32 x 32 -> 64-bit multiply-add instead of a 64 x 32-bit product.
+    constexpr bool EARLY = epi_early<Epi>::value;
     const int M32 = (int)g.M, m032 = (int)m0;
-    auto tile_epilogue = [&](auto full_tag) {
+    auto rowof = [&](int a, int v) { return m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk; };
+    auto colof = [&](int b) { return n0 + wn * 64 + b * 32 + li; };
+    auto finish = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;   // every row of the tile is inside M
+        f32x2 pv[EARLY ? 2 : 1][EARLY ? 2 : 1][16];
+        float ta[2] = {0.f, 0.f}, tb[2] = {0.f, 0.f};
+        const bool tk = kk < g.ktail;
+        if (g.ktail) {   // raw loads (clamped addresses); zeroed after the MFMAs
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int64_t r = m0 + wm * 64 + i * 32 + li;
+                const int c = n0 + wn * 64 + i * 32 + li;
+                ta[i] = g.A[(r < g.M ? r : g.M - 1) * g.lda + g.K + (tk ? kk : 0)];
+                tb[i] = g.Bt[(int64_t)(c < g.N ? c : g.N - 1) * g.ldb + g.K + (tk ? kk : 0)];
+            }
+        }
+        if (EARLY) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    int col = colof(b);
+                    col = col < g.N ? col : g.N - 1;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        int row = rowof(a, v);
+                        if (!FULL) row = row < M32 ? row : M32 - 1;
+                        pv[a][b][v] = epi.pre(row, col);
+                    }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ktile((nkt - 1) & 1, std::false_type{}, 0);
+        if (g.ktail) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!(tk && m0 + wm * 64 + i * 32 + li < g.M)) ta[i] = 0.f;
+                if (!(tk && n0 + wn * 64 + i * 32 + li < g.N)) tb[i] = 0.f;
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[0], tb[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[0], tb[1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[1], tb[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[1], tb[1], acc[1][1], 0, 0, 0);
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int col = n0 + wn * 64 + b * 32 + li;
+                const int col = colof(b);
                 if (col >= g.N) continue;
-                f32x2 pv[16];
+                if (!EARLY) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    int row = m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                    if (!FULL) row = row < M32 ? row : M32 - 1;
-                    pv[v] = epi.pre(row, col);
+                    for (int v = 0; v < 16; ++v) {
+                        int row = rowof(a, v);
+                        if (!FULL) row = row < M32 ? row : M32 - 1;
+                        pv[0][0][v] = epi.pre(row, col);
+                    }
                 }
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const int row = m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                    if (FULL || row < M32) epi(row, col, acc[a][b][v], pv[v]);
+                    int row = rowof(a, v);
+                    // opaque copy: the store addresses are formed again here instead of 64 64-bit
+                    // load addresses staying live across the MFMAs (that cost the second wave per SIMD)
+                    if (EARLY) asm volatile("" : "+v"(row));
+                    if (FULL || row < M32) epi(row, col, acc[a][b][v], pv[EARLY ? a : 0][EARLY ? b : 0][v]);
                 }
             }
     };
-    if (m032 + BM <= M32) tile_epilogue(std::true_type{});
-    else tile_epilogue(std::false_type{});
+    if (m032 + BM <= M32) finish(std::true_type{});
+    else finish(std::false_type{});
 }
 
 template <class Epi>
@@ -184,7 +289,8 @@ inline hipError_t launch(const Operands& g, const Epi& epi, hipStream_t stream) 
     const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) &&
                      (((uintptr_t)g.A & 15) == 0) && (((uintptr_t)g.Bt & 15) == 0);
     const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    if (tiles <= 0 || tiles > 0x7fffffff || g.M > 0x7fffff00) return hipErrorInvalidValue;
+    if (tiles <= 0 || tiles > 0x7fffffff || g.M > 0x7fffff00 || g.ktail < 0 || g.ktail > 2)
+        return hipErrorInvalidValue;
     if (vec)
         hipLaunchKernelGGL((gemm_nt_kernel<Epi, true>), dim3((unsigned)tiles), dim3(256), 0, stream,
                            g, epi);

@@ -52,24 +52,15 @@ struct EpiResidual {   // R = g(X, X^): enhance.py:412 / 431 / 450
     }
 };
 
-// NT = odd bins kept out of the GEMMs (0..2, see drnmf_ista_forward): their contribution to
-// G = R W is the rank-NT term sum_i R[row][Fm+i] * W[Fm+i][col], added here.
-template <int NT>
+// Odd bins kept out of the k-tiles (0..2, see drnmf_ista_forward) enter G = R W through
+// gemm::Operands::ktail.
 struct EpiIstaUpdate {   // H <- max(0, -lam1/alph + H + (1/alph) G): enhance.py:412
     float* H;
     int N;
     float neg_lam_over_alph, inv_alph;
-    const float* Rt;     // R + Fm   (row stride ldr)
-    const float* Wtt;    // Wt + Fm  (row stride ldr): Wtt[col * ldr + i] = W[Fm+i][col]
-    int ldr;
-    __device__ f32x2 pre(int64_t row, int col) const {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) t = fmaf(Rt[row * ldr + i], Wtt[(int64_t)col * ldr + i], t);
-        return f32x2{H[row * N + col], t};
-    }
+    __device__ f32x2 pre(int64_t row, int col) const { return f32x2{H[row * N + col], 0.f}; }
     __device__ void operator()(int64_t row, int col, float gacc, f32x2 pv) const {
-        H[row * N + col] = fmaxf(0.f, neg_lam_over_alph + pv[0] + inv_alph * (gacc + pv[1]));
+        H[row * N + col] = fmaxf(0.f, neg_lam_over_alph + pv[0] + inv_alph * gacc);
     }
 };
 
@@ -164,34 +155,13 @@ struct EpiMuUpdate {   // H <- H * dmh / max(dph + sparsity, flr): sparse_nmf_gp
     const float* colsum;   // [N]    (beta == 1: dph = sum_f w + sparsity, dmh = acc)
     int N;
     float sparsity, flr;
+    static constexpr bool EARLY = BC == 1;   // two loaded values per output do not fit early (gemm_nt.h)
     __device__ f32x2 pre(int64_t row, int col) const {
         return f32x2{H[row * N + col], BC == 1 ? colsum[col] : DMH[row * N + col]};
     }
     __device__ void operator()(int64_t row, int col, float acc, f32x2 pv) const {
         if (BC == 1) H[row * N + col] = pv[0] * acc / fmaxf(pv[1] + sparsity, flr);
         else H[row * N + col] = pv[0] * pv[1] / fmaxf(acc + sparsity, flr);
-    }
-};
-
-// beta == 2 inference with the odd bins kept out of the GEMM tiles (see ista_tail_kernel): the
-// rank-NT term sum_i lambda[row][Fm+i] * W[Fm+i][col] completes dph = lambda W.
-template <int NT>
-struct EpiMuUpdateTail {
-    float* H;
-    const float* DMH;      // [n][N]
-    int N;
-    float sparsity, flr;
-    const float* Lt;       // lambda + Fm (row stride ld)
-    const float* Wtt;      // Wt + Fm     (row stride ld)
-    int ld;
-    __device__ f32x2 pre(int64_t row, int col) const {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) t = fmaf(Lt[row * ld + i], Wtt[(int64_t)col * ld + i], t);
-        return f32x2{H[row * N + col] * DMH[row * N + col], t};
-    }
-    __device__ void operator()(int64_t row, int col, float acc, f32x2 pv) const {
-        H[row * N + col] = pv[0] / fmaxf(acc + pv[1] + sparsity, flr);
     }
 };
 
@@ -358,7 +328,7 @@ extern "C" int32_t drnmf_ista_forward(drnmf_handle_t h, int64_t n, int32_t F, in
     const int nt = (F % 16 != 0 && F % 16 <= 2 && F > 16) ? F % 16 : 0;
     const int Fm = F - nt;
     gemm::Operands g1{H, W, n, Fm, N, N, N};                     // X^ = H . W^T  (contract atoms)
-    gemm::Operands g2{R, Wt, n, N, nt ? Fm : Fp4, Fp4, Fp4};     // G  = R . W    (contract bins)
+    gemm::Operands g2{R, Wt, n, N, nt ? Fm : Fp4, Fp4, Fp4, nt};   // G = R . W (contract bins; odd bins: ktail)
     const dim3 tgrid((unsigned)((n + 3) / 4));
     for (int k = 0; k < K; ++k) {
         if (divergence == DRNMF_DIV_ED) {
@@ -375,14 +345,7 @@ extern "C" int32_t drnmf_ista_forward(drnmf_handle_t h, int64_t n, int32_t F, in
                                        stream, X, W, H, R, n, F, N, Fm, nt, Fp4, beta);
         }
         const float c0 = -lam1 / alph, c1 = 1.f / alph;
-        if (nt == 0)
-            DRNMF_HIP(h, gemm::launch(g2, EpiIstaUpdate<0>{H, N, c0, c1, R, Wt, Fp4}, stream));
-        else if (nt == 1)
-            DRNMF_HIP(h, gemm::launch(g2, EpiIstaUpdate<1>{H, N, c0, c1, R + Fm, Wt + Fm, Fp4},
-                                      stream));
-        else
-            DRNMF_HIP(h, gemm::launch(g2, EpiIstaUpdate<2>{H, N, c0, c1, R + Fm, Wt + Fm, Fp4},
-                                      stream));
+        DRNMF_HIP(h, gemm::launch(g2, EpiIstaUpdate{H, N, c0, c1}, stream));
     }
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
@@ -474,15 +437,9 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
             gemm::Operands gd{P2, Wt, n, N, Fp4, Fp4, Fp4};
             DRNMF_HIP(h, gemm::launch(gd, EpiStore{DMH, N}, stream));
         }
-        gemm::Operands gu{P1, Wt, n, N, nt ? Fm : Fp4, Fp4, Fp4};
+        gemm::Operands gu{P1, Wt, n, N, nt ? Fm : Fp4, Fp4, Fp4, nt};   // odd bins: ktail
         if (beta == 1.f)
             DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<1>{H, DMH, colsum, N, sparsity, flr}, stream));
-        else if (nt == 1)
-            DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdateTail<1>{H, DMH, N, sparsity, flr, P1 + Fm,
-                                                             Wt + Fm, Fp4}, stream));
-        else if (nt == 2)
-            DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdateTail<2>{H, DMH, N, sparsity, flr, P1 + Fm,
-                                                             Wt + Fm, Fp4}, stream));
         else
             DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<2>{H, DMH, colsum, N, sparsity, flr}, stream));
         DRNMF_HIP(h, launch_lambda());                  // lambda = max(w*h, flr)  (:228)
