@@ -121,15 +121,32 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
             __builtin_amdgcn_sched_barrier(0);
             const float* As = lds + buf * 2 * BK * BM + kk * BM + wm * 64 + li;
             const float* Bs = lds + buf * 2 * BK * BM + BK * BM + kk * BN + wn * 64 + li;
+            // fragments of step s+1 are read while the 4 MFMAs of step s issue (pinned: one
+            // ds_read2 behind every 2nd MFMA; see gemm_nt.h for what the unpinned schedule cost)
+            float fa0[2], fa1[2], fb0[2], fb1[2];
+            auto fetch = [&](int s) {
+                fa0[s & 1] = As[2 * s * BM];
+                fb0[s & 1] = Bs[2 * s * BN];
+                fa1[s & 1] = As[2 * s * BM + 32];
+                fb1[s & 1] = Bs[2 * s * BN + 32];
+            };
+            fetch(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const float a0 = As[2 * s * BM], a1 = As[2 * s * BM + 32];
-                const float b0 = Bs[2 * s * BN], b1 = Bs[2 * s * BN + 32];
+                if (s < 15) fetch(s + 1);
+                const float a0 = fa0[s & 1], a1 = fa1[s & 1], b0 = fb0[s & 1], b1 = fb1[s & 1];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < 30; ++i) {   // (the four dword reads of a step pair up as two ds_read2_b32)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < kt1) swrite(buf ^ 1, kt + 1);
             __syncthreads();
