@@ -491,6 +491,11 @@ dlogd_kernel(const float* __restrict__ P, const float* __restrict__ Dn, float* _
 }
 
 // per-atom sums over all frames of layer k: Sb = sum dz, Sgi = sum dz * (h_k - base) (= ia * sum dz G)
+// and, for F = 16 j + 1 (the 2^k + 1 STFT sizes), the ODD BIN's row of the two weight-gradient
+// products -- S1 = sum_t r_k[t][Fm] dz_k[t][n], S2 = sum_t d r_k[t][Fm] h_{k-1}[t][n] -- which would
+// otherwise cost the TN GEMMs a fifth, 1/128-full row of output tiles (M = 528: 5 x 128).  dz and
+// h_{k-1} are streamed here anyway.
+constexpr int CR_SLOTS = 4;
 struct ColRedArgs {
     const float* hall;
     const float* dz_all;
@@ -498,9 +503,11 @@ struct ColRedArgs {
     const float* psum_all;   // [T][Bp]
     const unsigned char* seen;
     const float* log_h0;
-    float* part;             // [CR_SPLITS][2][Np]
+    float* part;             // [CR_SPLITS][CR_SLOTS][Np]
+    const float* rt;         // r_k[.][Fm]  (row stride ldr) or nullptr: no odd-bin row
+    const float* drt;        // d r_k[.][Fm] (row stride ldr), k >= 1
     float u0d, u0o, uko;
-    int k, B, T, N, K, Bp, Np;
+    int k, B, T, N, K, Bp, Np, ldr;
 };
 __global__ void __launch_bounds__(256) colreduce_kernel(const ColRedArgs a) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -518,27 +525,36 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const ColRedArgs a) {
         const float z = a.log_h0[n];
         h0v = (z > 20.f) ? z : log1pf(expf(z));
     }
-    float sb = 0.f, sg = 0.f;
+    const bool tail = a.rt != nullptr, tail2 = tail && a.k >= 1;
+    float sb = 0.f, sg = 0.f, s1 = 0.f, s2 = 0.f;
     int b = (int)(r0 / a.T), t = (int)(r0 % a.T) - 1;
     // dz is sparse (it inherits the zeros of h): its loads decide everything else, so eight of
     // them are in flight at a time (one dependent load per row made this kernel latency-bound:
     // 1.7 ms per layer at the C2 shape)
     constexpr int U = 8;
     const float* dzp = a.dz_all + (size_t)a.k * a.N + n;
+    const float* hpp = a.hall + (size_t)(a.k >= 1 ? a.k - 1 : 0) * a.N + n;
     for (int64_t bt0 = r0; bt0 < r1; bt0 += U) {
-        float dzv[U];
+        float dzv[U], hpv[U], rtv[U], drv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t bt = bt0 + u < r1 ? bt0 + u : r1 - 1;
             dzv[u] = dzp[bt * KN];
+            if (tail) rtv[u] = a.rt[bt * a.ldr];
+            if (tail2) {
+                hpv[u] = hpp[bt * KN];
+                drv[u] = a.drt[bt * a.ldr];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t bt = bt0 + u;
             if (bt >= r1) break;
             if (++t == a.T) { t = 0; ++b; }
+            if (tail2) s2 = fmaf(drv[u], hpv[u], s2);
             const float dz = dzv[u];
             if (dz == 0.f) continue;
+            if (tail) s1 = fmaf(rtv[u], dz, s1);
             const float ps = a.psum_all[(size_t)t * a.Bp + b];
             const float hk = a.hall[bt * KN + (size_t)a.k * a.N + n];
             float base;
@@ -547,29 +563,43 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const ColRedArgs a) {
                                     ? a.hall[(bt - 1) * KN + (size_t)(a.K - 1) * a.N + n] : h0v;
                 base = a.u0d * p + a.u0o * (ps - p) + bk;
             } else {
-                base = a.hall[bt * KN + (size_t)(a.k - 1) * a.N + n] + bk + a.uko * ps;
+                base = (tail2 ? hpv[u] : a.hall[bt * KN + (size_t)(a.k - 1) * a.N + n]) + bk +
+                       a.uko * ps;
             }
             sb += dz;
             sg = fmaf(dz, hk - base, sg);
         }
     }
-    a.part[((size_t)sp * 2 + 0) * a.Np + n] = sb;
-    a.part[((size_t)sp * 2 + 1) * a.Np + n] = sg;
+    float* o = a.part + (size_t)sp * CR_SLOTS * a.Np + n;
+    o[0] = sb;
+    o[(size_t)a.Np] = sg;
+    o[(size_t)2 * a.Np] = s1;
+    o[(size_t)3 * a.Np] = s2;
 }
 
 // stage 1 of the scalar gradients: the CR_SPLITS partial sums of every atom, added in split order
-// (one thread per atom; slot 0 of `part` receives the totals)
+// (one thread per atom; slot 0 of `part` receives the totals).  With an odd-bin row (Ptail != null)
+// its gradient ia[n] S1[n] - S2[n] goes where the GEMM partials of that row would have been: split 0
+// of P, zeros in the other splits (dlogd_kernel adds the splits up).
 __global__ void __launch_bounds__(256)
-colreduce_fold_kernel(float* __restrict__ part, int N, int Np) {
+colreduce_fold_kernel(float* __restrict__ part, int N, int Np, float* __restrict__ Ptail,
+                      const float* __restrict__ ia, int splits, size_t pstride) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
-    float sb = 0.f, sg = 0.f;
+    float sb = 0.f, sg = 0.f, s1 = 0.f, s2 = 0.f;
     for (int s = 0; s < CR_SPLITS; ++s) {
-        sb += part[((size_t)s * 2 + 0) * Np + n];
-        sg += part[((size_t)s * 2 + 1) * Np + n];
+        const float* p = part + (size_t)s * CR_SLOTS * Np + n;
+        sb += p[0];
+        sg += p[(size_t)Np];
+        s1 += p[(size_t)2 * Np];
+        s2 += p[(size_t)3 * Np];
     }
     part[n] = sb;
     part[(size_t)Np + n] = sg;
+    if (Ptail) {
+        Ptail[n] = ia[n] * s1 - s2;
+        for (int s = 1; s < splits; ++s) Ptail[s * pstride + n] = 0.f;
+    }
 }
 
 // d log_alph / d log_lam1 of layer k from the per-atom sums: ia = exp(-log_alph), b = -lam * ia
@@ -641,7 +671,7 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     L.off_dn = take((size_t)W.Fp * W.Np * 4);
     L.off_dnia = take(W.gram ? (size_t)W.Fp * W.Np * 4 : 0);
     L.off_P = take((size_t)TN_SPLITS * W.Fp * W.Np * 4);
-    L.off_cr = take((size_t)CR_SPLITS * 2 * W.Np * 4);
+    L.off_cr = take((size_t)CR_SPLITS * CR_SLOTS * W.Np * 4);
     L.off_dq = take((size_t)2 * MAX_TAIL * W.Bp * W.numA * 4);
     L.off_dqsum = take((size_t)MAX_TAIL * W.Bp * 4);
     L.total = o;
@@ -920,9 +950,13 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
             DRNMF_HIP(h, gemm::launch(g1, EpiResid{x, Rk, F, W.Fp}, stream));
             Aop = Rk;
         }
-        // M = Fp: the padded bins of R / X / dR are zero, and whole 4-column groups keep the loads vectorised
-        gemm_tn::Operands t1{Aop, dz_all + (size_t)k * N, BT, W.Fp, N, W.Fp, KN};
-        const int nsplit = tn_splits(W.Fp, N, BT);
+        // M = Fp: the padded bins of R / X / dR are zero, and whole 4-column groups keep the loads
+        // vectorised.  F = 16 j + 1: M = F - 1, the odd bin's row comes from colreduce_kernel.
+        const bool odd = (F % 16 == 1) && F > 16;
+        const int Mg = odd ? F - 1 : W.Fp;
+        gemm_tn::Operands t1{Aop, dz_all + (size_t)k * N, BT, Mg, N, W.Fp, KN};
+        const int nsplit = tn_splits(Mg, N, BT);
+        const float* dRk_tail = nullptr;
         DRNMF_HIP(h, gemm_tn::launch(t1, EpiP1{P, ia_of(k), W.Np, pstr}, nsplit, stream));
         if (k >= 1) {
             const float* dRk = dR_all + (size_t)k * BT * W.Fp;
@@ -936,14 +970,14 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                 DRNMF_HIP(h, gemm::launch(g2, EpiStore{dR_all, W.Fp}, stream));
                 dRk = dR_all;
             }
-            gemm_tn::Operands t2{dRk, hall + (size_t)(k - 1) * N, BT, W.Fp, N, W.Fp, KN};
+            gemm_tn::Operands t2{dRk, hall + (size_t)(k - 1) * N, BT, Mg, N, W.Fp, KN};
             DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, nsplit, stream));
+            dRk_tail = dRk + (F - 1);
         }
-        const int kd = d->n_D == 1 ? 0 : k;
-        hipLaunchKernelGGL(dlogd_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, P, Dn_rm,
-                           d_log_D + (size_t)kd * F * N, F, N, W.Np, nsplit, pstr,
-                           (d->n_D == 1 && k > 0) ? 1 : 0);
         ColRedArgs ca;
+        ca.rt = odd ? Aop + (F - 1) : nullptr;
+        ca.drt = dRk_tail;
+        ca.ldr = W.Fp;
         ca.hall = hall; ca.dz_all = dz_all; ca.bias = b_of(k); ca.psum_all = psum_all;
         ca.seen = seen; ca.log_h0 = log_h0; ca.part = crp;
         ca.u0d = u0_diag; ca.u0o = u0_off; ca.uko = uk_off;
@@ -952,7 +986,12 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                            ca);
         const int ka = d->n_alph == 1 ? 0 : k, kl = d->n_lam == 1 ? 0 : k;
         hipLaunchKernelGGL(colreduce_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, crp,
-                           N, W.Np);
+                           N, W.Np, odd ? P + (size_t)(F - 1) * W.Np : (float*)nullptr, ia_of(k),
+                           nsplit, pstr);
+        const int kd = d->n_D == 1 ? 0 : k;
+        hipLaunchKernelGGL(dlogd_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, P, Dn_rm,
+                           d_log_D + (size_t)kd * F * N, F, N, W.Np, nsplit, pstr,
+                           (d->n_D == 1 && k > 0) ? 1 : 0);
         hipLaunchKernelGGL(scalar_grads_kernel, dim3(1), dim3(256), 0, stream, crp, b_of(k),
                            d_log_alph + (size_t)ka * d->alph_len, d_log_lam1 + kl, N, W.Np,
                            d->alph_len, (d->n_alph == 1 && k > 0) ? 1 : 0,
