@@ -208,6 +208,45 @@ def dense_cell_forward(x, mask_value, params, desc, h0, out=None, workspace=None
     return out
 
 
+def dense_cell_backward(x, mask_value, desc, U, S, W, b, h0, hall, d_out, workspace=None):
+    """BPTT of the dense step (drnmf_dense_cell_backward): hall [B,T,K*N] is the forward's
+    all-hidden output, d_out the gradient w.r.t. the returned output ([B,T,N], or [B,T,K*N] when
+    desc.return_all_hidden).  Returns dict(dU [K,N,N], dS [K-1,N,N] | None, dW [K,F,N] | None,
+    db [K,N], dh0 [N])."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(x))
+    B, T, F, N, K = desc.B, desc.T, desc.F, desc.N, desc.K
+    x, U, b, h0 = _f32c(x, "x"), _f32c(U, "U"), _f32c(b, "b"), _f32c(h0, "h0")
+    hall, d_out = _f32c(hall, "hall"), _f32c(d_out, "d_out")
+    width = N * (K if desc.return_all_hidden else 1)
+    if tuple(x.shape) != (B, T, F) or tuple(hall.shape) != (B, T, K * N) or \
+            tuple(d_out.shape) != (B, T, width):
+        raise ValueError("x / hall / d_out must have shapes (B,T,F) / (B,T,K*N) / (B,T,%d)" % width)
+    if tuple(U.shape) != (K, N, N) or tuple(b.shape) != (K, N) or h0.numel() != N:
+        raise ValueError("U / b / h0 must have shapes (K,N,N) / (K,N) / (N,)")
+    dev = x.device
+    S = _f32c(S, "S") if K > 1 else None
+    W = _f32c(W, "W") if desc.connect_input else None
+    g = dict(dU=torch.empty((K, N, N), dtype=torch.float32, device=dev),
+             dS=torch.empty((K - 1, N, N), dtype=torch.float32, device=dev) if K > 1 else None,
+             dW=torch.empty((K, F, N), dtype=torch.float32, device=dev) if desc.connect_input
+             else None,
+             db=torch.empty((K, N), dtype=torch.float32, device=dev),
+             dh0=torch.empty((N,), dtype=torch.float32, device=dev))
+    nbytes = L.drnmf_dense_backward_workspace_bytes(C.byref(desc))
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    mv = float("nan") if mask_value is None else float(mask_value)
+    rc = L.drnmf_dense_cell_backward(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(U), _capi.ptr(S),
+                                     _capi.ptr(W), _capi.ptr(b), _capi.ptr(h0), _capi.ptr(hall),
+                                     _capi.ptr(d_out), _capi.ptr(g["dU"]), _capi.ptr(g["dS"]),
+                                     _capi.ptr(g["dW"]), _capi.ptr(g["db"]), _capi.ptr(g["dh0"]),
+                                     _capi.ptr(workspace), workspace.numel(), _stream())
+    _capi.check(rc, h, "drnmf_dense_cell_backward")
+    g["workspace"] = workspace
+    return g
+
+
 def cell_forward_ista(x, mask_value, params, desc, log_h0, beta=1.5, out=None, workspace=None,
                       initial_state=None, final_state=None):
     """KL / beta variant of the cell (desc.divergence = 'kl' | 'beta'): every frame runs K full

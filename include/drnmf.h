@@ -153,7 +153,7 @@ int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t* d, const f
  * once log_U1/log_Uk have been trained away from the rank-structured form that
  * drnmf_cell_forward exploits:
  *     h_k = act(p U_k + [k>0] h_{k-1} S_{k-1} + [connect_input] x_t Wk_k + b_k)
- * Forward only.  One launch per layer-step contracts [p | h_{k-1} | x_t] with the stacked
+ * One launch per layer-step contracts [p | h_{k-1} | x_t] with the stacked
  * [U_k; S_{k-1}; Wk_k] (2*B*(2N+F)*N flops; the factored cell needs 4*B*F*N). */
 enum {
     DRNMF_ACT_LINEAR = 0,
@@ -184,6 +184,24 @@ int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_desc_t* d, 
                                  float mask_value, const void* params, const float* h0,
                                  const float* initial_state, float* final_state, float* h_out,
                                  void* workspace, size_t workspace_bytes, void* stream);
+/* BPTT of the same step: what Theano's autodiff gives the reference for ANY trainable key
+ * (custom_layers.py:216-228; enhance.py:237-248), log_U1 / log_Uk included.  Gradients are with
+ * respect to the matrices the step multiplies by; the chain rule through maps_from_alt stays with
+ * the host (the maps are the caller's callables).
+ *   U, S, W, b: the plain row-major matrices given to drnmf_dense_prepare_params (b is unused)
+ *   hall  [B][T][K*N]: the forward's output with return_all_hidden = 1 (every layer is needed)
+ *   d_out [B][T][K*N or N]: gradient of the loss w.r.t. the layer's returned output (width by
+ *          d->return_all_hidden)
+ *   dU [K][N][N], dS [K-1][N][N] (NULL iff K == 1), dW [K][F][N] (NULL iff !connect_input),
+ *   db [K][N], dh0 [N] (w.r.t. the initial state vector; stateful initial states get no gradient)
+ * 2K launches per frame + 3K time-batched products; deterministic. */
+size_t drnmf_dense_backward_workspace_bytes(const drnmf_dense_desc_t* d);
+int32_t drnmf_dense_cell_backward(drnmf_handle_t h, const drnmf_dense_desc_t* d, const float* x,
+                                  float mask_value, const float* U, const float* S,
+                                  const float* W, const float* b, const float* h0,
+                                  const float* hall, const float* d_out, float* dU, float* dS,
+                                  float* dW, float* db, float* dh0, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 
 /* ---- mask head: replaces the H_clean/H_noise slices, TimeDistributed(DenseNonNegW) x2
  * (custom_layers.py:23-29; enhance.py:277-292), the optional 'square' transform

@@ -61,3 +61,45 @@ def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, s
     cnt = (w != 0).to(x.dtype).sum()
     loss = sse / cnt if normalise else sse
     return loss, mask, hs
+
+
+_ACT = {
+    'linear': lambda v: v,
+    'relu': torch.relu,
+    'tanh': torch.tanh,
+    'sigmoid': torch.sigmoid,
+    'softplus': torch.nn.functional.softplus,
+    'hard_sigmoid': lambda v: torch.clamp(0.2 * v + 0.5, 0.0, 1.0),
+}
+
+
+def dense_cell(x, Uk, Sk, Wk, bk, h0, mask_value=-1.0, return_all_hidden=False,
+               connect_input=True, activation='relu'):
+    """torch twin of oracle.cell_forward_dense (custom_layers.py:343-375 under K.rnn's masked scan),
+    for reference gradients w.r.t. the step's matrices.  Uk [K,N,N], Sk [K-1,N,N], Wk [K,F,N],
+    bk [K,N], h0 [N] = the initial state itself."""
+    B, T, F = x.shape
+    K, N = Uk.shape[0], Uk.shape[1]
+    act = _ACT[activation]
+    valid = (x != mask_value).any(-1)
+    xm = x * valid[..., None].to(x.dtype)
+    width = K * N if return_all_hidden else N
+    state = h0[None, :].expand(B, N)
+    out_prev = torch.zeros(B, width, dtype=x.dtype)
+    outs = []
+    for t in range(T):
+        p = state
+        hidden = []
+        for k in range(K):
+            pre = p @ Uk[k]
+            if k > 0:
+                pre = pre + hidden[k - 1] @ Sk[k - 1]
+            if connect_input:
+                pre = pre + xm[:, t] @ Wk[k]
+            hidden.append(act(pre + bk[k]))
+        out = torch.cat(hidden, 1) if return_all_hidden else hidden[-1]
+        v = valid[:, t][:, None]
+        out_prev = torch.where(v, out, out_prev)
+        state = torch.where(v, hidden[-1], state)
+        outs.append(out_prev)
+    return torch.stack(outs, 1)

@@ -11,7 +11,8 @@ fn_t drnmf_all_exports[] = {
     REF(drnmf_params_bytes), REF(drnmf_prepare_params), REF(drnmf_cell_workspace_bytes),
     REF(drnmf_cell_forward), REF(drnmf_cell_forward_stateful), REF(drnmf_cell_forward_ista),
     REF(drnmf_cell_profile), REF(drnmf_dense_params_bytes), REF(drnmf_dense_prepare_params),
-    REF(drnmf_dense_workspace_bytes), REF(drnmf_dense_cell_forward), REF(drnmf_padded_f),
+    REF(drnmf_dense_workspace_bytes), REF(drnmf_dense_cell_forward),
+    REF(drnmf_dense_backward_workspace_bytes), REF(drnmf_dense_cell_backward), REF(drnmf_padded_f),
     REF(drnmf_head_forward), REF(drnmf_loss_head_workspace_bytes), REF(drnmf_loss_head_backward),
     REF(drnmf_snmf_cost_head_backward), REF(drnmf_cell_backward_workspace_bytes),
     REF(drnmf_cell_backward), REF(drnmf_adam_step), REF(drnmf_sumsq),

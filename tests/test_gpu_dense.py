@@ -234,3 +234,78 @@ def test_small_elementwise_kernels(dev):
         mx = np.max(np.abs(sig))
         want = np.int16((sig / mx if mx > 1 else sig) * np.float32(32767.0))
         assert q.dtype == np.int16 and np.max(np.abs(q.astype(int) - want.astype(int))) <= 1
+
+
+# ---- BPTT of the dense step (csrc/cell_dense_bwd.hip) vs torch fp64 autograd of the same op graph ----
+G_TOL = 2e-4      # max|dg| / max|g| per gradient, fp32 kernels vs fp64 autograd
+
+
+def _ragged_x(rng, B, T, F, mask_value=-1.0):
+    X = np.abs(rng.standard_normal((B, T, F))).astype(np.float32)
+    lens = rng.integers(max(1, T // 2), T + 1, size=B)
+    lens[0] = T
+    for b in range(B):
+        X[b, lens[b]:] = mask_value
+    if B > 1 and T > 3:
+        X[1, 1] = mask_value          # a masked frame in the middle: state and output pass through
+        X[B - 1, 0] = mask_value      # a masked FIRST frame: output zeros, state h0
+    return X
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, T=5, F=21, N=12, K=1),
+    dict(B=4, T=6, F=20, N=16, K=3),
+    dict(B=5, T=7, F=33, N=40, K=3, all_hidden=True),
+    dict(B=2, T=4, F=16, N=24, K=2, connect=False),
+    dict(B=3, T=5, F=12, N=20, K=2, activation="tanh"),
+    dict(B=3, T=5, F=12, N=20, K=2, activation="softplus", all_hidden=True),
+    dict(B=3, T=4, F=12, N=8, K=2, activation="sigmoid"),
+    dict(B=18, T=3, F=40, N=36, K=2),
+])
+def test_dense_backward_matches_autograd(dev, cfg):
+    from drnmf_amd import ops
+    from oracle import drnmf_torch_ref as R
+    B, T, F, N, K = cfg["B"], cfg["T"], cfg["F"], cfg["N"], cfg["K"]
+    act, connect = cfg.get("activation", "relu"), cfg.get("connect", True)
+    all_hidden = cfg.get("all_hidden", False)
+    rng = np.random.default_rng(100 + B + 7 * T + N)
+    U, S, W, b = _random_mats(rng, K, N, F)
+    h0 = np.abs(rng.standard_normal(N)).astype(np.float32) * 0.3
+    X = _ragged_x(rng, B, T, F)
+    width = K * N if all_hidden else N
+    Rw = rng.standard_normal((B, T, width)).astype(np.float32)     # loss = sum(out * Rw)
+
+    # reference gradients
+    td = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    tU, tS, tW, tb, th0 = td(U), td(S), td(W), td(b), td(h0)
+    out = R.dense_cell(torch.tensor(X.astype(np.float64)), tU, tS, tW, tb, th0,
+                       return_all_hidden=all_hidden, connect_input=connect, activation=act)
+    (out * torch.tensor(Rw.astype(np.float64))).sum().backward()
+
+    # device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    dfw = ops.make_dense_desc(B, T, F, N, K, connect, act, True)
+    params = ops.dense_prepare_params(dfw, t(U), t(S) if K > 1 else None, t(W) if connect else None,
+                                      t(b))
+    hall = ops.dense_cell_forward(t(X), -1.0, params, dfw, t(h0))
+    ref_all = R.dense_cell(torch.tensor(X.astype(np.float64)), tU, tS, tW, tb, th0,
+                           return_all_hidden=True, connect_input=connect,
+                           activation=act).detach().numpy()
+    _check(hall.cpu().numpy(), ref_all)
+    dbw = ops.make_dense_desc(B, T, F, N, K, connect, act, all_hidden)
+    g = ops.dense_cell_backward(t(X), -1.0, dbw, t(U), t(S) if K > 1 else None,
+                                t(W) if connect else None, t(b), t(h0), hall, t(Rw))
+    torch.cuda.synchronize()
+
+    def cmp(name, got, ref):
+        ref = ref.numpy()
+        scale = max(np.max(np.abs(ref)), 1e-30)
+        err = np.max(np.abs(got.cpu().numpy() - ref)) / scale
+        assert err <= G_TOL, "%s: max|dg|/max|g| = %.3e" % (name, err)
+    cmp("dU", g["dU"], tU.grad)
+    if K > 1:
+        cmp("dS", g["dS"], tS.grad)
+    if connect:
+        cmp("dW", g["dW"], tW.grad)
+    cmp("db", g["db"], tb.grad)
+    cmp("dh0", g["dh0"], th0.grad)

@@ -266,3 +266,29 @@ def test_warm_ista_cell_is_the_reference_iteration_run_recurrently():
         for t in range(T):
             H = fn(X[:, t].astype(np.float64).T, H)
             np.testing.assert_allclose(hs[:, t], H.T, rtol=1e-10, atol=1e-12)
+
+
+def test_torch_dense_cell_matches_numpy_oracle():
+    """oracle/drnmf_torch_ref.dense_cell (used for reference gradients of the dense step) computes
+    the same forward as oracle.cell_forward_dense, masked frames and all."""
+    import torch
+    from oracle import drnmf_torch_ref as R
+    rng = np.random.default_rng(5)
+    B, T, F, N, K = 3, 6, 9, 7, 3
+    U = rng.standard_normal((K, N, N)) * 0.3
+    S = rng.standard_normal((K - 1, N, N)) * 0.3
+    W = rng.standard_normal((K, F, N)) * 0.3
+    b = rng.standard_normal((K, N)) * 0.1
+    h0 = np.abs(rng.standard_normal(N))
+    X = np.abs(rng.standard_normal((B, T, F)))
+    X[0, 4:] = -1.0
+    X[1, 0] = -1.0
+    X[2, 2] = -1.0
+    for act in ("relu", "tanh", "softplus"):
+        for ah in (False, True):
+            ref = O.cell_forward_dense(X, list(W), list(U), list(b), list(S), None, h0=h0,
+                                       return_all_hidden=ah, activation=act)
+            got = R.dense_cell(torch.tensor(X), torch.tensor(U), torch.tensor(S), torch.tensor(W),
+                               torch.tensor(b), torch.tensor(h0), return_all_hidden=ah,
+                               activation=act).numpy()
+            assert np.max(np.abs(got - ref)) < 1e-12
