@@ -9,8 +9,12 @@ Same names, constructor arguments and protocol as the reference (custom_layers.p
 Weights live in torch tensors on the GPU (containers only); every forward goes through the
 hand-written HIP kernels in libdrnmf.so: the fused factored kernels for the configuration
 build_unfolded_snmf constructs, the general dense-matrix kernel (SimpleDeepRNN.step as written) for
-every other configuration of the layer.  There is no CPU/oracle fallback: what the kernels do not
-cover (training outside the build_alt configuration) raises NotImplementedError.
+every other configuration of the layer.  Training likewise: the fused BPTT for the shipped
+trainable set (log_D, log_alph, log_lam1, log_h0), the dense-matrix BPTT (csrc/cell_dense_bwd.hip)
+for everything else the reference can train -- log_U1 / log_Uk, caller maps, free weights, other
+activations -- with torch autograd carrying the matrix gradients through the caller's maps.  There
+is no CPU/oracle fallback: what the kernels do not cover (dropout / regularizers in training, the
+KL / beta extension's BPTT) raises NotImplementedError.
 """
 from collections import OrderedDict
 
@@ -301,7 +305,7 @@ class SimpleDeepRNN(_Layer):
         # The fused factored kernels cover everything the reference's enhance.py constructs
         # (build_alt maps, relu, both flags on).  Any other configuration of the layer -- caller-
         # supplied maps, free W/U/b/S weights, another activation, flags off -- runs the general
-        # dense-matrix kernel (csrc/cell_dense.hip: SimpleDeepRNN.step as written), forward only.
+        # dense-matrix kernels (csrc/cell_dense.hip, cell_dense_bwd.hip: SimpleDeepRNN.step as written).
         if activation not in ops.ACTIVATIONS:
             raise ValueError("activation must be one of %s (got %r)" %
                              (sorted(ops.ACTIVATIONS), activation))
@@ -572,15 +576,15 @@ class SimpleDeepRNN(_Layer):
         """Forward that keeps every layer's hidden state: returns hall [B,T,K*N] (the last N
         columns are the layer output) and leaves the workspace ready for `backward`."""
         if self.divergence != 'ed':
-            raise NotImplementedError("the KL / beta variant of the cell is forward only")
-        if self._dense_now or self._train_blockers:
-            raise NotImplementedError(
-                'BPTT exists for the fused build_alt configuration (relu, rank-structured U, no '
-                'dropout/regularizers); this layer %s' %
-                ('uses ' + ', '.join(self._train_blockers) if self._train_blockers
-                 else 'runs on the forward-only dense-matrix kernel'))
+            raise NotImplementedError("the KL / beta variant of the cell (an extension, the "
+                                      "reference has no such network) is forward only")
+        if self._train_blockers:
+            raise NotImplementedError('training with %s is not implemented' %
+                                      ', '.join(self._train_blockers))
         if not self.built:
             self.build(tuple(x.shape))
+        if self._dense_now or getattr(self, '_train_dense', False):
+            return self._forward_train_dense(x, mask_value)
         B, T, F = x.shape
         self.prepare(B, T)
         lab = self.maps_from_alt.labels_per_k
@@ -602,10 +606,97 @@ class SimpleDeepRNN(_Layer):
         return hall
 
     def backward(self, x, hall, d_out, grads=None, profile=None):
-        """Gradients w.r.t. the stacked log-domain parameters (see ops.cell_backward)."""
+        """Gradients w.r.t. the stacked log-domain parameters (see ops.cell_backward); on the
+        dense-matrix path a dict {'by_name': {weight name: gradient}} (see _backward_dense)."""
+        if self._train_ctx[0] == 'dense':
+            return self._backward_dense(x, hall, d_out)
         desc, key, _ = self._train_ctx
         return ops.cell_backward(x, self._params_block, desc, self.log_h0, self._u, hall, d_out,
                                  self._ws[key], grads=grads, profile=profile)
+
+    # -- training on the dense-matrix path ---------------------------------------------------
+    # Whatever maps_from_alt produce (build_alt's maps with a trainable log_U1 / log_Uk, a caller's
+    # own maps, free W/U/b/S weights, any activation): the device computes the gradients w.r.t.
+    # the matrices of the step (csrc/cell_dense_bwd.hip) and torch autograd carries them through
+    # the maps to the weights -- the maps are the caller's callables, as the reference's are Theano
+    # lambdas differentiated by Theano (custom_layers.py:216-287).
+    def trainable_weight_items(self):
+        """[(name, tensor)] of the layer's trainable weights: log_h0 / h0, the alt parameters in
+        keys_trainable, every free matrix (custom_layers.py:203-287)."""
+        items = [('log_h0', self.log_h0)] if self.flag_nonnegative else [('h0', self.h0)]
+        items += [(k, v) for k, v in self._alt.items() if k in self.keys_trainable]
+        items += list(self._free.items())
+        return items
+
+    def _dense_matrices_torch(self):
+        """Uk/Sk/Wk/bk stacks and the initial state as torch tensors ON THE AUTOGRAD TAPE of fresh
+        leaf copies of the trainable weights; returns (leaves, U, S, W, b, h0)."""
+        K, N, F = self.K_layers, self.output_dim, self.input_dim
+        leaves = OrderedDict((n, t.detach().clone().requires_grad_(True))
+                             for n, t in self.trainable_weight_items())
+        a = OrderedDict((k, leaves.get(k, v)) for k, v in self._alt.items())
+
+        def get(kind, k, free_name):
+            if kind in self.maps_from_alt:
+                m = self.maps_from_alt[kind]
+                m = m[k] if isinstance(m, (list, tuple)) else m
+                v = m(a)
+                if not isinstance(v, torch.Tensor):
+                    v = torch.as_tensor(np.asarray(v, np.float32), device=self.device)
+                return v.to(torch.float32)
+            return leaves[free_name]
+        U = torch.stack([get('U', k, 'U_%d' % k).reshape(N, N) for k in range(K)])
+        b = torch.stack([torch.broadcast_to(get('b', k, 'b_%d' % k).reshape(-1), (N,))
+                         for k in range(K)])
+        S = torch.stack([get('S', k - 1, 'S_%dto%d' % (k - 1, k)).reshape(N, N)
+                         for k in range(1, K)]) if K > 1 else None
+        W = torch.stack([get('W', k, 'W_%d' % k).reshape(F, N) for k in range(K)]) \
+            if self.flag_connect_input_to_layers else None
+        h0 = torch.nn.functional.softplus(leaves['log_h0'], threshold=20.0) \
+            if self.flag_nonnegative else leaves['h0']
+        return leaves, U, S, W, b, h0
+
+    def _forward_train_dense(self, x, mask_value):
+        if self.stateful:
+            raise NotImplementedError('training a stateful layer is not implemented')
+        B, T, F = x.shape
+        leaves, U, S, W, b, h0 = self._dense_matrices_torch()
+        desc = ops.make_dense_desc(B, T, F, self.output_dim, self.K_layers,
+                                   self.flag_connect_input_to_layers, self.activation, True)
+        c = lambda v: None if v is None else v.detach().contiguous()
+        block = ops.dense_prepare_params(desc, c(U), c(S), c(W), c(b),
+                                         out=getattr(self, '_dense_train_block', None))
+        self._dense_train_block = block
+        key = ('dense', B, T)
+        if key not in self._ws:
+            self._ws.clear()
+            self._ws[key] = ops.dense_workspace(desc, x.device)
+        hall = ops.dense_cell_forward(x, mask_value, block, desc, c(h0), workspace=self._ws[key])
+        self._train_ctx = ('dense', leaves, (U, S, W, b, h0), mask_value)
+        return hall
+
+    def _backward_dense(self, x, hall, d_out):
+        _, leaves, (U, S, W, b, h0), mask_value = self._train_ctx
+        B, T, F = x.shape
+        N, K = self.output_dim, self.K_layers
+        all_hidden = d_out.shape[-1] == K * N and K > 1
+        desc = ops.make_dense_desc(B, T, F, N, K, self.flag_connect_input_to_layers,
+                                   self.activation, all_hidden)
+        c = lambda v: None if v is None else v.detach().contiguous()
+        g = ops.dense_cell_backward(x, mask_value, desc, c(U), c(S), c(W), c(b), c(h0), hall, d_out,
+                                    workspace=getattr(self, '_dense_bwd_ws', None))
+        self._dense_bwd_ws = g['workspace']
+        outs, grads = [], []
+        for t, gt in ((U, g['dU']), (S, g['dS']), (W, g['dW']), (b, g['db']), (h0, g['dh0'])):
+            if t is not None and t.requires_grad:
+                outs.append(t)
+                grads.append(gt)
+        if outs:
+            torch.autograd.backward(outs, grads)
+        by_name = OrderedDict((n, (l.grad if l.grad is not None else torch.zeros_like(l)))
+                              for n, l in leaves.items())
+        self._train_ctx = ('dense', None, None, None)
+        return {'by_name': by_name}
 
     def grad_slices(self):
         """[(weight name, stacked-gradient key, index)] mapping each alt parameter to its slice
@@ -792,20 +883,30 @@ class UnfoldedSNMFModel(object):
                         b1=float(beta_1), b2=float(beta_2), eps=float(epsilon), iterations=0)
         cell = self.cell
         if cell.divergence != 'ed':
-            raise NotImplementedError('the KL / beta variant of the cell is forward only')
-        if cell._generic:
-            raise NotImplementedError('training exists for the build_alt configuration of the cell '
-                                      '(enhance.py:257-266); this one runs on the forward-only '
-                                      'dense-matrix kernel')
-        covered = set(w for w, _, _ in cell.grad_slices())
-        missing = [k for k in cell._alt if k in cell.keys_trainable and k not in covered]
-        if missing:
-            # (the reference would train them; leaving their gradient at zero would be silent)
-            raise NotImplementedError('no gradient is implemented for %s: the BPTT kernels cover '
-                                      'log_D, log_alph, log_lam1 and log_h0 (the shipped '
-                                      'params_trainable is [log_D, log_alph])' % missing)
-        self._train_items = [('log_h0', cell.log_h0)]
-        self._train_items += [(k, cell._alt[k]) for k in cell._alt if k in cell.keys_trainable]
+            raise NotImplementedError('the KL / beta variant of the cell (an extension; the '
+                                      'reference has no such network) is forward only')
+        if cell._train_blockers:
+            raise NotImplementedError('training with %s is not implemented' %
+                                      ', '.join(cell._train_blockers))
+        # The fused BPTT (csrc/cell_backward.hip) covers log_D, log_alph, log_lam1 and log_h0 of the
+        # build_alt configuration -- the shipped params_trainable is [log_D, log_alph].  Any other
+        # trainable key (log_U1 / log_Uk: U leaves its rank structure with the first update), a
+        # trained dense U, caller maps or free weights train on the dense-matrix path.
+        cell._train_dense = False
+        if cell._generic or cell._dense_now:
+            cell._train_dense = True
+        else:
+            covered = set(w for w, _, _ in cell.grad_slices())
+            if any(k in cell.keys_trainable and k not in covered for k in cell._alt):
+                cell._train_dense = True
+        if cell._train_dense:
+            if cell.operand_dtype != 'float32':
+                raise NotImplementedError("operand_dtype='float16' trains on the fused path only")
+            self._train_items = cell.trainable_weight_items()
+        else:
+            self._train_items = [('log_h0', cell.log_h0)]
+            self._train_items += [(k, cell._alt[k]) for k in cell._alt
+                                  if k in cell.keys_trainable]
         self._train_items += [('kernel_clean', self.clean.kernel), ('kernel_noise', self.noise.kernel)]
         self._opt_state = {n: (torch.zeros_like(t), torch.zeros_like(t))
                            for n, t in self._train_items}
@@ -865,10 +966,14 @@ class UnfoldedSNMFModel(object):
         mark('cell_backward', 1)
         self._flat.zero_()
         gv = self._gview
-        gv['log_h0'].copy_(g['d_log_h0'])
-        for wname, gkey, idx in cell.grad_slices():
-            if wname in gv:
-                gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
+        if 'by_name' in g:                          # dense-matrix path: gradients per weight name
+            for wname, gw in g['by_name'].items():
+                gv[wname].copy_(gw.reshape(gv[wname].shape))
+        else:
+            gv['log_h0'].copy_(g['d_log_h0'])
+            for wname, gkey, idx in cell.grad_slices():
+                if wname in gv:
+                    gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
         gv['kernel_clean'].copy_(dkc)
         gv['kernel_noise'].copy_(dkn)
         self._set_scalars(sums, x)
@@ -907,6 +1012,11 @@ class UnfoldedSNMFModel(object):
         # from log_U1 / log_Uk, which compile() refuses to train: re-deriving them here would cost
         # two N x N device-to-host copies and a host pass per step
         self.cell._params_block_valid = False
+        if getattr(self.cell, '_train_dense', False):
+            # the matrices have moved: inference runs on the dense kernel from now on (no host
+            # round trip to re-examine U's structure after every step)
+            self.cell._dense_now = True
+            self.cell._dense_block_valid = False
         return sse * scale
 
     def train_on_batch(self, x, y, sample_weight=None):
@@ -1087,10 +1197,14 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
         g = cell.backward(x, hall, d_hidden)
         self._flat.zero_()
         gv = self._gview
-        gv['log_h0'].copy_(g['d_log_h0'])
-        for wname, gkey, idx in cell.grad_slices():
-            if wname in gv:
-                gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
+        if 'by_name' in g:                          # dense-matrix path: gradients per weight name
+            for wname, gw in g['by_name'].items():
+                gv[wname].copy_(gw.reshape(gv[wname].shape))
+        else:
+            gv['log_h0'].copy_(g['d_log_h0'])
+            for wname, gkey, idx in cell.grad_slices():
+                if wname in gv:
+                    gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
         gv['kernel_clean'].copy_(dkc)
         gv['kernel_noise'].copy_(dkn)
         self._set_scalars(sums, x)

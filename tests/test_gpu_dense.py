@@ -138,8 +138,6 @@ def test_layer_with_trained_dense_u_matches_reference_graph(dev):
              params_trainable=["log_D", "log_alph", "log_U1", "log_Uk"])
     model = layers.build_unfolded_snmf(p, device=dev)
     cell = model.cell
-    with pytest.raises(NotImplementedError):      # no gradient for log_U1 / log_Uk: loud, not zero
-        model.compile(lr=1e-3)
     x = torch.from_numpy(P["X"]).to(dev)
     h_fused = cell.call(x, mask_value=-1.).cpu().numpy()
     assert not cell._dense_now
@@ -159,8 +157,6 @@ def test_layer_with_trained_dense_u_matches_reference_graph(dev):
     alt = {n[len(cell.name) + 1:]: v for n, v in zip(names[1:], w[1:])}
     Wk, Uk, bk, Sk = O.maps_dense(alt, cell.maps_from_alt.labels_per_k, K, N)
     _check(h, O.cell_forward_dense(P["X"], Wk, Uk, bk, Sk, w[0]))
-    with pytest.raises(NotImplementedError):
-        cell.forward_train(x, mask_value=-1.)
     # the whole model (mask head on top) still predicts
     irm = model.predict_on_batch(P["X"])
     assert irm.shape == (B, T, F) and np.all(np.isfinite(irm))
@@ -309,3 +305,121 @@ def test_dense_backward_matches_autograd(dev, cfg):
         cmp("dW", g["dW"], tW.grad)
     cmp("db", g["db"], tb.grad)
     cmp("dh0", g["dh0"], th0.grad)
+
+
+def test_model_trains_log_u_on_the_dense_path(dev):
+    """params_trainable with log_U1 / log_Uk (the reference lets every alt key train,
+    custom_layers.py:216-228): compile() routes the cell to the dense-matrix BPTT; the gradients of
+    ALL weights equal torch fp64 autograd of the reference's op graph built from maps_dense, and an
+    Adam step moves log_U1 / log_Uk."""
+    from drnmf_amd import layers
+    from oracle import drnmf_torch_ref as R
+    B, T, F, r, K = 4, 6, 21, 6, 3
+    P = O.synth_problem(B, T, F, r, seed=33, ragged=True, density=0.15)
+    N = 2 * r
+    trainable = ["log_D", "log_alph", "log_lam1", "log_U1", "log_Uk"]
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+             params_trainable=trainable)
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.compile(lr=1e-3)
+    cell = model.cell
+    assert cell._train_dense
+    names = [n[len(cell.name) + 1:] for n in cell.weight_names]
+    w0 = dict(zip(names, cell.get_weights()))
+    kc, kn = model.clean.get_weights()[0], model.noise.get_weights()[0]
+    x = torch.from_numpy(P["X"]).to(dev)
+    y = torch.from_numpy(P["Y"] if "Y" in P else P["X"] * 0.5).to(dev)
+    valid = np.any(P["X"] != -1.0, axis=-1).astype(np.float32)
+    wgt = torch.from_numpy(valid).to(dev)
+    flat = model.loss_and_grads(x, y, wgt).clone()
+    torch.cuda.synchronize()
+    got = {n: model._gview[n].cpu().numpy().copy() for n, _ in model._train_items}
+
+    # reference: the dense op graph from the same alt parameters, torch fp64
+    td = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    leaves = {n: td(w0[n]) for n in names}
+    lab = cell.maps_from_alt.labels_per_k
+    eye = torch.eye(N, dtype=torch.float64)
+    Us, Ss, Ws, bs = [], [], [], []
+    for k in range(K):
+        Dn = R.unit_cols(leaves[lab["log_D"][k]])
+        ia = torch.exp(-leaves[lab["log_alph"][k]])
+        lam = torch.exp(leaves[lab["log_lam1"][k]])
+        Us.append(torch.exp(leaves["log_U1" if k == 0 else "log_Uk"]).t())
+        if k > 0:
+            Ss.append((eye - (Dn * ia).t() @ Dn).t())
+        Ws.append(Dn * ia)
+        bs.append(-torch.ones(N, dtype=torch.float64) * lam * ia)
+    h0 = torch.nn.functional.softplus(leaves["log_h0"])
+    xt = torch.tensor(P["X"].astype(np.float64))
+    hs = R.dense_cell(xt, torch.stack(Us), torch.stack(Ss), torch.stack(Ws), torch.stack(bs), h0)
+    tkc, tkn = td(kc), td(kn)
+    A = hs[..., :r] @ torch.exp(tkc)
+    Bn = hs[..., r:] @ torch.exp(tkn)
+    mask = torch.exp(torch.log(1e-7 + A) - torch.log(1e-7 + A + Bn))
+    yt = torch.tensor(y.cpu().numpy().astype(np.float64))
+    mse = ((xt * mask - yt) ** 2).mean(-1)
+    sse = (mse * torch.tensor(valid.astype(np.float64))).sum()
+    sse.backward()
+    assert abs(float(flat[-3]) - float(sse.detach())) <= 1e-4 * abs(float(sse.detach()))
+    for n, g in got.items():
+        ref = {"kernel_clean": tkc, "kernel_noise": tkn}.get(n, leaves.get(n)).grad
+        ref = np.zeros_like(g) if ref is None else ref.numpy().reshape(g.shape)
+        scale = max(np.max(np.abs(ref)), 1e-30)
+        err = np.max(np.abs(g - ref)) / scale
+        assert err <= 5e-4, "%s: max|dg|/max|g| = %.3e" % (n, err)
+    # one optimiser step: log_U1 / log_Uk move, the model keeps predicting (dense kernel now)
+    loss = model.train_on_batch(P["X"], y.cpu().numpy(), valid)
+    assert np.isfinite(loss)
+    w1 = dict(zip(names, cell.get_weights()))
+    assert np.max(np.abs(w1["log_U1"] - w0["log_U1"])) > 0
+    assert np.max(np.abs(w1["log_Uk"] - w0["log_Uk"])) > 0
+    assert cell._dense_now
+    irm = model.predict_on_batch(P["X"])
+    assert np.all(np.isfinite(irm))
+    l2 = [model.train_on_batch(P["X"], y.cpu().numpy(), valid) for _ in range(5)]
+    assert l2[-1] < loss
+
+
+def test_generic_layer_trains_free_weights(dev):
+    """Layer-level training API on a generic configuration (caller maps for W and b, free U / S
+    weights, tanh, h0 weight): forward_train + backward give the gradients of every weight, equal
+    to torch fp64 autograd of the oracle's op graph."""
+    from drnmf_amd import layers
+    from oracle import drnmf_torch_ref as R
+    B, T, F, N, K = 3, 5, 12, 16, 2
+    rng = np.random.default_rng(8)
+    A = (0.2 * rng.standard_normal((F, N))).astype(np.float32)
+    c = (0.1 * rng.standard_normal((N,))).astype(np.float32)
+    maps = {"W": [lambda a: a["A"], lambda a: 0.5 * a["A"]], "b": lambda a: a["c"]}
+    np.random.seed(1)
+    cell = layers.SimpleDeepRNN(N, activation="tanh", K_layers=K, alt_params={"A": A, "c": c},
+                                keys_trainable=["A"], maps_from_alt=maps,
+                                flag_connect_input_to_layers=True, flag_nonnegative=False,
+                                return_sequences=True, device=dev)
+    X = _ragged_x(rng, B, T, F)
+    x = torch.from_numpy(X).to(dev)
+    cell.build(tuple(x.shape))
+    w2 = cell.get_weights()
+    w2[0] = (0.2 * rng.standard_normal(N)).astype(np.float32)        # a non-trivial h0
+    cell.set_weights(w2)
+    names = [n[len(cell.name) + 1:] for n in cell.weight_names]
+    w = dict(zip(names, cell.get_weights()))
+    Rw = rng.standard_normal((B, T, N)).astype(np.float32)
+    hall = cell.forward_train(x, mask_value=-1.)
+    g = cell.backward(x, hall, torch.from_numpy(Rw).to(dev))["by_name"]
+    torch.cuda.synchronize()
+    assert sorted(g) == sorted(["h0", "A", "U_0", "U_1", "S_0to1"])   # c is not in keys_trainable
+
+    td = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    L = {n: td(w[n]) for n in names}
+    out = R.dense_cell(torch.tensor(X.astype(np.float64)), torch.stack([L["U_0"], L["U_1"]]),
+                       torch.stack([L["S_0to1"]]), torch.stack([L["A"], 0.5 * L["A"]]),
+                       torch.stack([L["c"], L["c"]]), L["h0"], activation="tanh")
+    _check(hall[..., (K - 1) * N:].cpu().numpy(), out.detach().numpy())
+    (out * torch.tensor(Rw.astype(np.float64))).sum().backward()
+    for n, gv in g.items():
+        ref = L[n].grad.numpy()
+        err = np.max(np.abs(gv.cpu().numpy() - ref)) / max(np.max(np.abs(ref)), 1e-30)
+        assert err <= G_TOL, "%s: max|dg|/max|g| = %.3e" % (n, err)
