@@ -10,6 +10,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace gemm_tn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -121,46 +123,56 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
         }
     };
 
+    // One k-tile = 16 steps of 4 MFMAs.  Everything else is pinned between them (gemm_nt.h has the
+    // measurements behind this): the fragments of step s+1 (two ds_read2_b32) behind the 1st and
+    // 3rd MFMA of step s; the 8 global loads of the NEXT k-tile in steps 0..3; its 8 LDS writes in
+    // steps 12..15.  STAGE = false: the last k-tile of the split.
+    auto ktile = [&](int buf, auto stage_tag, int64_t kt_next) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        const float* As = lds + buf * 2 * BK * BM + kk * BM + wm * 64 + li;
+        const float* Bs = lds + buf * 2 * BK * BM + BK * BM + kk * BN + wn * 64 + li;
+        float fa0[2], fa1[2], fb0[2], fb1[2];
+        auto fetch = [&](int s) {
+            fa0[s & 1] = As[2 * s * BM];
+            fa1[s & 1] = As[2 * s * BM + 32];
+            fb0[s & 1] = Bs[2 * s * BN];
+            fb1[s & 1] = Bs[2 * s * BN + 32];
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAGE) gload(kt_next);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s < 15) fetch(s + 1);
+            const float a0 = fa0[s & 1], a1 = fa1[s & 1], b0 = fb0[s & 1], b1 = fb1[s & 1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (STAGE) swrite(buf ^ 1, kt_next);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (s < 15) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ds_read2 of step s+1
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (STAGE && s < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // global load
+                if (STAGE && s >= 12) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // LDS write
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     if (kt0 < kt1) {
         gload(kt0);
         swrite(0, kt0);
         __syncthreads();
-        for (int64_t kt = kt0; kt < kt1; ++kt) {
-            const int buf = (int)((kt - kt0) & 1);
-            if (kt + 1 < kt1) gload(kt + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const float* As = lds + buf * 2 * BK * BM + kk * BM + wm * 64 + li;
-            const float* Bs = lds + buf * 2 * BK * BM + BK * BM + kk * BN + wn * 64 + li;
-            // fragments of step s+1 are read while the 4 MFMAs of step s issue (pinned: one
-            // ds_read2 behind every 2nd MFMA; see gemm_nt.h for what the unpinned schedule cost)
-            float fa0[2], fa1[2], fb0[2], fb1[2];
-            auto fetch = [&](int s) {
-                fa0[s & 1] = As[2 * s * BM];
-                fb0[s & 1] = Bs[2 * s * BN];
-                fa1[s & 1] = As[2 * s * BM + 32];
-                fb1[s & 1] = Bs[2 * s * BN + 32];
-            };
-            fetch(0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (s < 15) fetch(s + 1);
-                const float a0 = fa0[s & 1], a1 = fa1[s & 1], b0 = fb0[s & 1], b1 = fb1[s & 1];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 30; ++i) {   // (the four dword reads of a step pair up as two ds_read2_b32)
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < kt1) swrite(buf ^ 1, kt + 1);
+        for (int64_t kt = kt0; kt + 1 < kt1; ++kt) {
+            ktile((int)((kt - kt0) & 1), std::true_type{}, kt + 1);
             __syncthreads();
         }
+        ktile((int)((kt1 - 1 - kt0) & 1), std::false_type{}, 0);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
