@@ -361,8 +361,14 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     for (int e = 0; e < 2; ++e) {
         const float dh = dzk[e] - gsum[e];
         dzn[e] = hprev[e] > 0.f ? dh : 0.f;
-        if (rg < a.B && n + e < a.N)
-            a.dz_all[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n + e] = dzn[e];
+    }
+    if (rg < a.B) {     // one 8-byte store where the pair is whole and aligned (n is even)
+        float* dzo = a.dz_all + ((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n;
+        if (n + 1 < a.N && (a.N & 1) == 0) *(f32x2*)dzo = dzn;
+        else {
+            if (n < a.N) dzo[0] = dzn[0];
+            if (n + 1 < a.N) dzo[1] = dzn[1];
+        }
     }
     *(f32x2*)(a.dzp_out + hoff) = dzn;
     f32x2 dG = {dzn[0] * ia[0], dzn[1] * ia[1]};

@@ -142,6 +142,27 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     const f16* arow16 = (const f16*)rsrc + (size_t)mb0 * (Fp / 32) * 512 + l * 8;
     const size_t astep16 = (size_t)(Fp / 32) * 512;
 
+    // training: the summed residual of this row tile also goes out row-major for the BPTT's weight
+    // gradients (Rsave).  Every workgroup of the row tile holds all of it; chunk c is stored by atom
+    // block c mod numA, by the wave that owns it.  Its (re-)load is issued HERE, ahead of the
+    // operand stream, and the store follows the MFMA loop: by then the data is there (in-order return)
+    // and the stores drain under the reduction and the epilogue.
+#ifdef DRNMF_EXP_NORSAVE
+    constexpr bool RSAVE = false;
+#else
+    constexpr bool RSAVE = ALL_HIDDEN && !IS_FIRST && !HALF;
+#endif
+    const bool rs_mine = RSAVE && a.Rsave != nullptr && live && ab < a.nchunks &&
+                         (ab & (NW_A - 1)) == w;
+    f32x4 rsv[RSAVE ? RB : 1][RSAVE ? KS : 1];
+    if (RSAVE && rs_mine) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                rsv[rb][ks] = *(const f32x4*)(arow + rb * astep + 256 * ab + (size_t)ks * pstride);
+    }
+
     // ---- GEMM operands first (critical path), wave w takes chunks c = w (mod 4) -------------
     // Loads are branch-free (out-of-range chunks are clamped to the last chunk and their A
     // operand zeroed) so that the compiler can retire them with counted vmcnt waits and the
@@ -408,25 +429,19 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
         if (exact) last_group(base);
     }
 
-    // training: the summed residual of this row tile goes out row-major for the BPTT's weight
-    // gradients.  Every workgroup of the row tile holds all of it; chunk c is stored by atom block
-    // c mod numA, by the wave that owns it (re-read: cache hits), outside the MFMA loop -- as
-    // bwd_a_kernel does for d r (cell_backward.hip)
-    if (ALL_HIDDEN && !IS_FIRST && !HALF && a.Rsave != nullptr && live) {
-        for (int c = ab; c < a.nchunks; c += a.numA) {
-            if ((c & (NW_A - 1)) != w) continue;
+    // (Rsave: the data arrived long ago -- the loads are older than every operand load the MFMA loop
+    // waited for -- and the stores drain under the reduction and the epilogue)
+    if (RSAVE && rs_mine) {
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const float* src = arow + rb * astep + 256 * c;
-                f32x4 r4 = *(const f32x4*)src;
+        for (int rb = 0; rb < RB; ++rb) {
+            f32x4 r4 = rsv[rb][0];
 #pragma unroll
-                for (int ks = 1; ks < KS; ++ks) r4 += *(const f32x4*)(src + (size_t)ks * pstride);
-                const int row = (mb0 + rb) * ROWS + j;
-                if (row < a.B) {
-                    float* dst = a.Rsave + ((size_t)row * a.T + t) * Fp + 16 * c + q;
+            for (int ks = 1; ks < KS; ++ks) r4 += rsv[rb][ks];
+            const int row = (mb0 + rb) * ROWS + j;
+            if (row < a.B) {
+                float* dst = a.Rsave + ((size_t)row * a.T + t) * Fp + 16 * ab + q;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) dst[4 * s] = r4[s];
-                }
+                for (int s = 0; s < 4; ++s) dst[4 * s] = r4[s];
             }
         }
     }
@@ -494,16 +509,24 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
         }
 
         const bool row_live = live && rg < a.B;
+#ifdef DRNMF_EXP_NOOUT
+        if (WRITE_OUT && row_live && IS_LAST) {
+#else
         if (WRITE_OUT && row_live) {
+#endif
             // K.rnn masking: a masked step repeats the previous output (zeros before the first
             // valid step)
             float* orow = a.out + ((size_t)rg * a.T + t) * a.out_width + a.out_off;
+            if (vld[rb] && n + 1 < a.N && ((a.N | a.out_width | a.out_off) & 1) == 0) {
+                *(f32x2*)(orow + n) = hn;       // one 8-byte store (n is even): the usual case
+            } else {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (n + e < a.N) {
-                    float o = hn[e];
-                    if (!vld[rb]) o = (t > 0) ? orow[n + e - (ptrdiff_t)a.out_width] : 0.f;
-                    orow[n + e] = o;
+                for (int e = 0; e < 2; ++e) {
+                    if (n + e < a.N) {
+                        float o = hn[e];
+                        if (!vld[rb]) o = (t > 0) ? orow[n + e - (ptrdiff_t)a.out_width] : 0.f;
+                        orow[n + e] = o;
+                    }
                 }
             }
         }
@@ -529,6 +552,26 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 float sq = hn[0] * dtn[i][0] + hn[1] * dtn[i][1];
                 sq = row16_sum(sq);
                 if ((tid & 15) == 0) a.q_out[((size_t)i * a.Bp + rg) * a.numA + ab] = sq;
+            }
+        }
+    }
+    if (RSAVE && a.Rsave != nullptr && live) {
+        // fewer atom blocks than chunks (small dictionaries; those shapes run the Gram form unless
+        // it is switched off): the remaining chunks of this atom block, read here
+        for (int c = ab + a.numA; c < a.nchunks; c += a.numA) {
+            if ((c & (NW_A - 1)) != w) continue;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float* src = arow + rb * astep + 256 * c;
+                f32x4 r4 = *(const f32x4*)src;
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks) r4 += *(const f32x4*)(src + (size_t)ks * pstride);
+                const int row = (mb0 + rb) * ROWS + j;
+                if (row < a.B) {
+                    float* dst = a.Rsave + ((size_t)row * a.T + t) * Fp + 16 * c + q;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dst[4 * s] = r4[s];
+                }
             }
         }
     }
