@@ -227,6 +227,14 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) av[g][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // the d r copy (below): this workgroup's chunk c = ab, requested ahead of the operand stream
+    const bool dr_mine = live && ab < a.nchunks && (ab & 3) == w;
+    f32x4 drv[KS];
+    if (dr_mine) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            drv[ks] = *(const f32x4*)(arow + 256 * ab + (size_t)ks * pstride);
+    }
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(g, g);
     __builtin_amdgcn_sched_barrier(0);   // struct-dependent code stays behind the first operand loads
@@ -308,9 +316,21 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     }
 
     // the d r copy, outside the MFMA loop (a wave-uniform branch inside it costs several %): the
-    // chunks c = ab (mod numA) are re-read (cache hits) and stored by the wave that owns them
+    // chunks c = ab (mod numA) are stored by the wave that owns them.  The first one was requested
+    // before the operand stream (its data is there by now: loads return in order) -- re-read here
+    // its cache-hit latency sat in front of the cross-wave reduction of every launch; further
+    // chunks (fewer atom blocks than chunks: small dictionaries) are re-read.
+    if (dr_mine) {
+        f32x4 r4 = drv[0];
+#pragma unroll
+        for (int ks = 1; ks < KS; ++ks) r4 += drv[ks];
+        if (dr_lane) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dr_row[16 * ab + 4 * s] = r4[s];
+        }
+    }
     if (live) {
-        for (int c = ab; c < a.nchunks; c += a.numA) {
+        for (int c = ab + a.numA; c < a.nchunks; c += a.numA) {
             if ((c & 3) != w) continue;
             f32x4 r4 = *(const f32x4*)(arow + 256 * c);
 #pragma unroll
