@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
         *(f32x2*)(a.dzp_top + hoff) = dz;
         const f32x2 ia = *(const f32x2*)(a.ia_last + n);
         f32x2 dG = {dz[0] * ia[0], dz[1] * ia[1]};
-        *(f32x2*)(a.dGp_top + hoff) = dG;
+        if (a.dGp_top) *(f32x2*)(a.dGp_top + hoff) = dG;   // (Gram chain only, see scale_pack_kernel)
 #pragma unroll
         for (int i = 0; i < MAX_TAIL; ++i) {
             if (i >= a.ntail) continue;
@@ -392,7 +392,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     }
     *(f32x2*)(a.dzp_out + hoff) = dzn;
     f32x2 dG = {dzn[0] * ia[0], dzn[1] * ia[1]};
-    *(f32x2*)(a.dGp_out + hoff) = dG;
+    if (a.dGp_out) *(f32x2*)(a.dGp_out + hoff) = dG;       // (nullptr: cell_b reads dz, scale_pack_kernel)
     if (a.k >= 2) {
 #pragma unroll
         for (int i = 0; i < MAX_TAIL; ++i) {
@@ -431,6 +431,19 @@ void* pick_bwd_a(int nchunks, int KS, bool qred = false) {
         case 4: return bwd_a_func<4>(per_wave, qred);
         default: return bwd_a_func<8>(per_wave, qred);
     }
+}
+
+// The chain's d r_k = (dz_k * ia_k) Dn_k^T needs dz scaled per atom; scaling the dictionary's
+// columns once per step instead lets cell_b contract the packed dz itself, and bwd_a / bwd_edge
+// stop storing a second packed copy (dG) of every layer-step: out = Dp with column n times ia[n],
+// same packing (block (f/16, n/16), element ((n%16)/4 * 16 + f%16) * 4 + n%4).
+__global__ void __launch_bounds__(256)
+scale_pack_kernel(const float* __restrict__ Dp, const float* __restrict__ ia, float* __restrict__ out,
+                  size_t total, int Np) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int n = (int)((p >> 8) % (size_t)(Np / 16)) * 16 + (int)((p & 255) >> 6) * 4 + (int)(p & 3);
+    out[p] = Dp[p] * ia[n];
 }
 
 // ---------------- time-batched phase --------------------------------------------------------------
@@ -482,9 +495,61 @@ struct EpiP2 {      // partial[split] -= acc
     }
 };
 
-// d log_D (+)= Dn * (dDn - Dn * c),  c[n] = sum_f dDn[f][n] Dn[f][n],  dDn = sum of the partials
-// Workgroup = 32 atoms x 8 bin groups (bins f = fg mod 8); the column sums c are combined through
-// LDS in a fixed order (deterministic).
+// d log_D (+)= Dn * (dDn - Dn * c),  c[n] = sum_f dDn[f][n] Dn[f][n],  dDn = sum of the partials.
+// N % 4 == 0: two elementwise passes over (16-bin groups) x (64 atom quads) workgroups, 16-byte
+// accesses -- pass 1 adds the splits up (into split 0) and leaves each bin group's share of c in
+// `cpart`, pass 2 adds the shares in a fixed order and applies.  (The single-kernel form below
+// ran 63 workgroups for a whole layer: 0.4 ms at C2.)
+__global__ void __launch_bounds__(256)
+dlogd_sum_kernel(float* __restrict__ P, const float* __restrict__ Dn, float* __restrict__ cpart,
+                 int F, int N, int Np, int splits, size_t stride) {
+    __shared__ f32x4 cs[4][64];
+    const int qn = threadIdx.x & 63, fl = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + qn) * 4;
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = blockIdx.y * 16 + fl * 4 + i;
+            if (f >= F) break;
+            const size_t o = (size_t)f * Np + n;
+            f32x4 g = *(const f32x4*)(P + o);
+            for (int sidx = 1; sidx < splits; ++sidx) g += *(const f32x4*)(P + sidx * stride + o);
+            *(f32x4*)(P + o) = g;
+            const f32x4 dn = *(const f32x4*)(Dn + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = fmaf(g[e], dn[e], c[e]);
+        }
+    }
+    cs[fl][qn] = c;
+    __syncthreads();
+    if (fl == 0 && n < N)
+        *(f32x4*)(cpart + (size_t)blockIdx.y * Np + n) = (cs[0][qn] + cs[1][qn]) + (cs[2][qn] + cs[3][qn]);
+}
+__global__ void __launch_bounds__(256)
+dlogd_apply_kernel(const float* __restrict__ P, const float* __restrict__ Dn,
+                   const float* __restrict__ cpart, float* __restrict__ dlogD, int F, int N, int Np,
+                   int ngroups, int accumulate) {
+    const int qn = threadIdx.x & 63, fl = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + qn) * 4;
+    if (n >= N) return;
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int gq = 0; gq < ngroups; ++gq) c += *(const f32x4*)(cpart + (size_t)gq * Np + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = blockIdx.y * 16 + fl * 4 + i;
+        if (f >= F) break;
+        const size_t o = (size_t)f * Np + n;
+        const f32x4 g = *(const f32x4*)(P + o), dn = *(const f32x4*)(Dn + o);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dn[e] * (g[e] - dn[e] * c[e]);
+        f32x4* op = (f32x4*)(dlogD + (size_t)f * N + n);
+        *op = accumulate ? *op + v : v;
+    }
+}
+// General N: workgroup = 32 atoms x 8 bin groups (bins f = fg mod 8); the column sums c are combined
+// through LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256)
 dlogd_kernel(const float* __restrict__ P, const float* __restrict__ Dn, float* __restrict__ dlogD,
              int F, int N, int Np, int splits, size_t stride, int accumulate) {
@@ -755,7 +820,7 @@ dlogh0_kernel(const float* __restrict__ dh0_part, const float* __restrict__ log_
 
 struct BwdWs {
     size_t off_dstate, off_gq, off_dzp0, off_dzp1, off_dGp0, off_dGp1, off_drpart, off_z0s, off_dps,
-        off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_dnia, off_P, off_cr, off_dq,
+        off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_dpia, off_dnia, off_P, off_cr, off_dq,
         off_dqsum, total;
 };
 BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
@@ -778,6 +843,7 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     L.off_xpad = take((size_t)BT * W.Fp * 4);
     L.off_R = take((size_t)BT * W.Fp * 4);
     L.off_dn = take((size_t)W.Fp * W.Np * 4);
+    L.off_dpia = take(W.gram ? 0 : (size_t)d->K * W.Fp * W.Np * 4);
     L.off_dnia = take(W.gram ? (size_t)W.Fp * W.Np * 4 : 0);
     L.off_P = take((size_t)TN_SPLITS * W.Fp * W.Np * 4);
     L.off_cr = take((size_t)CR_SPLITS * CR_SLOTS * W.Np * 4);
@@ -874,7 +940,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
 
     EdgeArgs ea;
     ea.hall = hall; ea.d_out = d_out; ea.dz_all = dz_all; ea.ia_last = ia_of(K - 1);
-    ea.dstate = dstate; ea.gq = gq; ea.dzp_top = dzp[(K - 1) & 1]; ea.dGp_top = dGp[(K - 1) & 1];
+    ea.dstate = dstate; ea.gq = gq; ea.dzp_top = dzp[(K - 1) & 1]; ea.dGp_top = W.gram ? dGp[(K - 1) & 1] : nullptr;
     ea.dzp0 = dzp[0]; ea.dz0s_part = z0s; ea.dps_part = dps; ea.dh0_part = dh0_part;
     ea.valid = valid;
     ea.c_rd = (K == 1) ? cA : cB;
@@ -913,10 +979,17 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     // (the fp16-operand forward counts 32-atom chunks; the fp32 kernels of this pass 16-atom ones)
     const int nch_ks_b = half ? W.Np / 16 : W.nch_ks;
     const bool qred = qred_wanted(W.numA, W.ntail, nft, W.KS, W.RB);
+    float* DpIa = (float*)(bw + L.off_dpia);
+    if (!W.gram) {
+        const size_t tot = (size_t)W.Fp * W.Np;
+        for (int k = 1; k < K; ++k)
+            hipLaunchKernelGGL(scale_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                               stream, Dp_of(k), ia_of(k), DpIa + (size_t)k * tot, tot, W.Np);
+    }
     auto make_b = [&](int k) {
         CellBArgs b;
-        b.Dn_next = Dp_of(k);
-        b.h = dGp[k & 1];
+        b.Dn_next = DpIa + (size_t)k * W.Fp * W.Np;    // Dn_k with column n scaled by ia_k[n]
+        b.h = dzp[k & 1];
         b.xp = nullptr;
         b.rpart = drpart;
         b.t_rd = cA;
@@ -935,7 +1008,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         a.drpart = drpart;
         a.dzp_in = dzp[k & 1];
         a.dzp_out = dzp[(k - 1) & 1];
-        a.dGp_out = dGp[(k - 1) & 1];
+        a.dGp_out = nullptr;
         a.hall = hall; a.dz_all = dz_all;
         a.dR = dR_all + (size_t)k * BT * W.Fp;
         a.dz0s_part = z0s; a.dps_part = dps;
@@ -1102,9 +1175,21 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                            N, W.Np, odd ? P + (size_t)(F - 1) * W.Np : (float*)nullptr, ia_of(k),
                            nsplit, pstr);
         const int kd = d->n_D == 1 ? 0 : k;
-        hipLaunchKernelGGL(dlogd_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, P, Dn_rm,
-                           d_log_D + (size_t)kd * F * N, F, N, W.Np, nsplit, pstr,
-                           (d->n_D == 1 && k > 0) ? 1 : 0);
+        if (N % 4 == 0) {
+            // (cpart: the split >= 2 slots of the column-reduction partials, dead after the fold)
+            float* cpart = crp + (size_t)2 * CR_SLOTS * W.Np;
+            const int ngroups = (F + 15) / 16;
+            const dim3 dgrid((N / 4 + 63) / 64, ngroups);
+            hipLaunchKernelGGL(dlogd_sum_kernel, dgrid, dim3(256), 0, stream, P, Dn_rm, cpart, F, N,
+                               W.Np, nsplit, pstr);
+            hipLaunchKernelGGL(dlogd_apply_kernel, dgrid, dim3(256), 0, stream, P, Dn_rm, cpart,
+                               d_log_D + (size_t)kd * F * N, F, N, W.Np, ngroups,
+                               (d->n_D == 1 && k > 0) ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(dlogd_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, P, Dn_rm,
+                               d_log_D + (size_t)kd * F * N, F, N, W.Np, nsplit, pstr,
+                               (d->n_D == 1 && k > 0) ? 1 : 0);
+        }
         hipLaunchKernelGGL(scalar_grads_kernel, dim3(1), dim3(256), 0, stream, crp, b_of(k),
                            d_log_alph + (size_t)ka * d->alph_len, d_log_lam1 + kl, N, W.Np,
                            d->alph_len, (d->n_alph == 1 && k > 0) ? 1 : 0,
