@@ -166,10 +166,13 @@ stft_real_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int
                  int nf, float* __restrict__ mag, float* __restrict__ re, float* __restrict__ im) {
     constexpr int M = (R == 8 ? (P == 3 ? 512 : 64) : (P == 4 ? 256 : 64)), N = 2 * M;
     __shared__ float2 tw[N / 2];              // e^{-2 pi i k / N}, k < N/2
-    // per wave: ping-pong.  Index i lives at i + i/8: the Stockham scatter of the early passes
-    // (stride R, then R*R) would otherwise put 8-16 lanes on one bank
+    // per wave: ONE buffer, rewritten in place by every pass -- a wave executes its LDS reads of a
+    // pass (all 64 lanes, into registers) before that pass's writes are issued, and LDS serves one
+    // wave's requests in order, so the Stockham reorder needs no second buffer (the ping-pong pair
+    // it replaced held the kernel to 3 workgroups per CU; 7 now).  Index i lives at i + i/8: the
+    // scatter of the early passes (stride R, then R*R) would otherwise put 8-16 lanes on one bank
     constexpr int MP = M + M / 8;
-    __shared__ float2 bufs[4][2][MP];
+    __shared__ float2 bufs[4][MP];
     auto pad = [](int i) { return i + (i >> 3); };
     const int tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
     const int frame = blockIdx.x * 4 + wv, sig = blockIdx.y;
@@ -184,6 +187,31 @@ stft_real_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int
     // pass 0 input straight from the signal: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1]), n = j + r M/R
     const int64_t base = (int64_t)frame * hop - N;       // first sample of the frame (N leading zeros)
     float2 v[R];
+    // interior frames (all but the first N/hop and the last few): no bounds tests, one 8-byte load
+    // per sample pair -- this kernel is VALU-issue bound (~1000 instructions per lane and frame),
+    // the 16 64-bit range tests were a tenth of them
+    const size_t e0 = (size_t)sig * nsampl + (size_t)(base > 0 ? base : 0);   // first element
+    const bool interior = base >= 0 && base + N <= nsampl &&
+                          ((((uintptr_t)pcm >> (is_int16 ? 1 : 2)) + e0) & 1) == 0;
+    if (interior && is_int16) {
+        const short* p = (const short*)pcm + e0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = j + r * (M / R);
+            const short2 x2 = *(const short2*)(p + 2 * n);
+            const float2 w2 = *(const float2*)(win + 2 * n);
+            v[r] = make_float2((float)x2.x / 32768.0f * w2.x, (float)x2.y / 32768.0f * w2.y);
+        }
+    } else if (interior) {
+        const float* p = (const float*)pcm + e0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = j + r * (M / R);
+            const float2 x2 = *(const float2*)(p + 2 * n);
+            const float2 w2 = *(const float2*)(win + 2 * n);
+            v[r] = make_float2(x2.x * w2.x, x2.y * w2.y);
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int n = j + r * (M / R);
@@ -201,8 +229,8 @@ stft_real_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int
         const float2 w2 = *(const float2*)(win + 2 * n);
         v[r] = make_float2(x0 * w2.x, x1 * w2.y);
     }
-    float2* cur = bufs[wv][0];
-    float2* nxt = bufs[wv][1];
+    float2* cur = bufs[wv];
+    float2* nxt = bufs[wv];
     int Ns = 1;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -222,7 +250,6 @@ stft_real_kernel(const void* __restrict__ pcm, int is_int16, int64_t nsampl, int
         for (int r = 0; r < R; ++r) nxt[pad(j0 + r * Ns)] = v[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float2* t_ = cur; cur = nxt; nxt = t_;
         Ns *= R;
     }
     // split + output: k = j + 64 i, i < M/64, and k = M
