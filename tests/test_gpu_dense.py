@@ -257,6 +257,9 @@ def _ragged_x(rng, B, T, F, mask_value=-1.0):
     dict(B=3, T=5, F=12, N=20, K=2, activation="softplus", all_hidden=True),
     dict(B=3, T=4, F=12, N=8, K=2, activation="sigmoid"),
     dict(B=18, T=3, F=40, N=36, K=2),
+    dict(B=3, T=4, F=10, N=12, K=2, activation="linear"),
+    dict(B=3, T=4, F=10, N=12, K=3, activation="hard_sigmoid", all_hidden=True),
+    dict(B=2, T=3, F=9, N=10, K=2),                     # N, F not multiples of 4: scalar GEMM paths
 ])
 def test_dense_backward_matches_autograd(dev, cfg):
     from drnmf_amd import ops
