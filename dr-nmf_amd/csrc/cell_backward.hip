@@ -320,6 +320,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     // before the operand stream (its data is there by now: loads return in order) -- re-read here
     // its cache-hit latency sat in front of the cross-wave reduction of every launch; further
     // chunks (fewer atom blocks than chunks: small dictionaries) are re-read.
+#ifndef DRNMF_EXP_NODR
     if (dr_mine) {
         f32x4 r4 = drv[0];
 #pragma unroll
@@ -329,6 +330,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
             for (int s = 0; s < 4; ++s) dr_row[16 * ab + 4 * s] = r4[s];
         }
     }
+#endif
     if (live) {
         for (int c = ab + a.numA; c < a.nchunks; c += a.numA) {
             if ((c & 3) != w) continue;
@@ -382,6 +384,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
         const float dh = dzk[e] - gsum[e];
         dzn[e] = hprev[e] > 0.f ? dh : 0.f;
     }
+#ifndef DRNMF_EXP_NODZ
     if (rg < a.B) {     // one 8-byte store where the pair is whole and aligned (n is even)
         float* dzo = a.dz_all + ((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n;
         if (n + 1 < a.N && (a.N & 1) == 0) *(f32x2*)dzo = dzn;
@@ -390,6 +393,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
             if (n + 1 < a.N) dzo[1] = dzn[1];
         }
     }
+#endif
     *(f32x2*)(a.dzp_out + hoff) = dzn;
     f32x2 dG = {dzn[0] * ia[0], dzn[1] * ia[1]};
     if (a.dGp_out) *(f32x2*)(a.dGp_out + hoff) = dG;       // (nullptr: cell_b reads dz, scale_pack_kernel)
