@@ -904,6 +904,44 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         *out = ge.exec;
         return DRNMF_OK;
     };
+    // One row tile and at most 32 output tiles: the persistent single-XCD kernel (cell_gram.h), one
+    // launch per block of frames.  DRNMF_PERSIST=0 keeps the launch-per-layer-step graphs.
+    bool persist = numM == 1 && numO <= 32 && K >= 2;
+    if (const char* e = getenv("DRNMF_PERSIST")) persist = persist && atoi(e) != 0;
+    if (persist) {
+        unsigned* bar = (unsigned*)(tA + 32);
+        for (int j = 0; j * GRAM_TB < d->T; ++j) {
+            const int t0 = j * GRAM_TB;
+            const int t1 = (j + 1) * GRAM_TB < d->T ? (j + 1) * GRAM_TB : d->T;
+            GramPersistArgs a;
+            memset(&a, 0, sizeof(a));
+            a.G = (const float*)(pb + L.off_gram);
+            a.g_stride = d->n_D == 1 ? 0 : (size_t)L.Np * L.Np;
+            a.ia = (const float*)(pb + L.off_inv_alpha);
+            a.Cp = Cp;
+            a.hb[0] = hb[0]; a.hb[1] = hb[1];
+            a.qb[0] = qb[0]; a.qb[1] = qb[1];
+            a.state = state;
+            a.rs_part = rs_part;
+            a.psum = (float*)(ws + W.off_psum);
+            a.psum_all = (float*)(ws + W.off_psum_all);
+            a.valid = valid;
+            a.out = h_out;
+            a.bar = bar;
+            a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
+            a.B = d->B; a.T = d->T; a.N = d->N; a.K = K; a.Bp = W.Bp; a.Np = W.Np; a.numO = numO;
+            a.out_width = d->return_all_hidden ? d->N * K : d->N;
+            a.all_hidden = d->return_all_hidden ? 1 : 0;
+            a.t0 = t0; a.nfr = t1 - t0;
+            DRNMF_HIP(h, hipMemsetAsync(bar, 0, 8, stream));   // counter + timeout flag
+            hipLaunchKernelGGL(gram_persist_kernel, dim3(8u * (unsigned)numO), dim3(64 * NW_G), 0,
+                               stream, a);
+            DRNMF_HIP(h, hipGetLastError());
+            int32_t rc = compute_block(j + 2);
+            if (rc) return rc;
+        }
+        return DRNMF_OK;
+    }
     // an even number of frames per graph (the frame parity of every node is then static) that
     // divides the block length
     int fpg = 2;

@@ -190,3 +190,36 @@ def test_gram_and_factored_forms_agree(dev, monkeypatch):
     assert f0[-2] == f1[-2] and abs(f0[-3] - f1[-3]) <= 1e-5 * abs(f0[-3])
     g0, g1 = f0[:-3], f1[:-3]
     assert np.max(np.abs(g0 - g1)) <= 2e-4 * np.max(np.abs(g0))
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=1, T=150, F=65, r=20, K=4),           # single utterance, > 2 ring blocks of frames
+    dict(B=7, T=70, F=33, r=50, K=3, ah=True),   # all-hidden (the training forward), ragged
+    dict(B=16, T=9, F=129, r=100, K=2),          # K = 2: first and last layer-step in one phase
+    dict(B=3, T=5, F=21, r=250, K=5),            # N = 500: 32 output tiles, the largest eligible
+])
+def test_persistent_gram_kernel_is_bit_identical(dev, monkeypatch, cfg):
+    """gram_persist_kernel (cell_gram.h): one launch per block of frames with an in-kernel barrier
+    between layer-steps, workgroups on one XCD -- the same arithmetic in the same order as the
+    launch-per-layer-step Gram kernels, so the two must agree bit for bit (ragged lengths, a masked
+    first frame, all-hidden output, stateful continuation); both are checked against the fp64
+    oracle by the parity suites."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as TP
+    B, T, F, r, K = cfg["B"], cfg["T"], cfg["F"], cfg["r"], cfg["K"]
+    ah = cfg.get("ah", False)
+    P, alt, labels, N = TP._problem(B, T, F, r, K, untied=("log_D", "log_alph"), ragged=B > 1,
+                                    seed=B + T)
+    if B > 1:
+        P["X"][B - 1, 0] = -1.0                   # a masked FIRST frame
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DRNMF_GRAM", "1")
+        monkeypatch.setenv("DRNMF_PERSIST", mode)
+        h, _, _ = TP._run_cell(dev, P, alt, labels, N, K, return_all_hidden=ah)
+        outs[mode] = h.copy()
+    assert np.array_equal(outs["0"], outs["1"])
+    ref = TP._oracle_cell(P, alt, labels, K, return_all_hidden=ah)
+    assert np.max(np.abs(outs["1"] - ref)) <= TP.H_TOL * np.max(np.abs(ref))
