@@ -244,6 +244,25 @@ struct EpiCPack {
     }
 };
 
+// The same for ALL K layers in one product (untied dictionaries: the K matrices Dn_k^T lie one
+// behind the other in the prepared block, so [x] . [Dn_0^T; ...; Dn_{K-1}^T]^T is one GEMM with
+// K * Np columns): col = k * Np + atom, ia / bias are the [K][Np] arrays.  K launches of a few
+// workgroups each per block of frames become one.
+struct EpiCPackAll {
+    float* Cp;
+    const float* ia;
+    const float* bias;
+    int TBc, K, NAC, Np;
+    size_t cstride;
+    __device__ f32x2 pre(int64_t, int col) const { return f32x2{ia[col], bias[col]}; }
+    __device__ void operator()(int64_t row, int col, float acc, f32x2 pv) const {
+        const int b = (int)(row / TBc), tl = (int)(row - (int64_t)b * TBc);
+        const int k = col / Np, n = col - k * Np;
+        Cp[((size_t)tl * K + k) * cstride + ((size_t)(b >> 4) * NAC + (n >> 4)) * 256 +
+           hp_pos(b & 15, n & 15)] = acc * pv[0] + pv[1];
+    }
+};
+
 // x[b][t0 .. t0+TBc)[F] -> xblk[b][tl][Fp] (padding bins zero)
 __global__ void __launch_bounds__(256)
 gather_block_kernel(const float* __restrict__ x, float* __restrict__ xblk, int B, int T, int F,
