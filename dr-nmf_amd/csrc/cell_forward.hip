@@ -822,6 +822,12 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             DRNMF_HIP(h, gemm::launch(g, epi, stream));
             return DRNMF_OK;
         }
+        if (d->n_D == 1 && K > 1) {      // tied: one product, K epilogue writes (EpiCPackTied)
+            gemm::Operands g{xpad, DnT_of(0), (int64_t)d->B * tbc, W.Np, W.Fp, W.Fp, W.Fp};
+            EpiCPackTied epi{slot, ia_of(0), b_of(0), tbc, K, NAC, W.Np, cstride};
+            DRNMF_HIP(h, gemm::launch(g, epi, stream));
+            return DRNMF_OK;
+        }
         for (int k = 0; k < K; ++k) {
             gemm::Operands g{xpad, DnT_of(k), (int64_t)d->B * tbc, W.Np, W.Fp, W.Fp, W.Fp};
             EpiCPack epi{slot + (size_t)k * cstride, ia_of(k), b_of(k), tbc, K, NAC, cstride};

@@ -263,6 +263,25 @@ struct EpiCPackAll {
     }
 };
 
+// A tied dictionary: x Dn is the same product for every layer, only 1/alpha_k and b_k differ -- one
+// GEMM of Np columns whose epilogue writes all K layers.
+struct EpiCPackTied {
+    float* Cp;
+    const float* ia;         // [K][Np]
+    const float* bias;       // [K][Np]
+    int TBc, K, NAC, Np;
+    size_t cstride;
+    static constexpr bool EARLY = false;
+    __device__ f32x2 pre(int64_t, int) const { return f32x2{0.f, 0.f}; }
+    __device__ void operator()(int64_t row, int col, float acc, f32x2) const {
+        const int b = (int)(row / TBc), tl = (int)(row - (int64_t)b * TBc);
+        float* dst = Cp + (size_t)tl * K * cstride + ((size_t)(b >> 4) * NAC + (col >> 4)) * 256 +
+                     hp_pos(b & 15, col & 15);
+        for (int k = 0; k < K; ++k)
+            dst[(size_t)k * cstride] = acc * ia[(size_t)k * Np + col] + bias[(size_t)k * Np + col];
+    }
+};
+
 // x[b][t0 .. t0+TBc)[F] -> xblk[b][tl][Fp] (padding bins zero)
 __global__ void __launch_bounds__(256)
 gather_block_kernel(const float* __restrict__ x, float* __restrict__ xblk, int B, int T, int F,
