@@ -916,9 +916,9 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         *out = ge.exec;
         return DRNMF_OK;
     };
-    // One row tile and at most 32 output tiles: the persistent single-XCD kernel (cell_gram.h), one
+    // At most 32 (row tile, output tile) pairs: the persistent single-XCD kernel (cell_gram.h), one
     // launch per block of frames.  DRNMF_PERSIST=0 keeps the launch-per-layer-step graphs.
-    bool persist = numM == 1 && numO <= 32 && K >= 2;
+    bool persist = numM * numO <= 32 && K >= 2;
     if (const char* e = getenv("DRNMF_PERSIST")) persist = persist && atoi(e) != 0;
     if (persist) {
         unsigned* bar = (unsigned*)(tA + 32);
@@ -942,12 +942,13 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             a.bar = bar;
             a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
             a.B = d->B; a.T = d->T; a.N = d->N; a.K = K; a.Bp = W.Bp; a.Np = W.Np; a.numO = numO;
+            a.numM = numM;
             a.out_width = d->return_all_hidden ? d->N * K : d->N;
             a.all_hidden = d->return_all_hidden ? 1 : 0;
             a.t0 = t0; a.nfr = t1 - t0;
             DRNMF_HIP(h, hipMemsetAsync(bar, 0, 8, stream));   // counter + timeout flag
-            hipLaunchKernelGGL(gram_persist_kernel, dim3(8u * (unsigned)numO), dim3(64 * NW_G), 0,
-                               stream, a);
+            hipLaunchKernelGGL(gram_persist_kernel, dim3(8u * (unsigned)(numO * numM)),
+                               dim3(64 * NW_G), 0, stream, a);
             DRNMF_HIP(h, hipGetLastError());
             int32_t rc = compute_block(j + 2);
             if (rc) return rc;

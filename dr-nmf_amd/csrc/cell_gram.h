@@ -367,7 +367,8 @@ unpack_scaled_kernel(const float* __restrict__ Dp, const float* __restrict__ ia,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent form for ONE row tile (B <= 16) and at most 32 output tiles (N <= 512): the whole
+// Persistent form for at most 32 (row tile, output tile) pairs -- B <= 16 with N <= 512, B <= 32 with
+// N <= 256 --: the whole
 // (frame, layer) chain of a block of frames in ONE launch.  Such a shape -- single-utterance /
 // small-batch serving, BASELINE configs[0] -- puts numO <= 32 workgroups on the chip and is nothing
 // but launch latency (1.9 us per layer-step).  The workgroups all sit on ONE XCD (workgroup ids go
@@ -393,7 +394,7 @@ struct GramPersistArgs {
     float* out;
     unsigned* bar;           // zeroed before the launch
     float u0d, u0o, uko;
-    int B, T, N, K, Bp, Np, numO, out_width, all_hidden;
+    int B, T, N, K, Bp, Np, numO, numM, out_width, all_hidden;
     int t0, nfr;
 };
 
@@ -421,15 +422,16 @@ __global__ void __launch_bounds__(64 * NW_G) gram_persist_kernel(const GramPersi
     __shared__ __attribute__((aligned(16))) float red[NW_G * 16 * 17];
     __shared__ float part[32][17];
     __shared__ float ps16[16], psv[16];
-    const int ot = blockIdx.x >> 3;                         // < numO (grid = 8 * numO)
+    const int wg = blockIdx.x >> 3;                         // < numM * numO (grid = 8 * that)
+    const int m = wg / a.numO, ot = wg - m * a.numO;        // row tile, output tile
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63, j = l & 15, q = l >> 4;
     const int NAC = a.Np / 16;
     const bool ethr = tid < 256;
     const int erow = (tid & 255) >> 4, ecol = tid & 15;
-    const int rg = erow, n = ot * 16 + ecol;
-    const size_t hoff = (size_t)ot * 256 + hp_pos(erow, ecol);
+    const int rg = m * 16 + erow, n = ot * 16 + ecol;
+    const size_t hoff = ((size_t)m * NAC + ot) * 256 + hp_pos(erow, ecol);
     const size_t cstride = (size_t)a.Bp * a.Np;
     constexpr int RING = 2 * GRAM_TB;
     const int clast = NAC - 1;
@@ -479,7 +481,7 @@ __global__ void __launch_bounds__(64 * NW_G) gram_persist_kernel(const GramPersi
         for (int g = 0; g < 4; ++g) {
             int c = w + NW_G * g;
             c = c > clast ? clast : c;
-            av[g] = ld4_sc1(arsrc, (unsigned)((256 * c + l * 4) * 4));
+            av[g] = ld4_sc1(arsrc, (unsigned)((((size_t)m * NAC + c) * 256 + l * 4) * 4));
             bv[g] = bvN[g];
         }
         float hraw = 0.f, psl = 0.f, rsum = 0.f;
@@ -487,7 +489,7 @@ __global__ void __launch_bounds__(64 * NW_G) gram_persist_kernel(const GramPersi
         const bool vld = vldN;
         if (first) {
             const int row = tid & 15, pt = tid >> 4;        // 32 parts
-            const float* rp = a.rs_part + (size_t)par * a.numO * a.Bp + row;
+            const float* rp = a.rs_part + (size_t)par * a.numO * a.Bp + m * 16 + row;
             for (int b2 = pt; b2 < a.numO; b2 += 32) rsum += ld1_sc1(rp + (size_t)b2 * a.Bp);
         }
         if (ethr) {
@@ -583,7 +585,7 @@ __global__ void __launch_bounds__(64 * NW_G) gram_persist_kernel(const GramPersi
             // with a wrong result and says so in bar[1] rather than hang the device)
             unsigned spins = 0;
             while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                   (unsigned)(p + 1) * (unsigned)a.numO) {
+                   (unsigned)(p + 1) * (unsigned)(a.numO * a.numM)) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 22)) { a.bar[1] = 1u; break; }
             }

@@ -197,6 +197,8 @@ def test_gram_and_factored_forms_agree(dev, monkeypatch):
     dict(B=7, T=70, F=33, r=50, K=3, ah=True),   # all-hidden (the training forward), ragged
     dict(B=16, T=9, F=129, r=100, K=2),          # K = 2: first and last layer-step in one phase
     dict(B=3, T=5, F=21, r=250, K=5),            # N = 500: 32 output tiles, the largest eligible
+    dict(B=32, T=70, F=33, r=100, K=3, ah=True), # two row tiles x 13 output tiles
+    dict(B=20, T=9, F=65, r=128, K=4),           # two row tiles x 16 output tiles = 32 workgroups
 ])
 def test_persistent_gram_kernel_is_bit_identical(dev, monkeypatch, cfg):
     """gram_persist_kernel (cell_gram.h): one launch per block of frames with an in-kernel barrier
