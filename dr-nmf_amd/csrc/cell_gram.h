@@ -443,34 +443,43 @@ __global__ void __launch_bounds__(64 * NW_G) gram_persist_kernel(const GramPersi
     // the validity flag, this thread's own state element -- are requested one phase AHEAD, before
     // the barrier, so that after the barrier only the exchanged activations (sc1, L2 hits) are on
     // the critical path.
+    // (the phase -> (frame, layer) bookkeeping is incremental and the address parts that do not
+    // change are formed once: in the in-kernel timeline the prefetch's integer division and 64-bit
+    // address arithmetic were 0.5 us of a 2.6-us phase)
     f32x4 bvN[4];
     float ckN = 0.f, cnextN = 0.f, iavN = 0.f, stoldN = 0.f;
     bool vldN = true;
-    auto prefetch = [&](int p) {
-        if (p >= nphase) return;
-        const int f = p / KL, k = p - f * KL + 1, t = a.t0 + f;
-        const float* Gk = a.G + (size_t)k * a.g_stride + (size_t)ot * NAC * 256 + l * 4;
+    const float* Gl = a.G + (size_t)ot * NAC * 256 + l * 4;      // + k * g_stride + 256 * c
+    int gc[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            int c = w + NW_G * g;
-            c = c > clast ? clast : c;
-            bvN[g] = *(const f32x4*)(Gk + 256 * c);
-        }
+    for (int g = 0; g < 4; ++g) {
+        const int c = w + NW_G * g;
+        gc[g] = 256 * (c > clast ? clast : c);
+    }
+    const float* ial = a.ia + n;                                   // + k * Np
+    const float* cpl = a.Cp + hoff;                                // + ((t mod RING) * K + k) * cstride
+    const unsigned char* vl = a.valid + rg;                        // + t * Bp
+    auto prefetch = [&](int fN, int kN) {                          // operands of (frame t0 + fN, layer kN)
+        if (fN >= a.nfr) return;
+        const int t = a.t0 + fN;
+        const float* Gk = Gl + (size_t)kN * a.g_stride;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bvN[g] = *(const f32x4*)(Gk + gc[g]);
         if (ethr) {
-            iavN = a.ia[(size_t)k * a.Np + n];
-            ckN = a.Cp[((size_t)(t & (RING - 1)) * a.K + k) * cstride + hoff];
-            vldN = a.valid[(size_t)t * a.Bp + rg] != 0;
-            if (k == a.K - 1) {
+            iavN = ial[(size_t)kN * a.Np];
+            ckN = cpl[(size_t)((t & (RING - 1)) * a.K + kN) * cstride];
+            vldN = vl[(size_t)t * a.Bp] != 0;
+            if (kN == a.K - 1) {
                 const int tn = t + 1 < a.T ? t + 1 : t;
-                cnextN = a.Cp[((size_t)(tn & (RING - 1)) * a.K) * cstride + hoff];
+                cnextN = cpl[(size_t)((tn & (RING - 1)) * a.K) * cstride];
                 stoldN = a.state[hoff];
             }
         }
     };
-    prefetch(0);
+    prefetch(0, 1);
 
+    int f = 0, k = 1;
     for (int p = 0; p < nphase; ++p) {
-        const int f = p / KL, k = p - f * KL + 1;
         const int t = a.t0 + f, par = t & 1;
         const bool first = k == 1, last = k == a.K - 1;
         const float* a_in = first ? a.qb[par] : a.hb[(k - 1) & 1];
@@ -578,7 +587,8 @@ __global__ void __launch_bounds__(64 * NW_G) gram_persist_kernel(const GramPersi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prefetch(p + 1);
+        if (last) { ++f; k = 1; } else ++k;                      // the next phase
+        prefetch(f, k);
         if (tid == 0) {
             // (bounded: ~2 s.  All numO <= 32 workgroups of this launch are resident at once on any
             // MI355X partition, so the bound is never reached; should it be, the launch runs on
