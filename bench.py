@@ -370,19 +370,35 @@ def pmc_traffic():
     """HBM-side bytes per cell launch from the newest committed PMC summary (separate rocprofv3
     --pmc passes over this same command, profiles/collect.sh; FETCH_SIZE KB x 1024 x 2 -- the
     gfx950 under-report of wide coalesced reads, MI355X_MICROARCH.md -- plus WRITE_SIZE KB x
-    1024).  PMC counters cannot be read from inside the process, so this is the profiled figure
-    of the same kernels, or None when no summary is present."""
+    1024).  PMC counters cannot be read from inside the process, so this is the PROFILED figure of
+    the same kernels.  Returns (traffic, from_profile): `traffic` is the figure only when the
+    summary was collected on a library built from exactly the sources this run uses (content hash
+    `_lib_src_sha16`, stamped by profiles/summarize_pmc.py), else None; `from_profile` always says
+    what the committed summary holds and for which sources."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_summary.json")))
+    try:
+        sys.path.insert(0, os.path.join(here, "dr-nmf_amd"))
+        import build as _b
+        cur = _b._src_hash()[:16]
+    except Exception:            # noqa: BLE001
+        cur = None
     for f in reversed(files):
         try:
-            v = json.load(open(f)).get("_cell_launch_mean_traffic_bytes")
+            js = json.load(open(f))
         except (OSError, ValueError):
-            v = None
+            continue
+        v = js.get("_cell_launch_mean_traffic_bytes")
         if v:
-            return float(v), "bytes per cell launch, HBM side (PMC passes: profiles/%s)" % \
-                os.path.basename(f)
+            sha = js.get("_lib_src_sha16")
+            same = bool(sha) and sha == cur
+            return (float(v) if same else None), {
+                "bytes_per_cell_launch_hbm_side": float(v), "file": "profiles/" + os.path.basename(f),
+                "lib_src_sha16_of_profile": sha, "lib_src_sha16_of_this_run": cur,
+                "same_sources": same,
+                "note": "PMC passes of the same bench command (profiles/collect.sh), not measured "
+                        "inside this run"}
     return None, None
 
 
@@ -481,16 +497,60 @@ def cpu_baseline(F, r, K, B, frames, tied):
     with _limit_threads(best_t):
         t_dense = run_dense(P)
         t_fact = run_fact(P)
+    fb = cpu_fwd_bwd(F, r, K, B, max(2, min(16, frames // 8)), tied, best_t)
     return {
         "value": B * frames / t_dense, "unit": "frames/s", "cores": int(best_t), "kind": "port",
-        "sample": "numpy fp32 restatement of the reference op graph (dense U, Gram S, per-step "
+        "sample": "FORWARD ONLY (the headline `value` beside it is forward + BPTT + Adam; the same "
+                  "step on the host is `fwd_bwd` below): numpy fp32 restatement of the reference op "
+                  "graph (dense U, Gram S, per-step "
                   "GEMMs), FORWARD of the recurrent cell on %d utterances x %d frames of the same "
                   "workload (Gram/matrix build %.1f s excluded); BLAS threads swept, best of %s "
                   "reported (host exposes %d); factored form on the same sample and threads: %.0f "
                   "frames/s" % (B, frames, t_maps, sorted(int(k) for k in sweep), max_threads,
                                 B * frames / t_fact),
         "thread_sweep_frames_per_s": sweep,
+        "fwd_bwd": fb,
     }
+
+
+def cpu_fwd_bwd(F, r, K, B, frames, tied, threads):
+    """The metric's own step on the host: forward + loss + backward of the whole model by torch-CPU
+    fp32 autograd of the oracle restatement (oracle/drnmf_torch_ref.py, factored form -- the
+    reference gets its gradients from Theano autodiff of the same graph, enhance.py:1071-1073), on
+    a bounded sample, `threads` intra-op threads."""
+    import torch
+    from oracle import drnmf_oracle as O
+    from oracle import drnmf_torch_ref as TR
+    N = 2 * r
+    P = O.synth_problem(B, frames, F, r, seed=7654)
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(400.0 if r >= 1000 else 50.0), lam1=np.float32(1.0))
+    alt, labels = O.build_alt(N, K, params, () if tied else ("log_D", "log_alph"))
+    old = torch.get_num_threads()
+    torch.set_num_threads(int(threads))
+    try:
+        f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+        a = {k: f32(v).requires_grad_(k.startswith("log_D") or k.startswith("log_alph"))
+             for k, v in alt.items()}
+        lh0 = f32(P["log_h0"]).requires_grad_(True)
+        kc = f32(np.log(1e-7 + P["W"][:, :r]).T).requires_grad_(True)
+        kn = f32(np.log(1e-7 + P["W"][:, r:]).T).requires_grad_(True)
+        x, y = f32(P["X"]), f32(P["Y"])
+        w = torch.ones((B, frames), dtype=torch.float32)
+        best = None
+        for _ in range(2):                           # second pass: allocator and BLAS warmed up
+            t0 = time.perf_counter()
+            loss, _, _ = TR.model_loss(x, y, w, a, labels, K, lh0, kc, kn)
+            loss.backward()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            for t_ in list(a.values()) + [lh0, kc, kn]:
+                t_.grad = None
+    finally:
+        torch.set_num_threads(old)
+    return {"value": B * frames / best, "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": "torch-CPU fp32 autograd of the factored restatement (forward + loss + backward, "
+                      "no optimiser step), %d utterances x %d frames, best of 2 passes" % (B, frames)}
 
 
 def config1_bench(torch, dev):
@@ -654,6 +714,7 @@ def main():
     out = {}
     train = None
     collective = None
+    comm_seen = None
     if not a.forward_only:
         def on_timeout():
             # a collective that never comes back: say so and leave with a failure code (the
@@ -665,27 +726,34 @@ def main():
             os._exit(3)
 
         if world > 1:
-            # the gradient all-reduce goes through libdrnmf's RCCL communicator (C ABI).  Should its
-            # creation fail on this node the measurement is still taken -- through
-            # torch.distributed's all-reduce -- and the JSON line says so, loudly.
+            # the gradient all-reduce goes through libdrnmf's RCCL communicator (C ABI).  A failure
+            # to create it ENDS the run with a non-zero code on every rank: a line whose collective
+            # is not the product's must never be mistaken for the N-GPU number.  Only an explicit
+            # DRNMF_DP_BACKEND=torch (several test ranks on one GPU) selects torch.distributed.
             from drnmf_amd import dp
             if os.environ.get("DRNMF_DP_BACKEND", "rccl") == "torch":
-                collective = "torch.distributed all-reduce (DRNMF_DP_BACKEND=torch)"
+                collective = "torch.distributed all-reduce (DRNMF_DP_BACKEND=torch, set explicitly)"
             else:
-                try:
+                def init_comm():
                     dp.comm_init(dev)
-                    collective = "drnmf_allreduce_grads (RCCL communicator owned by the library handle)"
-                except Exception as e:       # noqa: BLE001
-                    os.environ["DRNMF_DP_BACKEND"] = "torch"
-                    collective = ("FALLBACK to torch.distributed all-reduce: drnmf_comm_init failed: "
-                                  + repr(e)[:200])
-                # every rank must take the same path
-                flag = torch.tensor([1.0 if collective.startswith("FALLBACK") else 0.0], device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                if float(flag.item()) > 0 and not collective.startswith("FALLBACK"):
-                    dp.comm_destroy()
-                    os.environ["DRNMF_DP_BACKEND"] = "torch"
-                    collective = "FALLBACK to torch.distributed all-reduce: drnmf_comm_init failed on another rank"
+                    return {}
+                res = run_guarded(init_comm, 300.0, on_timeout)
+                failed = torch.tensor([1.0 if "error" in res else 0.0], device=dev)
+                dist.all_reduce(failed, op=dist.ReduceOp.MAX)        # every rank learns of it
+                if float(failed.item()) > 0:
+                    if rank == 0:
+                        print(json.dumps({"metric": "STFT frames/sec (fwd+bwd)", "value": None,
+                                          "n_gpus": world,
+                                          "error": "drnmf_comm_init failed (%s); no fallback: set "
+                                                   "DRNMF_DP_BACKEND=torch explicitly to measure "
+                                                   "with torch.distributed's all-reduce" %
+                                                   res.get("error", "on another rank")}), flush=True)
+                    raise SystemExit(5)
+                collective = "drnmf_allreduce_grads (RCCL communicator owned by the library handle)"
+                comm_seen = dp.comm_info(dev)          # (rank, world) as RCCL's communicator has them
+                if comm_seen is None or comm_seen[1] != world:
+                    raise SystemExit("bench.py: the library's communicator reports %r, expected "
+                                     "world %d" % (comm_seen, world))
 
         def headline():
             model.compile(lr=1e-3)
@@ -701,7 +769,21 @@ def main():
             model.train_on_batch(X, Y, wts)
             bp = dict(model.backward_profile)
             model.backward_profile = None
-            return dict(wall=wall, ev_ms=ev_ms, phases=phases, bp=bp, losses=losses)
+            ar = None
+            if world > 1:      # the step's one collective alone: all-reduce of the flat buffer, 5 times
+                from drnmf_amd import dp as _dp
+                flat = model._flat
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                _dp.allreduce_sum_(flat)
+                torch.cuda.synchronize()
+                barrier()
+                e0.record()
+                for _ in range(5):
+                    _dp.allreduce_sum_(flat)
+                e1.record()
+                torch.cuda.synchronize()
+                ar = {"bytes": int(flat.numel()) * 4, "ms": e0.elapsed_time(e1) / 5.0}
+            return dict(wall=wall, ev_ms=ev_ms, phases=phases, bp=bp, losses=losses, allreduce=ar)
         train = run_guarded(headline, 900.0, on_timeout)
     if train is not None and "error" not in train:
         wall, ev_ms = train["wall"], train["ev_ms"]
@@ -723,10 +805,13 @@ def main():
                                     ", one RCCL all-reduce of the flat gradient per step"
                                     if world > 1 else ""),
                        "B_per_gpu": B, "T": T, "F": F, "N": N, "K": K, "untied": not a.tied,
-                       "collective": collective},
+                       "collective": collective,
+                       "comm_rank_world_as_reported_by_drnmf_comm_info": comm_seen,
+                       "allreduce_bytes": (train.get("allreduce") or {}).get("bytes"),
+                       "allreduce_ms": (train.get("allreduce") or {}).get("ms")},
             "roofline": {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": traffic_src,
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_from_profile": traffic_src,
                 "kernel": "the chain kernels cell_a / cell_b (forward) and cell_b / bwd_a (BPTT): "
                           "each launch is one B x F x N contraction",
                 "launch_us": launch_us, "flops_per_launch": flops_per_launch,
@@ -798,7 +883,7 @@ def main():
                     "same model and batch" % K,
         "roofline": {"bound": "mfma", "achieved": f_ach, "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": f_ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                     "traffic_unit": traffic_src,
+                     "traffic_from_profile": traffic_src,
                      "kernel": "cell_a_kernel / cell_b_kernel (mean over the 2K-1 launches of a frame)",
                      "launch_us": f_launch_us, "flops_per_launch": flops_per_launch,
                      "duration_source": "HIP events around the cell's graph replays, unprofiled "

@@ -351,7 +351,6 @@ pack_input_kernel(const float* __restrict__ x, float* __restrict__ xp,
 // pair -> Gram launch): N = 200 6.0 -> 4.2, N = 512 6.1 -> 4.4, N = 1000 6.3 -> 5.7, N = 2000 7.7 ->
 // 8.9; N = 200 wins 1.5-1.6x at every batch from 1 to 250.  Rule: numM * Np^2 <= 3e6 (the crossover
 // sits near 25 MB of operand traffic per launch), independent of T and K.
-constexpr int64_t GRAM_MAX_WORK = 3000000;
 constexpr int GRAM_TB = 64;          // frames per block of the hoisted c_k products (ring of 2 blocks)
 static inline bool gram_wanted(const drnmf_cell_desc_t* d) {
     if (!gram_eligible(d)) return false;

@@ -34,11 +34,7 @@ struct Rccl {
     char why[256] = {0};
 };
 
-Rccl* rccl() {
-    static Rccl R;
-    static bool tried = false;
-    if (tried) return &R;
-    tried = true;
+void fill_rccl(Rccl& R) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -46,7 +42,7 @@ Rccl* rccl() {
     }
     if (!R.lib) {
         snprintf(R.why, sizeof(R.why), "librccl.so.1 not loadable: %s", dlerror());
-        return &R;
+        return;
     }
     R.get_unique_id = (get_unique_id_fn)dlsym(R.lib, "ncclGetUniqueId");
     R.comm_init_rank = (comm_init_rank_fn)dlsym(R.lib, "ncclCommInitRank");
@@ -59,6 +55,15 @@ Rccl* rccl() {
         snprintf(R.why, sizeof(R.why), "librccl lacks an expected nccl* entry point");
         R.lib = nullptr;
     }
+}
+
+// Lazy, once: a function-local static initialised by a lambda -- the language runs it on exactly
+// one thread and makes the others wait, so two host threads making their first comm call never see
+// a half-filled table.
+Rccl* rccl() {
+    static Rccl R;
+    static const bool once = [] { fill_rccl(R); return true; }();
+    (void)once;
     return &R;
 }
 

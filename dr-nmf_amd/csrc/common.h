@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -132,9 +133,18 @@ __device__ __forceinline__ f32x4 mfma32h(f16x8 a, f16x8 b, f32x4 c) {
 //   off_dn_rm: scratch, one layer of Dn row-major [Fp][Np]
 // for fp32 Euclidean descriptors with N <= GRAM_MAX_N (a property of the descriptor's F, N, K only:
 // the same block serves every batch size).
+// The bound is the one gram_wanted() (cell_shared.h) applies to a single row tile: a dictionary wider
+// than that can never take the Gram form, so its block must not carry (and every prepare_params
+// must not rebuild) G_k and Dn_k^T -- 0.5 GB and n_D extra GEMMs per training step at N = 2000,
+// K = 25.  DRNMF_GRAM=1 (tuning aid: force the form) widens eligibility to GRAM_MAX_N.
 constexpr int GRAM_MAX_N = 4096;
+constexpr int64_t GRAM_MAX_WORK = 3000000;      // (row tiles) * Np^2 of gram_wanted()
 static inline bool gram_eligible(const drnmf_cell_desc_t* d) {
-    return !d->operand_f16 && d->divergence == DRNMF_DIV_ED && d->N <= GRAM_MAX_N && d->K >= 2;
+    if (d->operand_f16 || d->divergence != DRNMF_DIV_ED || d->K < 2 || d->N > GRAM_MAX_N) return false;
+    const int64_t Np = pad_n(d->N);
+    if (Np * Np <= GRAM_MAX_WORK) return true;
+    const char* e = getenv("DRNMF_GRAM");
+    return e && atoi(e) == 1;
 }
 
 struct ParamsLayout {

@@ -50,16 +50,38 @@ def comm_init(device, rank_=None, world_=None):
     w = world_size() if world_ is None else int(world_)
     L, h = _capi.lib(), _capi.handle(idx)
     buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
+    err = None
     if r == 0:
-        _capi.check(L.drnmf_comm_unique_id(h, buf), h, "drnmf_comm_unique_id")
+        # (a failure here -- librccl not loadable -- must still reach the broadcast below: the other
+        # ranks are waiting in it)
+        try:
+            _capi.check(L.drnmf_comm_unique_id(h, buf), h, "drnmf_comm_unique_id")
+        except Exception as e:       # noqa: BLE001
+            err = repr(e)
     if w > 1:
-        box = [buf.raw if r == 0 else None]
+        box = [(buf.raw, err) if r == 0 else None]
         torch.distributed.broadcast_object_list(box, src=0)
-        buf = C.create_string_buffer(box[0], _capi.COMM_ID_BYTES)
+        raw, err = box[0]
+        buf = C.create_string_buffer(raw, _capi.COMM_ID_BYTES)
+    if err is not None:
+        raise RuntimeError("drnmf_comm_unique_id failed on rank 0: " + err)
     with torch.cuda.device(idx):
         _capi.check(L.drnmf_comm_init(h, buf, r, w), h, "drnmf_comm_init")
     _comms[idx] = (r, w)
     return _comms[idx]
+
+
+def comm_info(device=None):
+    """(rank, world) as the LIBRARY's communicator reports them (drnmf_comm_info), or None when the
+    device's handle owns no communicator."""
+    from . import _capi
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    if idx not in _comms:
+        return None
+    r, w = C.c_int32(-1), C.c_int32(-1)
+    h = _capi.handle(idx)
+    _capi.check(_capi.lib().drnmf_comm_info(h, C.byref(r), C.byref(w)), h, "drnmf_comm_info")
+    return int(r.value), int(w.value)
 
 
 def comm_destroy(device=None):
@@ -129,9 +151,15 @@ def shard(n_items, r=None, w=None):
     return lo, lo + base + (1 if r < rem else 0)
 
 
-def normalised(flat, n_scalars=2):
+N_SCALARS = 3        # tail of the model's flat buffer: [sum w*mse, count, rows] (layers.UnfoldedSNMFModel.N_SCALARS)
+
+
+def normalised(flat, n_scalars=N_SCALARS):
     """(gradient / global count, loss) from an all-reduced flat buffer whose last `n_scalars`
-    entries start with [sum w*mse, count]."""
-    cnt = float(flat[-n_scalars + 1])
+    entries START with [sum w*mse, count] (the model's buffer carries a third, the frame count)."""
+    if n_scalars < 2:
+        raise ValueError("the scalar tail holds at least [sum, count]")
+    tail = flat[flat.numel() - n_scalars:]
+    cnt = float(tail[1])
     scale = 1.0 / max(cnt, 1.0)
-    return flat[:-n_scalars] * scale, float(flat[-n_scalars]) * scale
+    return flat[:flat.numel() - n_scalars] * scale, float(tail[0]) * scale

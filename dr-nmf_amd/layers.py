@@ -936,7 +936,7 @@ class UnfoldedSNMFModel(object):
         for l in (self.cell, self.clean, self.noise):
             l._weights_changed()
 
-    def loss_and_grads(self, x, y, sample_weight):
+    def loss_and_grads(self, x, y, sample_weight, live=True):
         """Unnormalised loss/gradients of one (local) batch into the flat buffer; returns the
         flat tensor [grads..., sum w*mse, count, frames].  `self.phase_events` (bench.py only): a
         dict that receives (start, end) torch events of the cell forward, the head + loss, and the
@@ -976,13 +976,16 @@ class UnfoldedSNMFModel(object):
                     gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
         gv['kernel_clean'].copy_(dkc)
         gv['kernel_noise'].copy_(dkn)
-        self._set_scalars(sums, x)
+        self._set_scalars(sums, x, live)
         return self._flat
 
-    def _set_scalars(self, sums, x):
+    def _set_scalars(self, sums, x, live=True):
+        # (a step that is not live -- fit() on a rank whose shard has run out replays a batch with
+        # zero weights -- contributes no rows either: 'rows' feeds p = count / rows of
+        # loss_norm='keras204', which must be the GLOBAL batch's, not inflated by the replay)
         ns = self.N_SCALARS
         self._flat[-ns:-ns + 2].copy_(sums)
-        self._flat[-1] = float(x.shape[0] * x.shape[1])
+        self._flat[-1] = float(x.shape[0] * x.shape[1]) if live else 0.0
 
     def apply_gradients(self, flat):
         """Adam step from the (already all-reduced) flat buffer; returns the normalised loss."""
@@ -1019,7 +1022,7 @@ class UnfoldedSNMFModel(object):
             self.cell._dense_block_valid = False
         return sse * scale
 
-    def train_on_batch(self, x, y, sample_weight=None):
+    def train_on_batch(self, x, y, sample_weight=None, _live=True):
         """One optimiser step.  x, y: (B,T,F); sample_weight: (B,T) (the data mask,
         enhance.py:1148-1152).  Under torch.distributed the flat gradient + (sum, count) are
         all-reduced (RCCL) before the update, so every rank applies the same step."""
@@ -1030,7 +1033,7 @@ class UnfoldedSNMFModel(object):
         x, y = tt(x), tt(y)
         if sample_weight is None:
             sample_weight = torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
-        flat = self.loss_and_grads(x, y, tt(sample_weight))
+        flat = self.loss_and_grads(x, y, tt(sample_weight), live=_live)
         dp.allreduce_sum_(flat)
         return self.apply_gradients(flat)
 
@@ -1080,6 +1083,11 @@ class UnfoldedSNMFModel(object):
         # every train_on_batch is a collective: all ranks must take the same number of steps even
         # when their shards differ in size (dp.shard hands the remainder to the first ranks)
         steps = dp.max_over_ranks(epoch_steps(n, batch_size))
+        # an empty shard has no batch to replay with zero weights; every rank must learn of it HERE
+        # (one that raised alone would leave the others waiting in the first all-reduce)
+        if dp.max_over_ranks(1 if n == 0 else 0):
+            raise ValueError("fit(): a rank holds no sequences (%d here); give every rank at least "
+                             "one (dp.shard of fewer sequences than ranks?)" % n)
         for ep in range(epochs):
             for cb in callbacks:
                 if hasattr(cb, 'on_epoch_begin'):
@@ -1092,7 +1100,7 @@ class UnfoldedSNMFModel(object):
                     # this rank has run out of data: it joins the all-reduce with zero weights
                     # (zero gradient, zero count) on a batch it has already used
                     sw = np.zeros((len(b), x.shape[1]), np.float32)
-                loss = self.train_on_batch(x[b], y[b], sw)
+                loss = self.train_on_batch(x[b], y[b], sw, _live=live)
                 tot += loss
                 for cb in callbacks:
                     if hasattr(cb, 'on_batch_end'):
@@ -1183,7 +1191,7 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
         xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.cell.device)
         return [o.cpu().numpy() for o in self.forward(xt)]
 
-    def loss_and_grads(self, x, y, sample_weight):
+    def loss_and_grads(self, x, y, sample_weight, live=True):
         cell = self.cell
         N, K = cell.output_dim, cell.K_layers
         hall = cell.forward_train(x, mask_value=self.mask_value)
@@ -1207,12 +1215,12 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
                     gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
         gv['kernel_clean'].copy_(dkc)
         gv['kernel_noise'].copy_(dkn)
-        self._set_scalars(sums, x)
+        self._set_scalars(sums, x, live)
         return self._flat
 
-    def train_on_batch(self, x, y=None, sample_weight=None):
+    def train_on_batch(self, x, y=None, sample_weight=None, _live=True):
         y = x if y is None else self._first(y)
-        return UnfoldedSNMFModel.train_on_batch(self, x, y, self._first(sample_weight))
+        return UnfoldedSNMFModel.train_on_batch(self, x, y, self._first(sample_weight), _live=_live)
 
     def test_on_batch(self, x, y=None, sample_weight=None):
         from . import dp

@@ -28,18 +28,18 @@ def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, s
     state = h0[None, :].expand(B, N)
     out_prev = torch.zeros(B, N, dtype=x.dtype)
     outs = []
+    # the maps from the log-domain parameters are evaluated once per graph execution, outside the
+    # scan over time (custom_layers.py:234-287 builds Wk/Sk/bk in build(), not in step())
+    Dns = [unit_cols(alt[labels_per_k['log_D'][k]]) for k in range(K)]
+    ias = [torch.exp(-alt[labels_per_k['log_alph'][k]]) for k in range(K)]
+    lams = [torch.exp(alt[labels_per_k['log_lam1'][k]]) for k in range(K)]
     for t in range(T):
         p = state
         ps = p.sum(1, keepdim=True)
         xt = xm[:, t]
-        Dn = unit_cols(alt[labels_per_k['log_D'][0]])
-        ia = torch.exp(-alt[labels_per_k['log_alph'][0]])
-        lam = torch.exp(alt[labels_per_k['log_lam1'][0]])
-        h = torch.relu(u0d * p + u0o * (ps - p) + (xt @ Dn) * ia - lam * ia)
+        h = torch.relu(u0d * p + u0o * (ps - p) + (xt @ Dns[0]) * ias[0] - lams[0] * ias[0])
         for k in range(1, K):
-            Dn = unit_cols(alt[labels_per_k['log_D'][k]])
-            ia = torch.exp(-alt[labels_per_k['log_alph'][k]])
-            lam = torch.exp(alt[labels_per_k['log_lam1'][k]])
+            Dn, ia, lam = Dns[k], ias[k], lams[k]
             rr = xt - h @ Dn.t()
             h = torch.relu(h + (rr @ Dn) * ia - lam * ia + uko * ps)
         v = valid[:, t][:, None]

@@ -63,6 +63,16 @@ def main():
                 tot_b += n * b
     if tot_n:
         res["_cell_launch_mean_traffic_bytes"] = tot_b / tot_n
+    # which library the counters belong to: content hash of libdrnmf's sources and flags (the same
+    # one build.py stamps the .so with).  bench.py reports the figure as `roofline.traffic` only while
+    # the library it runs is built from exactly these sources.
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dr-nmf_amd"))
+        import build as _b
+        res["_lib_src_sha16"] = _b._src_hash()[:16]
+    except Exception as e:       # noqa: BLE001
+        res["_lib_src_sha16"] = None
+        res["_lib_src_sha16_error"] = repr(e)[:200]
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps({k: v for k, v in res.items() if k.startswith("_")}))

@@ -58,9 +58,23 @@ def _worker(rank, world, port, out_dir):
     lo, hi = dp.shard(P["X"].shape[0])
     flat = _flat_grads(P, alt, labels, K, kc, kn, w, lo, hi)
     dp.allreduce_sum_(flat)
-    g, loss = dp.normalised(flat)
+    g, loss = dp.normalised(flat, n_scalars=2)      # this test's buffer ends in [sum, count]
     np.save(os.path.join(out_dir, "g%d.npy" % rank), np.concatenate([g.numpy(), [loss]]))
     torch.distributed.destroy_process_group()
+
+
+def test_normalised_reads_the_models_three_scalar_tail():
+    # the model's flat buffer ends in [sum w*mse, count, rows] (layers.UnfoldedSNMFModel.N_SCALARS = 3):
+    # the default must index the tail from its START (rows is not the count)
+    from drnmf_amd import dp, layers
+    assert dp.N_SCALARS == layers.UnfoldedSNMFModel.N_SCALARS == 3
+    flat = torch.tensor([2.0, 4.0, 6.0, 10.0, 4.0, 64.0], dtype=torch.float64)
+    g, loss = dp.normalised(flat)
+    np.testing.assert_allclose(g.numpy(), [0.5, 1.0, 1.5])
+    assert loss == 2.5
+    g2, loss2 = dp.normalised(flat[:5], n_scalars=2)
+    np.testing.assert_allclose(g2.numpy(), [0.5, 1.0, 1.5])
+    assert loss2 == 2.5
 
 
 def test_shard_covers_everything():
