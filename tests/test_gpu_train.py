@@ -111,6 +111,44 @@ def test_gradients_match_autograd(dev, cfg):
     assert checked >= 4
 
 
+@pytest.mark.parametrize("cfg", [
+    # T >= 200: the BPTT replays hipGraphs of up to 64 frames (cell_backward.hip: fpg_max) plus
+    # single-frame graphs for the remainder, the Gram form works on a ring of 2 x 64 frames of
+    # hoisted products (GRAM_TB) and, for few tiles, runs whole 64-frame blocks in one persistent
+    # launch: every one of those boundaries is crossed here, against fp64 autograd of the oracle
+    dict(B=3, T=200, F=21, r=6, K=2, untied=("log_D", "log_alph")),
+    dict(B=3, T=257, F=21, r=6, K=5, untied=("log_D", "log_alph")),
+    dict(B=18, T=211, F=33, r=8, K=5, untied=("log_D", "log_alph")),       # two row tiles, odd bin
+    dict(B=5, T=200, F=65, r=24, K=2, untied=("log_D", "log_alph"), untie_alph=True),
+    dict(B=4, T=322, F=40, r=10, K=3, untied=()),                          # tied, > 5 graph blocks
+])
+def test_long_sequence_gradients_match_autograd(dev, cfg):
+    """every gradient tensor of a LONG ragged batch against torch-CPU fp64 autograd
+    (independent of the device code), under both cell forms."""
+    cfg = dict(cfg)
+    K = cfg["K"]
+    model, P, wmask = _setup(**cfg)
+    assert wmask.sum(1).min() < cfg["T"] and wmask.sum(1).max() > 64      # ragged, beyond one block
+    model.compile(lr=1e-3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    flat = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(wmask)).clone()
+    torch.cuda.synchronize()
+    ref_loss, ref, cnt = _autograd(model, P, wmask, K, False)
+    assert abs(float(flat[-3]) - ref_loss) <= 2e-5 * abs(ref_loss) + 1e-9
+    assert float(flat[-2]) == cnt
+    name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
+    checked = 0
+    for n, _ in model._train_items:
+        g = model._gview[n].cpu().numpy()
+        r_ = ref[name_map.get(n, n)]
+        assert r_ is not None, n
+        scale = max(np.max(np.abs(r_)), 1e-12)
+        err = np.max(np.abs(g - r_)) / scale
+        assert err <= G_TOL, "%s: rel err %.3e (max ref %.3e)" % (n, err, scale)
+        checked += 1
+    assert checked >= 4
+
+
 def test_train_on_batch_matches_reference_adam_step_and_learns(dev):
     K = 3
     model, P, wmask = _setup(4, 8, 33, 8, K, ("log_D", "log_alph"))
