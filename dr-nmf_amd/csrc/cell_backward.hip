@@ -15,6 +15,7 @@
 // (repeated) output is handed to the last valid frame and the state gradient passes through.
 #include "cell_shared.h"
 #include "cell_gram.h"
+#include "cell_gram_persist.h"
 #include "gemm_nt.h"
 #include "gemm_tn.h"
 
@@ -135,8 +136,8 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
         s0 = row16_sum(s0);
         sp = row16_sum(sp);
         if (vn) {
-            ds[0] = a.u0d * dz0[0] + a.u0o * (s0 - dz0[0]) + sp;
-            ds[1] = a.u0d * dz0[1] + a.u0o * (s0 - dz0[1]) + sp;
+            ds[0] = bptt_state_grad(a.u0d, a.u0o, dz0[0], s0, sp);
+            ds[1] = bptt_state_grad(a.u0d, a.u0o, dz0[1], s0, sp);
         }
     }
     if (top) {
@@ -880,7 +881,7 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     const int nparts = W.gram ? W.numO : W.numA;
     L.off_z0s = take((size_t)2 * nparts * W.Bp * 4);
     L.off_dps = take((size_t)2 * nparts * W.Bp * 4);
-    L.off_cnt = take(256);
+    L.off_cnt = take(256 + 1024);   // frame counters + the persistent chains' sync lines
     L.off_dh0 = take((size_t)(W.Bp / ROWS) * W.Np * 4);
     L.off_dzall = take((size_t)BT * d->K * d->N * 4);
     // d r_k of every layer from the sequential pass; the Gram form recomputes one layer at a time
@@ -914,7 +915,9 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                                   float* d_log_alph, float* d_log_lam1, float* d_log_h0,
                                   void* stream_, float* prof_ms) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
-    int rc = validate_cell_desc(h, d);
+    int rc = persist_check_flag(h);
+    if (rc) return rc;
+    rc = validate_cell_desc(h, d);
     if (rc) return rc;
     // operand_f16: the forward ran on fp16 matrix-core operands; its BPTT is computed in fp32 from
     // the stored hiddens and the fp32 dictionary packings kept in the same prepared block
@@ -1070,6 +1073,28 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         return a;
     };
 
+    // Gram form with few tiles: the whole sequential pass as ONE launch of independent persistent
+    // chains, one per row tile (cell_gram_persist.h); same arithmetic as the graphs below.
+    const bool persist = W.gram && persist_shape_ok(numM, W.numO, K) && persist_admit(h, stream);
+    if (persist) {
+        GramPersistBwdArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.G = (const float*)(pb + PL.off_gram);
+        pa.g_stride = d->n_D == 1 ? 0 : (size_t)PL.Np * PL.Np;
+        pa.ia = (const float*)(pb + PL.off_inv_alpha);
+        pa.hall = hall; pa.d_out = d_out; pa.dz_all = dz_all;
+        pa.dGp[0] = dGp[0]; pa.dGp[1] = dGp[1];
+        pa.z0s_part = z0s; pa.dps_part = dps; pa.dh0_part = dh0_part; pa.dstate = dstate;
+        pa.valid = valid;
+        pa.bar = (unsigned*)(bw + L.off_cnt + 256);            // (zeroed by the memset above)
+        pa.host_flag = h->persist_flag;
+        pa.u0d = u0_diag; pa.u0o = u0_off; pa.uko = uk_off;
+        pa.B = B; pa.T = T; pa.N = N; pa.K = K; pa.Bp = W.Bp; pa.Np = W.Np; pa.numO = W.numO; pa.numM = numM;
+        void* kp[1] = {&pa};
+        DRNMF_HIP(h, hipLaunchKernel(pick_persist_bwd(W.Np / 16), dim3(8u * (unsigned)W.numO),
+                                     dim3(64 * (NW_G + 1)), kp, 0, stream));
+        persist_mark(h, stream);
+    }
     std::vector<uint64_t> key = {W.gram ? 0xB00Cull : 0xB00Bull, (uint64_t)B, (uint64_t)T, (uint64_t)F, (uint64_t)N,
                                  (uint64_t)K, (uint64_t)d->n_D, (uint64_t)(uintptr_t)params,
                                  (uint64_t)(uintptr_t)hall, (uint64_t)(uintptr_t)d_out,
@@ -1139,7 +1164,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     *out = entry->exec;
     return DRNMF_OK;
     };
-    {
+    if (!persist) {
         hipGraphExec_t exec_n = nullptr, exec_1 = nullptr;
         int32_t grc = get_graph(fpg_max, &exec_n);
         if (grc) return grc;
@@ -1151,7 +1176,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
             for (; t < T; ++t) DRNMF_HIP(h, hipGraphLaunch(exec_1, stream));
         }
     }
-    hipLaunchKernelGGL(bwd_edge_kernel, grid_a, dim3(256), 0, stream, ea);   // t = -1
+    if (!persist) hipLaunchKernelGGL(bwd_edge_kernel, grid_a, dim3(256), 0, stream, ea);   // t = -1
     hipLaunchKernelGGL(dlogh0_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dh0_part,
                        log_h0, d_log_h0, N, W.Np, numM);
     DRNMF_HIP(h, hipGetLastError());

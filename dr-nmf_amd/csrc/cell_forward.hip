@@ -36,6 +36,7 @@
 // latency; all of a wave's operand loads are issued before its first MFMA.
 #include "cell_shared.h"
 #include "cell_gram.h"
+#include "cell_gram_persist.h"
 #include "gemm_nt.h"
 
 #include <type_traits>
@@ -739,6 +740,10 @@ void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_h
 }  // namespace
 
 #ifdef DRNMF_TIMELINE
+extern "C" int32_t drnmf_debug_persist_timeline(void* out_host, size_t bytes) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_ptl),
+                               bytes < sizeof(g_ptl) ? bytes : sizeof(g_ptl)) == hipSuccess ? 0 : -3;
+}
 extern "C" int32_t drnmf_debug_timeline(void* out_host, size_t bytes) {
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_timeline),
                                bytes < sizeof(g_timeline) ? bytes : sizeof(g_timeline)) == hipSuccess
@@ -916,12 +921,12 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         *out = ge.exec;
         return DRNMF_OK;
     };
-    // At most 32 (row tile, output tile) pairs: the persistent single-XCD kernel (cell_gram.h), one
-    // launch per block of frames.  DRNMF_PERSIST=0 keeps the launch-per-layer-step graphs.
-    bool persist = numM * numO <= 32 && K >= 2;
-    if (const char* e = getenv("DRNMF_PERSIST")) persist = persist && atoi(e) != 0;
-    if (persist) {
-        unsigned* bar = (unsigned*)(tA + 32);
+    // Few tiles per row tile: every row tile runs as an independent persistent chain on its own XCD
+    // (cell_gram_persist.h), one launch per block of frames.  DRNMF_PERSIST=0, a shape outside its
+    // limits, or persistent launches of another stream still in flight on this handle keep the
+    // launch-per-layer-step graphs.
+    if (persist_shape_ok(numM, numO, K) && persist_admit(h, stream)) {
+        unsigned* bar = (unsigned*)(ws + W.off_t + 256);
         for (int j = 0; j * GRAM_TB < d->T; ++j) {
             const int t0 = j * GRAM_TB;
             const int t1 = (j + 1) * GRAM_TB < d->T ? (j + 1) * GRAM_TB : d->T;
@@ -940,19 +945,21 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             a.valid = valid;
             a.out = h_out;
             a.bar = bar;
+            a.host_flag = h->persist_flag;
             a.u0d = u0_diag; a.u0o = u0_off; a.uko = uk_off;
             a.B = d->B; a.T = d->T; a.N = d->N; a.K = K; a.Bp = W.Bp; a.Np = W.Np; a.numO = numO;
             a.numM = numM;
             a.out_width = d->return_all_hidden ? d->N * K : d->N;
             a.all_hidden = d->return_all_hidden ? 1 : 0;
             a.t0 = t0; a.nfr = t1 - t0;
-            DRNMF_HIP(h, hipMemsetAsync(bar, 0, 8, stream));   // counter + timeout flag
-            hipLaunchKernelGGL(gram_persist_kernel, dim3(8u * (unsigned)(numO * numM)),
-                               dim3(64 * NW_G), 0, stream, a);
-            DRNMF_HIP(h, hipGetLastError());
+            DRNMF_HIP(h, hipMemsetAsync(bar, 0, PERSIST_SYNC_BYTES, stream));   // arrivals, abort, XCC masks
+            void* kp[1] = {&a};
+            DRNMF_HIP(h, hipLaunchKernel(pick_persist_fwd(NAC), dim3(8u * (unsigned)numO),
+                                         dim3(64 * (NW_G + 1)), kp, 0, stream));
             int32_t rc = compute_block(j + 2);
             if (rc) return rc;
         }
+        persist_mark(h, stream);
         return DRNMF_OK;
     }
     // an even number of frames per graph (the frame parity of every node is then static) that
@@ -991,7 +998,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                                  int profile_frames, float* out_us,
                                  const float* initial_state = nullptr) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
-    int rc = validate_cell_desc(h, d);
+    int rc = persist_check_flag(h);
+    if (rc) return rc;
+    rc = validate_cell_desc(h, d);
     if (rc) return rc;
     if (d->divergence != DRNMF_DIV_ED)
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,

@@ -113,6 +113,14 @@ __device__ __forceinline__ float gram_contract(const float* __restrict__ G,
     return s;
 }
 
+// BPTT, bottom of a frame: gradient w.r.t. the state p that entered it, from dz_0 (this atom), the
+// row sum s0 of dz_0 and sp = uko * sum_{k>=1} rowsum(dz_k).  One fixed sequence of fused operations,
+// shared by bwd_edge_kernel and the persistent chain (cell_gram_persist.h): the compiler's own
+// choice of contractions differs between the two kernels and the results must not.
+__device__ __forceinline__ float bptt_state_grad(float u0d, float u0o, float dz0, float s0, float sp) {
+    return fmaf(u0d, dz0, fmaf(u0o, s0 - dz0, sp));
+}
+
 // One layer-step k >= 1 of one frame (FIRST: k == 1, carries layer 0; LAST: k == K-1).
 template <int GS, bool FIRST, bool LAST>
 __global__ void __launch_bounds__(64 * NW_G) gram_fwd_kernel(const GramFwdArgs a) {
@@ -350,7 +358,7 @@ __global__ void __launch_bounds__(64 * NW_G) gram_bwd_kernel(const GramBwdArgs a
     const float sk = row16_sum(dzk), s0 = row16_sum(dzn);
     if (ecol == 0) {
         const size_t po = ((size_t)(cnt & 1) * a.numO + ot) * a.Bp + rg;
-        a.dps_part[po] += a.uko * sk;
+        a.dps_part[po] = fmaf(a.uko, sk, a.dps_part[po]);
         if (a.k == 1) a.dz0s_part[po] = s0;
     }
 }
@@ -364,244 +372,6 @@ unpack_scaled_kernel(const float* __restrict__ Dp, const float* __restrict__ ia,
     const int f = (int)(i / Np), n = (int)(i % Np);
     out[i] = ia[n] * Dp[((size_t)(f >> 4) * (Np / 16) + (n >> 4)) * 256 +
                         (((n & 15) >> 2) * 16 + (f & 15)) * 4 + (n & 3)];
-}
-
-// ---------------------------------------------------------------------------------------------
-// Persistent form for at most 32 (row tile, output tile) pairs -- B <= 16 with N <= 512, B <= 32 with
-// N <= 256 --: the whole
-// (frame, layer) chain of a block of frames in ONE launch.  Such a shape -- single-utterance /
-// small-batch serving, BASELINE configs[0] -- puts numO <= 32 workgroups on the chip and is nothing
-// but launch latency (1.9 us per layer-step).  The workgroups all sit on ONE XCD (workgroup ids go
-// round the 8 XCDs, so the grid is 8 x numO and only ids = 0 mod 8 work): the grid barrier's counter
-// and the exchanged activations never leave that XCD's L2 -- tools/probes/xcd_local_probe.hip:
-// 0.5 us per barrier, 1.56 us per exchange phase against 2.36 us with a launch per phase.
-// Everything one workgroup writes and another reads inside the launch (h ping-pong, q, row-sum
-// partials, psum) goes through L1-bypassing (sc1) stores and loads + one agent-scope counter: correct
-// on ANY placement of the workgroups, fast when they share an XCD.  Same arithmetic, in the same
-// order, as gram_fwd_kernel: results are bit-identical to the launch-per-layer-step form.
-struct GramPersistArgs {
-    const float* G;          // packed G of layer 0's slot; layer k at G + k * g_stride (0: tied)
-    size_t g_stride;
-    const float* ia;         // [K][Np]
-    const float* Cp;
-    float* hb[2];
-    float* qb[2];
-    float* state;
-    float* rs_part;
-    float* psum;
-    float* psum_all;
-    const unsigned char* valid;
-    float* out;
-    unsigned* bar;           // zeroed before the launch
-    float u0d, u0o, uko;
-    int B, T, N, K, Bp, Np, numO, numM, out_width, all_hidden;
-    int t0, nfr;
-};
-
-__device__ __forceinline__ float ld1_sc1(const float* p) {
-    const unsigned u = __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-__device__ __forceinline__ void st1_sc1(float* p, float v) {
-    unsigned u;
-    memcpy(&u, &v, 4);
-    __hip_atomic_store((unsigned*)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);   // aux 16 = sc1
-    f32x4 v;
-    memcpy(&v, &raw, 16);
-    return v;
-}
-
-__global__ void __launch_bounds__(64 * NW_G) gram_persist_kernel(const GramPersistArgs a) {
-    if ((blockIdx.x & 7) != 0) return;
-    __shared__ __attribute__((aligned(16))) float red[NW_G * 16 * 17];
-    __shared__ float part[32][17];
-    __shared__ float ps16[16], psv[16];
-    const int wg = blockIdx.x >> 3;                         // < numM * numO (grid = 8 * that)
-    const int m = wg / a.numO, ot = wg - m * a.numO;        // row tile, output tile
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l = tid & 63, j = l & 15, q = l >> 4;
-    const int NAC = a.Np / 16;
-    const bool ethr = tid < 256;
-    const int erow = (tid & 255) >> 4, ecol = tid & 15;
-    const int rg = m * 16 + erow, n = ot * 16 + ecol;
-    const size_t hoff = ((size_t)m * NAC + ot) * 256 + hp_pos(erow, ecol);
-    const size_t cstride = (size_t)a.Bp * a.Np;
-    constexpr int RING = 2 * GRAM_TB;
-    const int clast = NAC - 1;
-    const int per_wave = (NAC - w + NW_G - 1) / NW_G;        // <= 4 (NAC <= 32)
-    const unsigned abytes = (unsigned)(cstride * 4);
-    const int KL = a.K - 1, nphase = a.nfr * KL;
-
-    // Operands that no other workgroup writes inside this launch -- the G tile, c_k[t], 1/alpha,
-    // the validity flag, this thread's own state element -- are requested one phase AHEAD, before
-    // the barrier, so that after the barrier only the exchanged activations (sc1, L2 hits) are on
-    // the critical path.
-    // (the phase -> (frame, layer) bookkeeping is incremental and the address parts that do not
-    // change are formed once: in the in-kernel timeline the prefetch's integer division and 64-bit
-    // address arithmetic were 0.5 us of a 2.6-us phase)
-    f32x4 bvN[4];
-    float ckN = 0.f, cnextN = 0.f, iavN = 0.f, stoldN = 0.f;
-    bool vldN = true;
-    const float* Gl = a.G + (size_t)ot * NAC * 256 + l * 4;      // + k * g_stride + 256 * c
-    int gc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int c = w + NW_G * g;
-        gc[g] = 256 * (c > clast ? clast : c);
-    }
-    const float* ial = a.ia + n;                                   // + k * Np
-    const float* cpl = a.Cp + hoff;                                // + ((t mod RING) * K + k) * cstride
-    const unsigned char* vl = a.valid + rg;                        // + t * Bp
-    auto prefetch = [&](int fN, int kN) {                          // operands of (frame t0 + fN, layer kN)
-        if (fN >= a.nfr) return;
-        const int t = a.t0 + fN;
-        const float* Gk = Gl + (size_t)kN * a.g_stride;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bvN[g] = *(const f32x4*)(Gk + gc[g]);
-        if (ethr) {
-            iavN = ial[(size_t)kN * a.Np];
-            ckN = cpl[(size_t)((t & (RING - 1)) * a.K + kN) * cstride];
-            vldN = vl[(size_t)t * a.Bp] != 0;
-            if (kN == a.K - 1) {
-                const int tn = t + 1 < a.T ? t + 1 : t;
-                cnextN = cpl[(size_t)((tn & (RING - 1)) * a.K) * cstride];
-                stoldN = a.state[hoff];
-            }
-        }
-    };
-    prefetch(0, 1);
-
-    int f = 0, k = 1;
-    for (int p = 0; p < nphase; ++p) {
-        const int t = a.t0 + f, par = t & 1;
-        const bool first = k == 1, last = k == a.K - 1;
-        const float* a_in = first ? a.qb[par] : a.hb[(k - 1) & 1];
-        // ---- exchanged operands (sc1) -----------------------------------------------------------
-        __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_in, 0, abytes, 0x00020000);
-        f32x4 av[4], bv[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            int c = w + NW_G * g;
-            c = c > clast ? clast : c;
-            av[g] = ld4_sc1(arsrc, (unsigned)((((size_t)m * NAC + c) * 256 + l * 4) * 4));
-            bv[g] = bvN[g];
-        }
-        float hraw = 0.f, psl = 0.f, rsum = 0.f;
-        const float iav = iavN, ck = ckN, cnext = cnextN, st_old = stoldN;
-        const bool vld = vldN;
-        if (first) {
-            const int row = tid & 15, pt = tid >> 4;        // 32 parts
-            const float* rp = a.rs_part + (size_t)par * a.numO * a.Bp + m * 16 + row;
-            for (int b2 = pt; b2 < a.numO; b2 += 32) rsum += ld1_sc1(rp + (size_t)b2 * a.Bp);
-        }
-        if (ethr) {
-            hraw = ld1_sc1(a_in + hoff);
-            if (!first) psl = ld1_sc1(a.psum + rg);
-        }
-        if (first) {
-            part[tid >> 4][tid & 15] = rsum;
-            __syncthreads();
-            if (tid < 16) {
-                float tot = 0.f;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) tot += part[i][tid];
-                ps16[tid] = a.u0o * tot;
-                psv[tid] = tot;
-            }
-            __syncthreads();
-        }
-        // ---- contraction (as gram_contract: waves split the input atoms, fixed-order reduce) ------
-        const float addv = first ? ps16[j] : 0.f;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const bool ok = g < per_wave;
-            f32x4 a4 = av[g];
-            if (first) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a4[e] = fmaxf(a4[e] + addv, 0.f);
-            }
-#pragma unroll
-            for (int sI = 0; sI < 4; ++sI) {
-                const float a1 = ok ? a4[sI] : 0.f;
-                if (sI & 1) acc1 = mfma16(a1, bv[g][sI], acc1);
-                else acc0 = mfma16(a1, bv[g][sI], acc0);
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) red[(w * 16 + 4 * q + v) * 17 + j] = acc0[v] + acc1[v];
-        __syncthreads();
-        if (ethr) {
-            float s = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < NW_G; ++ww) s += red[(ww * 16 + erow) * 17 + ecol];
-            // ---- update epilogue (as gram_fwd_kernel) -----------------------------------------
-            const float ps = first ? psv[erow] : psl;
-            if (first && ot == 0 && ecol == 0) {
-                st1_sc1(a.psum + rg, ps);
-                a.psum_all[(size_t)t * a.Bp + rg] = ps;
-            }
-            float hprev = hraw;
-            if (first) hprev = fmaxf(hprev + a.u0o * ps, 0.f);
-            const float pre = hprev - s * iav + ck + a.uko * ps;
-            const float hn = fmaxf(pre, 0.f);
-            if (rg < a.B && n < a.N) {
-                float* orow = a.out + ((size_t)rg * a.T + t) * a.out_width;
-                if (a.all_hidden) {
-                    if (first) {
-                        float o0 = hprev;
-                        if (!vld) o0 = (t > 0) ? orow[n - (ptrdiff_t)a.out_width] : 0.f;
-                        orow[n] = o0;
-                    }
-                    float o = hn;
-                    const int off = k * a.N + n;
-                    if (!vld) o = (t > 0) ? orow[off - (ptrdiff_t)a.out_width] : 0.f;
-                    orow[off] = o;
-                } else if (last) {
-                    float o = hn;
-                    if (!vld) o = (t > 0) ? orow[n - (ptrdiff_t)a.out_width] : 0.f;
-                    orow[n] = o;
-                }
-            }
-            if (last) {
-                const float st = vld ? hn : st_old;
-                a.state[hoff] = st;
-                const float rs = row16_sum(st);
-                if (ecol == 0)
-                    st1_sc1(a.rs_part + ((size_t)(par ^ 1) * a.numO + ot) * a.Bp + rg, rs);
-                st1_sc1(a.qb[par ^ 1] + hoff, (a.u0d - a.u0o) * st + cnext);
-            } else {
-                st1_sc1(a.hb[k & 1] + hoff, hn);
-            }
-        }
-        // ---- grid barrier over the numO workgroups; the next phase's private operands are requested
-        // between arriving and waiting (behind the arrival: the vmcnt(0) in front of it must cover the
-        // phase's stores only) --------------------------------------------------------------------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (last) { ++f; k = 1; } else ++k;                      // the next phase
-        prefetch(f, k);
-        if (tid == 0) {
-            // (bounded: ~2 s.  All numO <= 32 workgroups of this launch are resident at once on any
-            // MI355X partition, so the bound is never reached; should it be, the launch runs on
-            // with a wrong result and says so in bar[1] rather than hang the device)
-            unsigned spins = 0;
-            while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                   (unsigned)(p + 1) * (unsigned)(a.numO * a.numM)) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) { a.bar[1] = 1u; break; }
-            }
-        }
-        __syncthreads();
-    }
 }
 
 void* pick_gram_fwd(int NAC, bool first, bool last) {

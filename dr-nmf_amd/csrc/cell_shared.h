@@ -473,7 +473,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         // forward clears the buffer once per call)
         W.off_rsave = take((size_t)(d->K - 1) * d->B * d->T * W.Fp * 4);
     }
-    W.off_t = take(256);
+    W.off_t = take(256 + 1024);     // frame counters (256 B) + the persistent chains' sync lines (cell_gram_persist.h)
     W.total = o;
     return W;
 }

@@ -68,7 +68,20 @@ struct drnmf_handle_s {
     // RCCL communicator (comm.hip): one rank per handle / GPU
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    // persistent small-shape chains (cell_gram_persist.h): a host-mapped word the kernels raise when
+    // a chain times out, and the stream / completion event of the most recent call that launched
+    // them (two such launches in flight on DIFFERENT streams could each hold CUs the other's
+    // workgroups need: the second call takes the launch-per-layer-step graphs instead)
+    unsigned* persist_flag = nullptr;
+    hipEvent_t persist_done = nullptr;
+    hipStream_t persist_stream = nullptr;
+    bool persist_pending = false;
 };
+
+// cell_gram_persist.h support (params.hip)
+int32_t persist_check_flag(drnmf_handle_t h);             // DRNMF_ERR_TIMEOUT once after a chain gave up
+bool persist_admit(drnmf_handle_t h, hipStream_t stream); // false: another stream's persistent launches may still run
+void persist_mark(drnmf_handle_t h, hipStream_t stream);  // after a call's persistent launches
 
 // Bounded graph cache shared by the forward / backward / dense cells.  Evicting an entry must not
 // synchronise the device (ABI contract: calls only enqueue): the evicted executable may still be

@@ -38,8 +38,44 @@ extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
     drnmf_handle_t h = new (std::nothrow) drnmf_handle_s();
     if (!h) return DRNMF_ERR_HIP;
     h->device = device;
+    // (mapped + coherent: a kernel's system-scope store is seen by the host without a synchronise)
+    if (hipHostMalloc((void**)&h->persist_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess)
+        *h->persist_flag = 0u;
+    else {
+        h->persist_flag = nullptr;
+        (void)hipGetLastError();
+    }
     *out = h;
     return DRNMF_OK;
+}
+
+int32_t persist_check_flag(drnmf_handle_t h) {
+    if (!h->persist_flag || *(volatile unsigned*)h->persist_flag == 0u) return DRNMF_OK;
+    *(volatile unsigned*)h->persist_flag = 0u;
+    DRNMF_FAIL(h, DRNMF_ERR_TIMEOUT,
+               "a persistent small-shape launch of an earlier call on this handle timed out waiting "
+               "for its own workgroups (not resident together: other persistent kernels on this GPU?); "
+               "that call's result is invalid -- rerun it, or set DRNMF_PERSIST=0");
+}
+
+bool persist_admit(drnmf_handle_t h, hipStream_t stream) {
+    if (!h->persist_flag) return false;                  // no way to report a timeout: never take the path
+    if (!h->persist_pending || h->persist_stream == stream) return true;
+    if (hipEventQuery(h->persist_done) == hipSuccess) { h->persist_pending = false; return true; }
+    (void)hipGetLastError();                              // hipErrorNotReady is not an error
+    return false;
+}
+
+void persist_mark(drnmf_handle_t h, hipStream_t stream) {
+    if (!h->persist_done && hipEventCreateWithFlags(&h->persist_done, hipEventDisableTiming) != hipSuccess) {
+        h->persist_done = nullptr;
+        (void)hipGetLastError();
+        return;
+    }
+    if (hipEventRecord(h->persist_done, stream) == hipSuccess) {
+        h->persist_stream = stream;
+        h->persist_pending = true;
+    }
 }
 
 extern "C" int32_t drnmf_comm_destroy(drnmf_handle_t h);
@@ -59,6 +95,8 @@ extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
     }
     for (auto& e : h->fft_event)
         if (e) (void)hipEventDestroy(e);
+    if (h->persist_done) (void)hipEventDestroy(h->persist_done);
+    if (h->persist_flag) (void)hipHostFree(h->persist_flag);
     delete h;
     return DRNMF_OK;
 }

@@ -35,7 +35,10 @@ enum {
     DRNMF_ERR_UNSUPPORTED = -2,
     DRNMF_ERR_HIP = -3,
     DRNMF_ERR_WORKSPACE = -4,
-    DRNMF_ERR_RCCL = -5
+    DRNMF_ERR_RCCL = -5,
+    DRNMF_ERR_TIMEOUT = -6  /* a persistent small-shape launch of an EARLIER call on this handle gave up
+                             * waiting for its own workgroups (they were not resident together); that
+                             * call's output is invalid.  Reported by the next cell call on the handle. */
 };
 
 /* divergence selector for the frame-parallel ISTA / MU kernels */

@@ -122,7 +122,7 @@ def test_two_rank_product_training_equals_single_process(dev, tmp_path):
     assert os.path.exists(tmp_path / "ck_rank0.npz") and not os.path.exists(tmp_path / "ck_rank1.npz")
 
     # one process, the same global batches: step 0 = sequences 0-7 (rank 0) + 9-16 (rank 1),
-    # step 1 = sequence 8 (+ rank 1's zero-weight filler), two epochs, rank 0's initial weights
+    # step 1 = sequence 8 (rank 1 joins the reduction with zeros), two epochs, rank 0's initial weights
     P, w = _problem()
     model = _model(seed=100)
     model.compile(lr=1e-2, loss_norm="keras204")
@@ -130,10 +130,9 @@ def test_two_rank_product_training_equals_single_process(dev, tmp_path):
     losses = []
     for _ in range(2):
         a = model.train_on_batch(P["X"][g0], P["Y"][g0], w[g0])
-        # the filler rows count as frames of the batch (p = valid / frames)
-        g1 = [8] + list(range(9, 17))
-        w1 = np.concatenate([w[[8]], np.zeros((8, T), np.float32)])
-        b = model.train_on_batch(P["X"][g1], P["Y"][g1], w1)
+        # rank 1's filler batch carries zero weights AND zero rows (p = valid / frames of
+        # loss_norm='keras204' is the global batch's: sequence 8 alone)
+        b = model.train_on_batch(P["X"][[8]], P["Y"][[8]], w[[8]])
         losses.append(0.5 * (a + b))
     for k, ref in zip(keys, model.get_weights()):
         got = z0[k]
@@ -199,10 +198,14 @@ def test_gram_and_factored_forms_agree(dev, monkeypatch):
     dict(B=3, T=5, F=21, r=250, K=5),            # N = 500: 32 output tiles, the largest eligible
     dict(B=32, T=70, F=33, r=100, K=3, ah=True), # two row tiles x 13 output tiles
     dict(B=20, T=9, F=65, r=128, K=4),           # two row tiles x 16 output tiles = 32 workgroups
+    dict(B=32, T=130, F=65, r=250, K=3),         # two chains x 32 output tiles, > 2 blocks of frames
+    dict(B=128, T=66, F=33, r=24, K=5, ah=True), # eight chains (one per XCD) x 2 tiles, all-hidden
+    dict(B=100, T=10, F=21, r=100, K=2),         # seven chains, the last with 4 live rows
 ])
 def test_persistent_gram_kernel_is_bit_identical(dev, monkeypatch, cfg):
-    """gram_persist_kernel (cell_gram.h): one launch per block of frames with an in-kernel barrier
-    between layer-steps, workgroups on one XCD -- the same arithmetic in the same order as the
+    """gram_persist_kernel (cell_gram_persist.h): one launch per block of frames, every 16-row tile an
+    independent chain of <= 32 workgroups on its own XCD with an in-kernel barrier between
+    layer-steps -- the same arithmetic in the same order as the
     launch-per-layer-step Gram kernels, so the two must agree bit for bit (ragged lengths, a masked
     first frame, all-hidden output, stateful continuation); both are checked against the fp64
     oracle by the parity suites."""
@@ -225,3 +228,77 @@ def test_persistent_gram_kernel_is_bit_identical(dev, monkeypatch, cfg):
     assert np.array_equal(outs["0"], outs["1"])
     ref = TP._oracle_cell(P, alt, labels, K, return_all_hidden=ah)
     assert np.max(np.abs(outs["1"] - ref)) <= TP.H_TOL * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, T=150, F=21, r=6, K=2),             # one chain, K = 2: edge + one layer-step per frame
+    dict(B=7, T=70, F=33, r=50, K=3),             # ragged, 7 output tiles
+    dict(B=32, T=131, F=65, r=100, K=5),          # the shipped r = 100 batch: two chains x 13 tiles
+    dict(B=128, T=20, F=33, r=24, K=4),           # eight chains
+    dict(B=5, T=9, F=21, r=250, K=3),             # N = 500: 32 tiles per chain
+])
+def test_persistent_gram_bptt_is_bit_identical(dev, monkeypatch, cfg):
+    """gram_persist_bwd_kernel (cell_gram_persist.h): the BPTT's whole sequential pass in one launch of
+    independent per-row-tile chains, against bwd_edge_kernel + gram_bwd_kernel replayed from
+    hipGraphs -- the same arithmetic in the same order: every gradient and the loss bit for bit (the
+    graph form is checked against fp64 autograd of the oracle in tests/test_gpu_train.py, T up to
+    322)."""
+    from drnmf_amd import layers
+    B, T, F, r, K = cfg["B"], cfg["T"], cfg["F"], cfg["r"], cfg["K"]
+    P = O.synth_problem(B, T, F, r, seed=B + T, ragged=True, density=0.15)
+    P["X"][B - 1, 0] = -1.0                       # a masked first frame
+    P["Y"][B - 1, 0] = -1.0
+    N = 2 * r
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph", "log_lam1"])
+    w = (P["X"] != -1.0).any(-1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DRNMF_GRAM", "1")
+        monkeypatch.setenv("DRNMF_PERSIST", mode)
+        np.random.seed(5)
+        model = layers.build_unfolded_snmf(p, device=dev)
+        model.compile(lr=1e-3)
+        res[mode] = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(w)).cpu().numpy().copy()
+    assert np.isfinite(res["1"]).all() and np.abs(res["1"][:-3]).max() > 0
+    assert np.array_equal(res["0"], res["1"])
+
+
+def test_persistent_chains_from_concurrent_streams(dev, monkeypatch):
+    """persistent launches issued from several streams at once.  The handle admits one
+    stream's persistent launches at a time (the others take the launch-per-layer-step graphs, which
+    compute the same bits), so four concurrent streams must all finish, agree with a serial run, and
+    leave no timeout flag behind."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as TP
+    monkeypatch.setenv("DRNMF_GRAM", "1")
+    monkeypatch.setenv("DRNMF_PERSIST", "1")
+    B, T, F, r, K = 16, 192, 33, 100, 4
+    probs = [TP._problem(B, T, F, r, K, untied=("log_D", "log_alph"), ragged=True, seed=40 + i)
+             for i in range(4)]
+    from drnmf_amd import ops
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    serial, prepared = [], []
+    for P, alt, labels, N in probs:
+        h, params, desc = TP._run_cell(dev, P, alt, labels, N, K)
+        serial.append(h.copy())
+        prepared.append((t(P["X"]), params, desc, t(P["log_h0"]), O.u_scalars(alt, np.float32)))
+    # one host thread (a handle is not re-entrant), four streams: the launches of the four calls
+    # overlap on the GPU
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    outs = [None] * 4
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for i, (x, params, desc, lh0, u) in enumerate(prepared):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = ops.cell_forward(x, -1.0, params, desc, lh0, u)
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert np.array_equal(outs[i].cpu().numpy(), serial[i]), i
+    # and the handle still works (no timeout was recorded)
+    again = TP._run_cell(dev, *probs[0], K)[0]
+    assert np.array_equal(again, serial[0])

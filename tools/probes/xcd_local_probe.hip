@@ -12,6 +12,7 @@
 //     mode 0: sc1 (L1-bypassing) stores / loads + one agent-scope counter (correct on any placement)
 //     mode 1: the same exchange over kernel boundaries: one launch of W workgroups per phase (hipGraph)
 //     mode 2: mode 0 with empty phases (the barrier alone)
+//     mode 3..7: PLAIN producer stores (line kept dirty in the shared L2) + sc1 / nt / sc0 / plain / sc0 sc1 loads
 // Build: hipcc --offload-arch=gfx950:xnack- -O3 -o xcd_local_probe xcd_local_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -36,6 +37,10 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
     float v; memcpy(&v, &bits, 4); return v;
 }
 
+// PLAIN: the producers' stores are plain (the line stays, dirty, in the XCD's L2; the store's vmcnt
+// acknowledgement = it reached the L2); AUX: cache-policy bits of the consumers' loads (16 = sc1,
+// 2 = nt, 1 = sc0, 0 = plain).  Only valid when every participant shares one XCD (one L2).
+template <bool PLAIN, int AUX, bool L2ATOM = false>
 __global__ void __launch_bounds__(NT) persistent_kernel(float* E0, float* E1, Sync* S, int W, int total,
                                                         int phases, int empty) {
     if ((blockIdx.x & 7) != 0) return;
@@ -50,11 +55,17 @@ __global__ void __launch_bounds__(NT) persistent_kernel(float* E0, float* E1, Sy
     for (int p = 0; p < phases; ++p) {
         float* E = (p & 1) ? E1 : E0;
         if (!empty)
-            for (int i = b * per + tid; i < (b + 1) * per && i < total; i += NT) st_sc1(E + i, val_of(p, i));
+            for (int i = b * per + tid; i < (b + 1) * per && i < total; i += NT) {
+                if (PLAIN) E[i] = val_of(p, i);
+                else st_sc1(E + i, val_of(p, i));
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            add_rlx(&S->cnt[0], 1);
+            // L2ATOM: the arrival is a workgroup-scope atomic (no sc1: executed in the XCD's L2, not
+            // sent to memory) -- only valid when every participant shares that L2
+            if (L2ATOM) __hip_atomic_fetch_add(&S->cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else add_rlx(&S->cnt[0], 1);
             unsigned spins = 0;
             while (ld_rlx(&S->cnt[0]) < (unsigned)(p + 1) * W) {
                 __builtin_amdgcn_s_sleep(1);
@@ -67,7 +78,7 @@ __global__ void __launch_bounds__(NT) persistent_kernel(float* E0, float* E1, Sy
             __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)E, 0, total * 4, 0x00020000);
             u32x4 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k * NT + tid) * 16, 0, 16);
+            for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k * NT + tid) * 16, 0, AUX);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -137,9 +148,16 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0, st));
         if (mode == 1) CK(hipGraphLaunch(gexec, st));
         else {
-            int empty = mode == 2;
+            int empty = mode == 2 || mode == 9;
             void* kp[7] = {&E0, &E1, &S, &Wv, &total, &ph, &empty};
-            CK(hipLaunchKernel((void*)&persistent_kernel, dim3(8 * W), dim3(NT), kp, 0, st));
+            void* f = (void*)&persistent_kernel<false, 16>;
+            if (mode == 3) f = (void*)&persistent_kernel<true, 16>;
+            if (mode == 4) f = (void*)&persistent_kernel<true, 2>;
+            if (mode == 5) f = (void*)&persistent_kernel<true, 1>;
+            if (mode == 6) f = (void*)&persistent_kernel<true, 0>;
+            if (mode == 7) f = (void*)&persistent_kernel<true, 17>;
+            if (mode == 8 || mode == 9) f = (void*)&persistent_kernel<true, 16, true>;
+            CK(hipLaunchKernel(f, dim3(8 * W), dim3(NT), kp, 0, st));
         }
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
@@ -154,6 +172,6 @@ int main(int argc, char** argv) {
         }
     }
     printf("W %d, %d x %d fp32 exchanged, mode %d (%s): %.2f us per phase; wrong words %u, timeouts %u\n", W, ROWS,
-           N, mode, mode == 1 ? "one launch per phase" : mode == 2 ? "persistent, empty phases: barrier alone" : "persistent, participants on one XCD", best * 1e3f / phases, err, tmo);
+           N, mode, mode == 1 ? "one launch per phase" : mode == 2 ? "persistent, empty phases: barrier alone" : mode == 3 ? "persistent, PLAIN stores + sc1 loads" : mode == 4 ? "persistent, PLAIN stores + nt loads" : mode == 5 ? "persistent, PLAIN stores + sc0 loads" : mode == 6 ? "persistent, PLAIN stores + plain loads" : mode == 7 ? "persistent, PLAIN stores + sc0 sc1 loads" : mode == 8 ? "persistent, PLAIN stores + sc1 loads, L2 (workgroup-scope) arrival atomics" : mode == 9 ? "barrier alone, L2 arrival atomics" : "persistent, participants on one XCD", best * 1e3f / phases, err, tmo);
     return (err || tmo) ? 2 : 0;
 }
