@@ -21,22 +21,12 @@
 
 namespace {
 
-constexpr int TN_SPLITS = 16;   // upper bound (partial buffers); the count per shape: tn_splits()
+constexpr int TN_SPLITS = 64;   // upper bound; the count per shape (and the partial buffers' size): tn_splits()
 
 // Split-K count of the time-batched weight-gradient GEMMs: tiles x splits workgroups run in rounds
 // of 512 (2 per CU); pick the count that minimises rounds / splits (8 splits at the C2 shape made
 // 640 workgroups = 2 rounds, 6 make 480 = 1 round: 3.8 -> 2.6 ms per GEMM).
-static int tn_splits(int M, int N, int64_t Kdim) {
-    const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
-    int best = 1;
-    double best_cost = 1e30;
-    for (int s = 1; s <= TN_SPLITS; ++s) {
-        if (Kdim / s < 256) break;                      // keep the k loop of a split long
-        const double cost = (double)((tiles * s + 511) / 512) / s;
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
-    }
-    return best;
-}
+static int tn_splits(int M, int N, int64_t Kdim) { return gemm_tn::pick_splits(M, N, Kdim, TN_SPLITS); }
 constexpr int CR_SPLITS = 256;
 
 struct EdgeArgs {
@@ -891,7 +881,10 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     L.off_dn = take((size_t)W.Fp * W.Np * 4);
     L.off_dpia = take(W.gram ? 0 : (size_t)d->K * W.Fp * W.Np * 4);
     L.off_dnia = take(W.gram ? (size_t)W.Fp * W.Np * 4 : 0);
-    L.off_P = take((size_t)TN_SPLITS * W.Fp * W.Np * 4);
+    {
+        const bool odd = (d->F % 16 == 1) && d->F > 16;
+        L.off_P = take((size_t)tn_splits(odd ? d->F - 1 : W.Fp, d->N, BT) * W.Fp * W.Np * 4);
+    }
     L.off_cr = take((size_t)CR_SPLITS * CR_SLOTS * W.Np * 4);
     L.off_dq = take((size_t)2 * MAX_TAIL * W.Bp * W.numA * 4);
     L.off_dqsum = take((size_t)MAX_TAIL * W.Bp * 4);

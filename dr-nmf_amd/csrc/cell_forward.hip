@@ -623,12 +623,18 @@ store_state_kernel(const float* __restrict__ state, float* __restrict__ out, int
 __global__ void __launch_bounds__(256)
 seen_kernel(const unsigned char* __restrict__ valid, unsigned char* __restrict__ seen, int T,
             int Bp) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    // one wave per row, 64 frames per step: an exclusive prefix-OR from the ballot of the step (a
+    // thread per row walking T dependent loads took 53 us at T = 500)
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     if (row >= Bp) return;
-    unsigned char s = 0;
-    for (int t = 0; t < T; ++t) {
-        seen[(size_t)t * Bp + row] = s;
-        s |= valid[(size_t)t * Bp + row];
+    bool carry = false;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + l;
+        const bool v = t < T && valid[(size_t)t * Bp + row] != 0;
+        const unsigned long long m = __ballot(v);
+        const unsigned long long below = m & ((1ull << l) - 1ull);            // lanes < l
+        if (t < T) seen[(size_t)t * Bp + row] = (carry || below != 0ull) ? 1 : 0;
+        carry = carry || m != 0ull;
     }
 }
 
@@ -796,7 +802,7 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                            stream, x, (float*)(ws + W.off_xp), valid, mask_value, d->B, d->T, d->F,
                            W.Bp, W.Fp);
-        hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 255) / 256), dim3(256), 0, stream, valid,
+        hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream, valid,
                            (unsigned char*)(ws + W.off_seen), d->T, W.Bp);
         if (initial_state)
             hipLaunchKernelGGL(load_state_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream,
@@ -808,19 +814,22 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         DRNMF_HIP(h, hipGetLastError());
         // padded batch rows of c are never produced by the GEMM: keep them finite
         if (W.Bp != d->B)
-            DRNMF_HIP(h, hipMemsetAsync(Cp, 0, (size_t)2 * GRAM_TB * K * cstride * 4, stream));
+            DRNMF_HIP(h, hipMemsetAsync(Cp, 0, (size_t)W.cp_frames * K * cstride * 4, stream));
     }
     // c_k of one block of GRAM_TB frames into its ring slot (stream-ordered behind the chain of the
     // block that used the slot before)
+    const bool cp_full = W.cp_frames == d->T;       // every frame's c_k resident: one product up front
+    const int cp_mask = cp_full ? 0x7fffffff : 2 * GRAM_TB - 1;
     auto compute_block = [&](int j) -> int32_t {
-        const int t0 = j * GRAM_TB;
+        if (cp_full && j > 0) return DRNMF_OK;
+        const int t0 = cp_full ? 0 : j * GRAM_TB;
         if (t0 >= d->T) return DRNMF_OK;
-        const int tbc = d->T - t0 < GRAM_TB ? d->T - t0 : GRAM_TB;
+        const int tbc = cp_full ? d->T : (d->T - t0 < GRAM_TB ? d->T - t0 : GRAM_TB);
         const size_t tot = (size_t)d->B * tbc * W.Fp;
         hipLaunchKernelGGL(gather_block_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                            stream, x, xpad, d->B, d->T, d->F, W.Fp, t0, tbc);
         DRNMF_HIP(h, hipGetLastError());
-        float* slot = Cp + (size_t)(t0 & (2 * GRAM_TB - 1)) * K * cstride;
+        float* slot = Cp + (size_t)(t0 & cp_mask) * K * cstride;
         if (d->n_D == K && K > 1) {      // untied: all layers in one product (EpiCPackAll)
             gemm::Operands g{xpad, DnT_of(0), (int64_t)d->B * tbc, K * W.Np, W.Fp, W.Fp, W.Fp};
             EpiCPackAll epi{slot, ia_of(0), b_of(0), tbc, K, NAC, W.Np, cstride};
@@ -877,6 +886,7 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.all_hidden = d->return_all_hidden ? 1 : 0;
         a.par = par;
+        a.cp_mask = cp_mask;
         return a;
     };
     std::vector<uint64_t> key = {
@@ -927,9 +937,10 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     // launch-per-layer-step graphs.
     if (persist_shape_ok(numM, numO, K) && persist_admit(h, stream)) {
         unsigned* bar = (unsigned*)(ws + W.off_t + 256);
-        for (int j = 0; j * GRAM_TB < d->T; ++j) {
-            const int t0 = j * GRAM_TB;
-            const int t1 = (j + 1) * GRAM_TB < d->T ? (j + 1) * GRAM_TB : d->T;
+        const int tb = cp_full ? d->T : GRAM_TB;          // frames per launch
+        for (int j = 0; j * tb < d->T; ++j) {
+            const int t0 = j * tb;
+            const int t1 = (j + 1) * tb < d->T ? (j + 1) * tb : d->T;
             GramPersistArgs a;
             memset(&a, 0, sizeof(a));
             a.G = (const float*)(pb + L.off_gram);
@@ -952,10 +963,12 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             a.out_width = d->return_all_hidden ? d->N * K : d->N;
             a.all_hidden = d->return_all_hidden ? 1 : 0;
             a.t0 = t0; a.nfr = t1 - t0;
+            a.cp_mask = cp_mask;
             DRNMF_HIP(h, hipMemsetAsync(bar, 0, PERSIST_SYNC_BYTES, stream));   // arrivals, abort, XCC masks
             void* kp[1] = {&a};
             DRNMF_HIP(h, hipLaunchKernel(pick_persist_fwd(NAC), dim3(8u * (unsigned)numO),
-                                         dim3(64 * (NW_G + 1)), kp, 0, stream));
+                                         dim3(64 * (NW_G + 1)), kp,
+                                         persist_fwd_lds(K, d->return_all_hidden != 0), stream));
             int32_t rc = compute_block(j + 2);
             if (rc) return rc;
         }
@@ -1043,7 +1056,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         const size_t rows = (size_t)d->T * W.Bp;
         hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                            stream, x, xp, valid, mask_value, d->B, d->T, d->F, W.Bp, W.Fp);
-        hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 255) / 256), dim3(256), 0, stream, valid,
+        hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream, valid,
                            (unsigned char*)(ws + W.off_seen), d->T, W.Bp);
         if (initial_state)
             hipLaunchKernelGGL(load_state_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream,

@@ -49,6 +49,8 @@ struct GramFwdArgs {
     int out_width, all_hidden;
     int par;                 // parity of this node's frame index (static: graphs hold an even number
                              // of frames), selects the rs_part / q buffers without waiting for t
+    int cp_mask;             // frame t's c_k live in slot t & cp_mask of Cp (ring of 2 GRAM_TB frames:
+                             // 2 GRAM_TB - 1; all T frames resident: 0x7fffffff)
 };
 
 // Contraction shared by the forward and backward kernels: s(row, o) = sum_i A[row][i] G[o][i] for
@@ -146,7 +148,6 @@ __global__ void __launch_bounds__(64 * NW_G) gram_fwd_kernel(const GramFwdArgs a
     const int rg = m * 16 + erow, n = ot * 16 + ecol;
     const size_t hoff = ((size_t)m * NAC + ot) * 256 + hp_pos(erow, ecol);
     const size_t cstride = (size_t)a.Bp * a.Np;                       // one (t, k) slice of Cp
-    constexpr int RING = 2 * GRAM_TB;
     float hraw = 0.f, iav = 0.f, psl = 0.f, st_old = 0.f, ck = 0.f, cnext = 0.f;
     bool vld = true;
     // sum(p) of the 16 rows (first launch of a frame): the row sums left per output tile by the
@@ -165,11 +166,11 @@ __global__ void __launch_bounds__(64 * NW_G) gram_fwd_kernel(const GramFwdArgs a
     }
     auto mid = [&]() {
         if (ethr) {
-            ck = a.Cp[((size_t)(t & (RING - 1)) * a.K + a.k) * cstride + hoff];
+            ck = a.Cp[((size_t)(t & a.cp_mask) * a.K + a.k) * cstride + hoff];
             vld = a.valid[(size_t)t * a.Bp + rg] != 0;
             if (LAST) {
                 const int tn = t + 1 < a.T ? t + 1 : t;
-                cnext = a.Cp[((size_t)(tn & (RING - 1)) * a.K) * cstride + hoff];
+                cnext = a.Cp[((size_t)(tn & a.cp_mask) * a.K) * cstride + hoff];
             }
         }
         if (!FIRST) return;

@@ -143,6 +143,7 @@ struct GramPersistArgs {
     float u0d, u0o, uko;
     int B, T, N, K, Bp, Np, numO, numM, out_width, all_hidden;
     int t0, nfr;
+    int cp_mask;             // as GramFwdArgs
 };
 
 // NS = chunk slots any wave owns = ceil(Np / 16 / 8) (workgroup-uniform, 1..4): the slots beyond would
@@ -156,6 +157,11 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
     __shared__ float part[32][17];
     __shared__ float ps16[16], psv[16];
     __shared__ int ctl[2];
+    // this thread's previous OUTPUT per layer ([K][256] with all_hidden, else [256]; dynamic): a masked
+    // step repeats it (K.rnn), and re-reading it from the output tensor would put a global-memory
+    // round trip into the epilogue of every phase of a frame in which any of the 16 rows is masked
+    // (ragged batches: measured 2.25 against 1.65 us per phase)
+    extern __shared__ float oprev[];
     const int ot = blockIdx.x >> 3;                         // output tile (grid = 8 * numO)
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,7 +192,6 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
     const int rg = m * 16 + erow, n = ot * 16 + ecol;
     const size_t hoff = ((size_t)m * NAC + ot) * 256 + hp_pos(erow, ecol);
     const size_t cstride = (size_t)a.Bp * a.Np;
-    constexpr int RING = 2 * GRAM_TB;
     const int clast = NAC - 1;
     const int per_wave = (NAC - w + NW_G - 1) / NW_G;        // <= 4 (NAC <= 32)
     const unsigned abytes = (unsigned)(cstride * 4);
@@ -222,7 +227,7 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
         gc[g] = 256 * (c > clast ? clast : c);
     }
     const float* ial = a.ia + n;                                   // + k * Np
-    const float* cpl = a.Cp + hoff;                                // + ((t mod RING) * K + k) * cstride
+    const float* cpl = a.Cp + hoff;                                // + ((t & cp_mask) * K + k) * cstride
     const unsigned char* vl = a.valid + rg;                        // + t * Bp
     auto prefetch = [&](int fN, int kN) {                          // operands of (frame t0 + fN, layer kN)
         if (fN >= a.nfr) return;
@@ -232,11 +237,11 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
         for (int g = 0; g < NS; ++g) bvN[g] = *(const f32x4*)(Gk + gc[g]);
         if (ethr) {
             iavN = ial[(size_t)kN * a.Np];
-            ckN = cpl[(size_t)((t & (RING - 1)) * a.K + kN) * cstride];
+            ckN = cpl[(size_t)((t & a.cp_mask) * a.K + kN) * cstride];
             vldN = vl[(size_t)t * a.Bp];
             if (kN == a.K - 1) {
                 const int tn = t + 1 < a.T ? t + 1 : t;
-                cnextN = cpl[(size_t)((tn & (RING - 1)) * a.K) * cstride];
+                cnextN = cpl[(size_t)((tn & a.cp_mask) * a.K) * cstride];
             }
         }
     };
@@ -246,6 +251,9 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
     if (ethr) {
         hcur = *((a.t0 & 1) ? p_qb1 : p_qb0);
         stcur = *p_state;
+        const int nl = a.all_hidden ? a.K : 1;
+        for (int kk = 0; kk < nl; ++kk)
+            oprev[kk * 256 + tid] = (a.t0 > 0 && out_live) ? p_out[kk * a.N - (ptrdiff_t)a.out_width] : 0.f;
     }
     bool fast = false;                                             // chain shares one XCD (known after phase 0)
     PTL_DECL;
@@ -326,17 +334,16 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
                 // K.rnn masking: a masked step repeats the previous output (zeros before the first valid)
                 if (a.all_hidden) {
                     if (first) {
-                        float o0 = hprev;
-                        if (!vld) o0 = (t > 0) ? p_out[-(ptrdiff_t)a.out_width] : 0.f;
+                        const float o0 = vld ? hprev : oprev[tid];
+                        oprev[tid] = o0;
                         p_out[0] = o0;
                     }
-                    float o = hn;
-                    const int off = k * a.N;
-                    if (!vld) o = (t > 0) ? p_out[off - (ptrdiff_t)a.out_width] : 0.f;
-                    p_out[off] = o;
+                    const float o = vld ? hn : oprev[k * 256 + tid];
+                    oprev[k * 256 + tid] = o;
+                    p_out[k * a.N] = o;
                 } else if (last) {
-                    float o = hn;
-                    if (!vld) o = (t > 0) ? p_out[-(ptrdiff_t)a.out_width] : 0.f;
+                    const float o = vld ? hn : oprev[tid];
+                    oprev[tid] = o;
                     p_out[0] = o;
                 }
             }
@@ -599,14 +606,16 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_bwd_kernel(const
 // Whether a Gram-form call may run as persistent chains: tile counts, and every chain's workgroups
 // resident together on one XCD's 32 CUs (checked once per process against the occupancy API with a
 // margin of one workgroup per CU -- the API can answer one too many, MI355X_MICROARCH.md).
+constexpr int PERSIST_MAX_K = 48;               // [K][256] floats of previous outputs in LDS
+static inline size_t persist_fwd_lds(int K, bool all_hidden) { return (size_t)(all_hidden ? K : 1) * 256 * 4; }
 static inline bool persist_shape_ok(int numM, int numO, int K) {
-    if (K < 2 || numO > PERSIST_MAX_TILES || numM > PERSIST_MAX_CHAINS) return false;
+    if (K < 2 || K > PERSIST_MAX_K || numO > PERSIST_MAX_TILES || numM > PERSIST_MAX_CHAINS) return false;
     if (const char* e = getenv("DRNMF_PERSIST"))
         if (atoi(e) == 0) return false;
     static int per_cu = -1;
     if (per_cu < 0) {
         int a = 0, b = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gram_persist_kernel<4>, 64 * (NW_G + 1), 0) != hipSuccess) a = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gram_persist_kernel<4>, 64 * (NW_G + 1), persist_fwd_lds(PERSIST_MAX_K, true)) != hipSuccess) a = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gram_persist_bwd_kernel<4>, 64 * (NW_G + 1), 0) != hipSuccess) b = 0;
         per_cu = a < b ? a : b;
     }

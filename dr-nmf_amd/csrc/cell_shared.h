@@ -379,6 +379,9 @@ struct Workspace {
     bool gram;
     int numO;              // output tiles of 16 atoms (= row-sum partials per row)
     size_t off_cp, off_xpad, off_q0, off_q1;
+    int cp_frames;         // frames of hoisted c_k the workspace holds: 2 GRAM_TB (a ring of two blocks)
+                           // or, for the shapes the persistent chains serve, all T (one product up
+                           // front, one launch for the whole sequence)
     size_t off_rsave;      // training forward (all hidden layers, fp32, factored): residuals r_k, k >= 1,
                            // row-major [K-1][B*T][Fp] for the BPTT's weight gradients; 0 = absent
 };
@@ -463,8 +466,14 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_h16_0 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_h16_1 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_r16 = take(W.half ? (size_t)W.Bp * W.Fp * 2 : 0);
-    W.off_cp = take(W.gram ? (size_t)2 * GRAM_TB * d->K * W.Bp * W.Np * 4 : 0);
-    W.off_xpad = take(W.gram ? (size_t)d->B * GRAM_TB * W.Fp * 4 : 0);
+    W.cp_frames = 2 * GRAM_TB;
+    if (W.gram && W.numO <= 32 && W.Bp / ROWS <= 8 && d->T > 2 * GRAM_TB &&
+        (size_t)d->T * d->K * W.Bp * W.Np * 4 <= ((size_t)1 << 30))
+        W.cp_frames = d->T;
+    if (const char* e = getenv("DRNMF_CP_FULL"))      // tuning aid: 0 keeps the ring of two blocks
+        if (atoi(e) == 0) W.cp_frames = 2 * GRAM_TB;
+    W.off_cp = take(W.gram ? (size_t)W.cp_frames * d->K * W.Bp * W.Np * 4 : 0);
+    W.off_xpad = take(W.gram ? (size_t)d->B * (W.cp_frames == d->T ? d->T : GRAM_TB) * W.Fp * 4 : 0);
     W.off_q0 = take(W.gram ? (size_t)W.Bp * W.Np * 4 : 0);
     W.off_q1 = take(W.gram ? (size_t)W.Bp * W.Np * 4 : 0);
     W.off_rsave = 0;

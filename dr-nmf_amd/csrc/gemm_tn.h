@@ -195,6 +195,23 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
         }
 }
 
+// Split-K count for an M x N output contracted over Kdim: tiles x splits workgroups run in rounds of
+// 512 (2 per CU); the count that minimises rounds / splits -- weighted by 1 + 0.004 s for the partial
+// tiles every split writes and the combine pass reads back -- with each split keeping >= 192
+// contraction steps.  A handful of output tiles (small dictionaries: F = 257, N = 200 is four) thus
+// still spreads over the chip.
+inline int pick_splits(int M, int N, int64_t Kdim, int max_splits) {
+    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= max_splits; ++s) {
+        if (s > 1 && Kdim / s < 192) break;
+        const double cost = (double)((tiles * s + 511) / 512) / s * (1.0 + 0.004 * s);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 template <class Epi>
 inline hipError_t launch(const Operands& g, const Epi& epi, int splits, hipStream_t stream) {
     // the 4-wide column groups must not straddle M / N: pad the operand or take the scalar path

@@ -197,9 +197,12 @@ __global__ void __launch_bounds__(256)
 prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
                  float* __restrict__ colnorm, float* __restrict__ tail, float* __restrict__ DnA_,
                  int F, int N, int Fp, int Np, int f_mfma) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    // workgroup = 64 atoms x 4 interleaved bin groups (a thread per atom walking all F bins twice
+    // left a small dictionary -- N = 200, K = 5 -- on five workgroups: 147 us per training step)
+    __shared__ float ssum[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int fq = threadIdx.x >> 6;
     const int layer = blockIdx.y;
-    if (n >= Np) return;
     const int NAC = Np / 16;
     const size_t lstride = (size_t)Fp * Np;
     // fp32 Dp block (ft, ac): [(q*16 + f%16)*4 + e] = Dn[f][16 ac + 4q + e] -- lane l = q*16 + f%16 of
@@ -229,30 +232,30 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
         }
     };
     const int t0 = (F / 16) * 16;
+    const bool live = n < N, inb = n < Np;   // (Np is a multiple of 32: the last block may overhang)
     float* tl = tail + (size_t)layer * MAX_TAIL * Np + n;
-    if (n >= N) {
-        for (int f = 0; f < Fp; ++f) put(f, 0.f);
-        for (int i = 0; i < MAX_TAIL; ++i) tl[(size_t)i * Np] = 0.f;
-        colnorm[(size_t)layer * Np + n] = 1.f;
-        return;
-    }
     const float* ld = log_D + (size_t)layer * F * N;
     float s = 0.f;
-    for (int f = 0; f < F; ++f) {
-        const float e = expf(ld[(size_t)f * N + n]);
-        s = fmaf(e, e, s);
-    }
-    const float nrm = sqrtf(s);
-    colnorm[(size_t)layer * Np + n] = nrm;
-    for (int f = 0; f < F; ++f) {
-        float v = expf(ld[(size_t)f * N + n]) / nrm;
+    if (live)
+        for (int f = fq; f < F; f += 4) {
+            const float e = expf(ld[(size_t)f * N + n]);
+            s = fmaf(e, e, s);
+        }
+    ssum[fq][threadIdx.x & 63] = s;
+    __syncthreads();
+    const int c = threadIdx.x & 63;
+    const float nrm = live ? sqrtf((ssum[0][c] + ssum[1][c]) + (ssum[2][c] + ssum[3][c])) : 1.f;
+    if (!inb) return;
+    if (fq == 0) colnorm[(size_t)layer * Np + n] = nrm;
+    for (int f = fq; f < Fp; f += 4) {
+        float v = (live && f < F) ? expf(ld[(size_t)f * N + n]) / nrm : 0.f;
         put(f, v);
         if (HALF) v = (float)(f16)v;
         if (f >= t0 && f - t0 < MAX_TAIL) tl[(size_t)(f - t0) * Np] = v;
     }
-    for (int f = F; f < Fp; ++f) put(f, 0.f);
-    for (int i = 0; i < MAX_TAIL; ++i)
-        if (t0 + i >= F) tl[(size_t)i * Np] = 0.f;
+    if (fq == 0)
+        for (int i = 0; i < MAX_TAIL; ++i)
+            if (t0 + i >= Fp) tl[(size_t)i * Np] = 0.f;
 }
 
 // 1/alpha[n] and b[n] = -lam/alpha[n] per layer (enhance.py:187-194, 201-203).  Padded atoms get
@@ -287,7 +290,7 @@ extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_
     hipStream_t stream = (hipStream_t)stream_;
     const ParamsLayout L = params_layout(d);
     char* base = (char*)params;
-    dim3 g1((L.Np + 255) / 256, d->n_D);
+    dim3 g1((L.Np + 63) / 64, d->n_D);
     // bins from f_mfma up are the odd bins the cell keeps out of the matrix cores (workspace_layout:
     // ntail): zero in the fp16 MFMA packings, present in the tail rows
     const bool has_tail = d->divergence == DRNMF_DIV_ED && d->F % 16 != 0 &&

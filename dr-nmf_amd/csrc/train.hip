@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int HB_SPLITS = 8;
+constexpr int HB_SPLITS = 64;    // upper bound; per shape: gemm_tn::pick_splits
 inline int pad4i(int v) { return (v + 3) / 4 * 4; }
 
 __global__ void __launch_bounds__(256)
@@ -226,7 +226,7 @@ LhWs lh_layout(int64_t rows, int F, int r) {
     L.off_dA = take((size_t)rows * L.Fp4 * 4);
     L.off_dB = take((size_t)rows * L.Fp4 * 4);
     L.off_part = take((size_t)L.nblocks * 2 * 4);
-    L.off_P = take((size_t)HB_SPLITS * r * L.Fp4 * 4);
+    L.off_P = take((size_t)gemm_tn::pick_splits(r, L.Fp4, rows, HB_SPLITS) * r * L.Fp4 * 4);
     L.total = o;
     return L;
 }
@@ -237,6 +237,7 @@ int32_t head_backward_gemms(drnmf_handle_t h, int64_t rows, int F, int r, const 
                             const float* E, float* P, int Fp4, float* d_hidden,
                             float* d_kernel_clean, float* d_kernel_noise, hipStream_t stream) {
     const int N2 = 2 * r;
+    const int nsplit = gemm_tn::pick_splits(r, Fp4, rows, HB_SPLITS);
     for (int seg = 0; seg < 2; ++seg) {
         const float* dX = seg ? dB : dA;
         const float* Es = E + (size_t)seg * r * Fp4;
@@ -246,10 +247,10 @@ int32_t head_backward_gemms(drnmf_handle_t h, int64_t rows, int F, int r, const 
         // dE[n][f] = sum_rows hidden[row][seg*r + n] dX[row][f];  dK = dE * E
         gemm_tn::Operands t1{hidden + h_off + (size_t)seg * r, dX, rows, r, Fp4, ld_h, Fp4};
         const size_t pstr = (size_t)r * Fp4;
-        DRNMF_HIP(h, gemm_tn::launch(t1, EpiPart{P, Fp4, pstr}, HB_SPLITS, stream));
+        DRNMF_HIP(h, gemm_tn::launch(t1, EpiPart{P, Fp4, pstr}, nsplit, stream));
         const size_t tot = (size_t)r * F;
         hipLaunchKernelGGL(dkernel_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
-                           P, Es, seg ? d_kernel_noise : d_kernel_clean, r, F, Fp4, HB_SPLITS, pstr);
+                           P, Es, seg ? d_kernel_noise : d_kernel_clean, r, F, Fp4, nsplit, pstr);
     }
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
