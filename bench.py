@@ -140,6 +140,41 @@ def mu_bench(torch, dev, F, N, W, n=32768, iters=20):
             "ms_per_iteration": sec / iters * 1e3}
 
 
+def snmf_train_bench(torch, dev, F, r, n=32768, iters=20):
+    """Dictionary training (sparse_nmf_gpu.m:156-298 through snmf.py's loop): iterations per second of
+    the W + H multiplicative updates on n frames, r atoms, beta = 1 (the reference's 'kl' default) and
+    beta = 2, objective logged on the device every iteration, no host synchronisation inside the
+    loop (conv_eps = 0, as enhance.py:842 and the shipped configs set it)."""
+    from drnmf_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    V = torch.rand((n, F), generator=g, device=dev) ** 2 + 1e-3
+    out = {"frames": n, "F": F, "atoms": r, "iterations": iters}
+    for name, beta in (("kl", 1.0), ("ed", 2.0)):
+        W0 = torch.rand((F, r), generator=g, device=dev)
+        H0 = torch.rand((n, r), generator=g, device=dev)
+        tr = ops.SnmfTrainer(V, W0, H0, beta=beta)
+        log = torch.zeros((iters + 2, 2), dtype=torch.float32, device=dev)
+        for i in range(2):
+            tr.step(5.0, None, True, obj=log[i])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            tr.step(5.0, None, True, obj=log[2 + i])
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3
+        c = log[:, 1].cpu().numpy()
+        out[name] = {"iterations_per_s": iters / sec, "ms_per_iteration": sec / iters * 1e3,
+                     "cost_first": float(c[0]), "cost_last": float(c[-1]),
+                     "cost_monotone": bool((c[1:] <= c[:-1] * (1 + 1e-5)).all())}
+        del tr, W0, H0
+    del V
+    torch.cuda.empty_cache()
+    return out
+
+
 def train_bench(torch, dev, steps=20, warmup=5, shape=(32, 500, 257, 1000, 5), ragged=True):
     """Forward + BPTT + Adam per step on a synthetic batch.  Default shape = BASELINE configs[2],
     the shipped training configuration (downsample1: F=257, maxlen=500, batch 32, K=5, r=1000,
@@ -921,6 +956,7 @@ def main():
             extra["ista_frame_parallel"] = safe(ista_bench, torch, dev, F, N, K, W)
             extra["mu_inference"] = safe(mu_bench, torch, dev, F, N, W)
             extra["stft_front_end"] = safe(stft_bench, torch, dev)
+            extra["dictionary_training"] = safe(snmf_train_bench, torch, dev, F, r)
         extra["config1_single_utterance"] = safe(config1_bench, torch, dev)
         if not a.no_slab:
             extra["inference_slab_250"] = safe(slab_bench, torch, dev, F, r, K, T)

@@ -212,7 +212,9 @@ struct BwdAArgs {
 };
 
 // (leading scalar arguments: preloaded into SGPRs, see cell_b_kernel)
-template <int G, int KS, bool QRED = false>
+// K0 (KL / beta cell only, layer 0 = a full ISTA step from the state p): the result is d p itself --
+// no relu mask of a previous layer, nothing to store in dz_all -- left in dzp_out for bwd_edge_kernel.
+template <int G, int KS, bool QRED = false, bool K0 = false>
 __global__ void __launch_bounds__(256)
 bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, int Fp_, int Np_,
              int numA_, int nchunks_, const BwdAArgs a_in) {
@@ -281,10 +283,13 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     const f32x2 dzk = *(const f32x2*)(a.dzp_in + hoff);
     const f32x2 ia = *(const f32x2*)(a.ia_prev + n);
     f32x2 hprev = {0.f, 0.f};
+    if (K0) hprev = f32x2{1.f, 1.f};
+    else {
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
-        if (rg < a.B && n + e < a.N)
-            hprev[e] = a.hall[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n + e];
+        for (int e = 0; e < 2; ++e)
+            if (rg < a.B && n + e < a.N)
+                hprev[e] = a.hall[((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n + e];
+    }
 
     f32x2 dt[MAX_TAIL], dtp[MAX_TAIL];
     float qs[MAX_TAIL], qv[MAX_TAIL][4];
@@ -417,7 +422,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
         dzn[e] = hprev[e] > 0.f ? dh : 0.f;
     }
 #ifndef DRNMF_EXP_NODZ
-    if (rg < a.B) {     // one 8-byte store where the pair is whole and aligned (n is even)
+    if (!K0 && rg < a.B) {     // one 8-byte store where the pair is whole and aligned (n is even)
         float* dzo = a.dz_all + ((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n;
         if (n + 1 < a.N && (a.N & 1) == 0) *(f32x2*)dzo = dzn;
         else {
@@ -459,8 +464,10 @@ void* bwd_a_func(int per_wave, bool qred) {
     if (per_wave <= 2) return (void*)&bwd_a_kernel<2, KS>;
     return (void*)&bwd_a_kernel<4, KS>;
 }
-void* pick_bwd_a(int nchunks, int KS, bool qred = false) {
+void* pick_bwd_a(int nchunks, int KS, bool qred = false, bool k0 = false) {
     const int per_wave = (nchunks + 3) / 4;
+    if (k0)          // (the KL / beta cell: one atom range, no odd-bin side path)
+        return per_wave <= 2 ? (void*)&bwd_a_kernel<2, 1, false, true> : (void*)&bwd_a_kernel<4, 1, false, true>;
     switch (KS) {
         case 1: return bwd_a_func<1>(per_wave, qred);
         case 2: return bwd_a_func<2>(per_wave, qred);
@@ -854,10 +861,82 @@ dlogh0_kernel(const float* __restrict__ dh0_part, const float* __restrict__ log_
     d_log_h0[n] = s / (1.f + expf(-log_h0[n]));   // d softplus = sigmoid
 }
 
+// ---- KL / beta cell (ista_kl / ista_beta run recurrently, cell_forward.hip) ----------------------------
+// r = g(x, x^) with g = x / x^ - 1 (KL) or x x^(beta-2) - x^(beta-1) (enhance.py:431, 450); the chain
+// needs d x^ = d r * dg/dx^.  With s = -dg/dx^ the launches around it keep the Euclidean cell's signs
+// (there s = 1):  s_KL = x / x^2,  s_beta = (beta-1) x^(beta-2) - (beta-2) x x^(beta-3).
+__device__ __forceinline__ float ista_g(int div, float beta, float xv, float xe) {
+    if (div == DRNMF_DIV_KL) return xv / xe - 1.f;
+    return xv * powf(xe, beta - 2.f) - powf(xe, beta - 1.f);
+}
+__device__ __forceinline__ float ista_neg_dg(int div, float beta, float xv, float xe) {
+    if (div == DRNMF_DIV_KL) return xv / (xe * xe);
+    return (beta - 1.f) * powf(xe, beta - 2.f) - (beta - 2.f) * xv * powf(xe, beta - 3.f);
+}
+// d r partial of the current (frame, layer), packed [Bp][Fp] (one atom range), times s(x_t, x^_{t,k})
+// (a masked frame carries no gradient, and its x^ may be 0 / 0 -- the forward ran the iteration on
+// x_t = 0 there and discarded the result: the factor is forced to 0, not multiplied by 0)
+__global__ void __launch_bounds__(256)
+dgdx_scale_kernel(const float* __restrict__ xp, const float* __restrict__ xhat,
+                  float* __restrict__ drpart, const int* c_rd, const unsigned char* __restrict__ valid,
+                  int T, int k, int K, int div, float beta, int F, int Fp, int Bp) {
+    const int t = T - 1 - *c_rd;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // one block = one 16 x 16 tile (rp_pos order)
+    if (i >= (size_t)Bp * Fp) return;
+    const int nft = Fp / 16;
+    const int ft = (int)(blockIdx.x % nft), m = (int)(blockIdx.x / nft);
+    const int pos = threadIdx.x;
+    const int f = 16 * ft + 4 * (pos & 3) + (pos >> 6);
+    const int row = m * 16 + ((pos >> 2) & 15);
+    const size_t slab = (size_t)Bp * Fp;
+    float sc = 0.f;
+    if (f < F && valid[(size_t)t * Bp + row])
+        sc = ista_neg_dg(div, beta, xp[(size_t)t * slab + i], xhat[((size_t)t * K + k) * slab + i]);
+    const float dr = drpart[i];
+    drpart[i] = sc != 0.f ? dr * sc : 0.f;
+}
+// R_k = g(X, X^_k) row-major [B*T][Fp] (padding bins 0) from the packed x^ of layer k
+__global__ void __launch_bounds__(256)
+unpack_g_kernel(const float* __restrict__ x, const float* __restrict__ xhat, float* __restrict__ R,
+                const unsigned char* __restrict__ valid, int B, int T, int F, int Fp, int Bp, int k,
+                int K, int div, float beta) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * T * Fp) return;
+    const int f = (int)(i % Fp);
+    const size_t bt = i / Fp;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    float g = 0.f;
+    if (f < F && valid[(size_t)t * Bp + b]) {       // (masked frames: no gradient, and x^ may be 0 / 0)
+        const float xe = xhat[((size_t)t * K + k) * Bp * Fp + ((size_t)(b >> 4) * (Fp / 16) + (f >> 4)) * 256 +
+                              rp_pos(b & 15, f & 15)];
+        g = ista_g(div, beta, x[bt * F + f], xe);
+    }
+    R[i] = g;
+}
+// state that entered frame t of row b: the previous (possibly repeated) output once a valid frame has
+// been seen, else softplus(log_h0)
+__global__ void __launch_bounds__(256)
+state_matrix_kernel(const float* __restrict__ hall, const unsigned char* __restrict__ seen,
+                    const float* __restrict__ log_h0, float* __restrict__ P, int B, int T, int N,
+                    int K, int Bp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * T * N) return;
+    const int n = (int)(i % N);
+    const size_t bt = i / N;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    float v;
+    if (seen[(size_t)t * Bp + b]) v = hall[(bt - 1) * K * N + (size_t)(K - 1) * N + n];
+    else {
+        const float z = log_h0[n];
+        v = (z > 20.f) ? z : log1pf(expf(z));
+    }
+    P[i] = v;
+}
+
 struct BwdWs {
     size_t off_dstate, off_gq, off_dzp0, off_dzp1, off_dGp0, off_dGp1, off_drpart, off_z0s, off_dps,
         off_cnt, off_dh0, off_dzall, off_dR, off_xpad, off_R, off_dn, off_dpia, off_dnia, off_P, off_cr, off_dq,
-        off_dqsum, total;
+        off_dqsum, off_pst, total;
 };
 BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     BwdWs L;
@@ -882,12 +961,13 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     L.off_dpia = take(W.gram ? 0 : (size_t)d->K * W.Fp * W.Np * 4);
     L.off_dnia = take(W.gram ? (size_t)W.Fp * W.Np * 4 : 0);
     {
-        const bool odd = (d->F % 16 == 1) && d->F > 16;
+        const bool odd = (d->F % 16 == 1) && d->F > 16 && d->divergence == DRNMF_DIV_ED;
         L.off_P = take((size_t)tn_splits(odd ? d->F - 1 : W.Fp, d->N, BT) * W.Fp * W.Np * 4);
     }
     L.off_cr = take((size_t)CR_SPLITS * CR_SLOTS * W.Np * 4);
     L.off_dq = take((size_t)2 * MAX_TAIL * W.Bp * W.numA * 4);
     L.off_dqsum = take((size_t)MAX_TAIL * W.Bp * 4);
+    L.off_pst = take(d->divergence != DRNMF_DIV_ED ? (size_t)BT * d->N * 4 : 0);   // KL / beta: state matrix
     L.total = o;
     return L;
 }
@@ -906,7 +986,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                                   size_t fwd_workspace_bytes, void* bwd_workspace,
                                   size_t bwd_workspace_bytes, float* d_log_D,
                                   float* d_log_alph, float* d_log_lam1, float* d_log_h0,
-                                  void* stream_, float* prof_ms) {
+                                  void* stream_, float* prof_ms, float beta = 0.f) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = persist_check_flag(h);
     if (rc) return rc;
@@ -915,8 +995,12 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     // operand_f16: the forward ran on fp16 matrix-core operands; its BPTT is computed in fp32 from
     // the stored hiddens and the fp32 dictionary packings kept in the same prepared block
     // (rounding treated as the identity: mixed-precision training)
-    if (d->divergence != DRNMF_DIV_ED)
-        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "cell_backward: the KL / beta cell is forward only");
+    // KL / beta cell (drnmf_cell_backward_ista): every layer is a full ISTA step from its input (layer
+    // 0 from the state), no U term -- the same chain with one more layer-step per frame, the residual
+    // map's derivative between its two launches, and u0_diag = 1, u0_off = uk_off = 0
+    const bool nonlin = d->divergence != DRNMF_DIV_ED;
+    if (nonlin) { u0_diag = 1.f; u0_off = 0.f; uk_off = 0.f; }
+    const int kmin = nonlin ? 0 : 1;                     // last layer-step of a frame's chain
     if (!d->return_all_hidden)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG,
                    "cell_backward needs the forward run with return_all_hidden=1 (all K hiddens)");
@@ -925,6 +1009,9 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_backward: NULL pointer argument");
     const Workspace W = workspace_layout(d);
     const BwdWs L = bwd_layout(d, W);
+    if (nonlin && (W.off_xhat == 0 || W.KS != 1 || W.gram || d->operand_f16))
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "cell_backward (KL / beta): needs the fp32 training forward "
+                   "of drnmf_cell_forward_ista (return_all_hidden = 1)");
     if (fwd_workspace_bytes < W.total || bwd_workspace_bytes < L.total)
         DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "cell_backward: workspace too small (fwd %zu/%zu, bwd "
                    "%zu/%zu)", fwd_workspace_bytes, W.total, bwd_workspace_bytes, L.total);
@@ -982,10 +1069,12 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     EdgeArgs ea;
     ea.hall = hall; ea.d_out = d_out; ea.dz_all = dz_all; ea.ia_last = ia_of(K - 1);
     ea.dstate = dstate; ea.gq = gq; ea.dzp_top = dzp[(K - 1) & 1]; ea.dGp_top = W.gram ? dGp[(K - 1) & 1] : nullptr;
-    ea.dzp0 = dzp[0]; ea.dz0s_part = z0s; ea.dps_part = dps; ea.dh0_part = dh0_part;
+    ea.dzp0 = nonlin ? dzp[1] : dzp[0];      // (KL / beta: layer 0's launch leaves d p in dzp[(0 - 1) & 1])
+    ea.dz0s_part = z0s; ea.dps_part = dps; ea.dh0_part = dh0_part;
     ea.valid = valid;
-    ea.c_rd = (K == 1) ? cA : cB;
-    ea.c_wr = (K == 1) ? nullptr : cA;
+    const bool edge_only = K == 1 && !nonlin;            // a frame of the ED cell with K = 1: the edge alone
+    ea.c_rd = edge_only ? cA : cB;
+    ea.c_wr = edge_only ? nullptr : cA;
     ea.u0d = u0_diag; ea.u0o = u0_off;
     ea.B = B; ea.T = T; ea.N = N; ea.K = K; ea.Bp = W.Bp; ea.Np = W.Np; ea.numA = W.numA;
     auto tail_of = [&](int k) {
@@ -1023,7 +1112,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     float* DpIa = (float*)(bw + L.off_dpia);
     if (!W.gram) {
         const size_t tot = (size_t)W.Fp * W.Np;
-        for (int k = 1; k < K; ++k)
+        for (int k = kmin; k < K; ++k)
             hipLaunchKernelGGL(scale_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                                stream, Dp_of(k), ia_of(k), DpIa + (size_t)k * tot, tot, W.Np);
     }
@@ -1045,7 +1134,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     auto make_a = [&](int k) {
         BwdAArgs a;
         a.Dn = DpA_base + (d->n_D == 1 ? 0 : (size_t)k * dstride);
-        a.ia_prev = ia_of(k - 1);
+        a.ia_prev = ia_of(k >= 1 ? k - 1 : 0);
         a.drpart = drpart;
         a.dzp_in = dzp[k & 1];
         a.dzp_out = dzp[(k - 1) & 1];
@@ -1054,12 +1143,12 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         a.dR = dR_all + (size_t)k * BT * W.Fp;
         a.dz0s_part = z0s; a.dps_part = dps;
         a.c_rd = cA;
-        a.c_wr = (k == 1) ? cB : nullptr;
+        a.c_wr = (k == kmin) ? cB : nullptr;
         a.uko = uk_off;
         a.k = k; a.B = B; a.T = T; a.N = N; a.K = K; a.Bp = W.Bp; a.Fp = W.Fp; a.Np = W.Np;
         a.numA = W.numA; a.nchunks = nft;
         a.Dtail = tail_of(k);
-        a.Dtail_prev = tail_of(k - 1);
+        a.Dtail_prev = tail_of(k >= 1 ? k - 1 : 0);
         a.dq_in = qred ? (const float*)(bw + L.off_dqsum) : dq + (size_t)(k & 1) * dqstride;
         a.dq_out = dq + (size_t)((k - 1) & 1) * dqstride;
         a.ntail = W.ntail;
@@ -1088,7 +1177,10 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                                      dim3(64 * (NW_G + 1)), kp, 0, stream));
         persist_mark(h, stream);
     }
-    std::vector<uint64_t> key = {W.gram ? 0xB00Cull : 0xB00Bull, (uint64_t)B, (uint64_t)T, (uint64_t)F, (uint64_t)N,
+    uint32_t beta_bits;
+    memcpy(&beta_bits, &beta, 4);
+    std::vector<uint64_t> key = {(W.gram ? 0xB00Cull : 0xB00Bull) + ((uint64_t)d->divergence << 16) +
+                                     ((uint64_t)beta_bits << 32), (uint64_t)B, (uint64_t)T, (uint64_t)F, (uint64_t)N,
                                  (uint64_t)K, (uint64_t)d->n_D, (uint64_t)(uintptr_t)params,
                                  (uint64_t)(uintptr_t)hall, (uint64_t)(uintptr_t)d_out,
                                  (uint64_t)(uintptr_t)fwd_workspace,
@@ -1131,7 +1223,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         for (int rep = 0; rep < fpg; ++rep) {
             void* ke[1] = {&ea};
             DRNMF_HIP(h, add((void*)&bwd_edge_kernel, grid_a, 256, ke));
-            for (int k = K - 1; k >= 1; --k) {
+            for (int k = K - 1; k >= kmin; --k) {
                 if (W.gram) {
                     GramBwdArgs g = make_g(k);
                     void* kg[1] = {&g};
@@ -1140,10 +1232,22 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                 }
                 CellBArgs b = make_b(k);
                 DRNMF_HIP(h, add(pick_b_func(nch_ks_b, W.RB, false, qred), grid_b, 64 * NW_B, CellBParams(b).p));
+                if (nonlin) {                          // d x^ = d r * dg/dx^ (x_t, x^_{t,k}), in place
+                    const float* xpp = (const float*)(fw + W.off_xp);
+                    const float* xh = (const float*)(fw + W.off_xhat);
+                    float* drp = drpart;
+                    const int* crd = cA;
+                    const unsigned char* vp = valid;
+                    int Tv = T, kv = k, Kv = K, dv = d->divergence, Fv = F, Fpv = W.Fp, Bpv = W.Bp;
+                    float bt = beta;
+                    void* ks[13] = {&xpp, &xh, &drp, &crd, &vp, &Tv, &kv, &Kv, &dv, &bt, &Fv, &Fpv, &Bpv};
+                    DRNMF_HIP(h, add((void*)&dgdx_scale_kernel,
+                                     dim3((unsigned)((size_t)W.Bp * W.Fp / 256)), 256, ks));
+                }
                 BwdAArgs a = make_a(k);
-                DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS, qred), grid_a, 256, BwdAParams(a).p));
+                DRNMF_HIP(h, add(pick_bwd_a(nft, W.KS, qred, nonlin && k == 0), grid_a, 256, BwdAParams(a).p));
             }
-            if (K == 1) {
+            if (edge_only) {
                 int* cp = cA;
                 void* kc[1] = {&cp};
                 DRNMF_HIP(h, add((void*)&advance_frame_kernel, dim3(1), 1, kc));
@@ -1187,7 +1291,14 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         hipLaunchKernelGGL(unpack_dn_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                            stream, Dp_of(k), Dn_rm, W.Fp, W.Np);
         const float* Aop = xpad;
-        if (k >= 1 && W.off_rsave != 0) {
+        if (nonlin) {
+            // R_k = g(X, X^_k) of EVERY layer, layer 0 included, from the x^ the forward kept
+            const size_t tot2 = (size_t)BT * W.Fp;
+            hipLaunchKernelGGL(unpack_g_kernel, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, stream,
+                               x, (const float*)(fw + W.off_xhat), Rk, valid, B, T, F, W.Fp, W.Bp, k, K,
+                               d->divergence, beta);
+            Aop = Rk;
+        } else if (k >= 1 && W.off_rsave != 0) {
             // the forward left r_k of every frame in its workspace (cell_a_kernel, Rsave)
             Aop = (const float*)(fw + W.off_rsave) + (size_t)(k - 1) * BT * W.Fp;
         } else if (k >= 1) {
@@ -1197,7 +1308,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         }
         // M = Fp: the padded bins of R / X / dR are zero, and whole 4-column groups keep the loads
         // vectorised.  F = 16 j + 1: M = F - 1, the odd bin's row comes from colreduce_kernel.
-        const bool odd = (F % 16 == 1) && F > 16;
+        const bool odd = (F % 16 == 1) && F > 16 && !nonlin;   // (KL / beta: no odd-bin side path at all)
         const int Mg = odd ? F - 1 : W.Fp;
         gemm_tn::Operands t1{Aop, dz_all + (size_t)k * N, BT, Mg, N, W.Fp, KN};
         const int nsplit = tn_splits(Mg, N, BT);
@@ -1218,6 +1329,14 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
             gemm_tn::Operands t2{dRk, hall + (size_t)(k - 1) * N, BT, Mg, N, W.Fp, KN};
             DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, nsplit, stream));
             dRk_tail = dRk + (F - 1);
+        } else if (nonlin) {
+            // layer 0 of the KL / beta cell contracts the STATE p_t: - d x^_0^T P, P row-major [B*T][N]
+            float* Pst = (float*)(bw + L.off_pst);
+            const size_t totp = (size_t)BT * N;
+            hipLaunchKernelGGL(state_matrix_kernel, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0,
+                               stream, hall, seen, log_h0, Pst, B, T, N, K, W.Bp);
+            gemm_tn::Operands t2{dR_all, Pst, BT, Mg, N, W.Fp, N};
+            DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, nsplit, stream));
         }
         ColRedArgs ca;
         ca.rt = odd ? Aop + (F - 1) : nullptr;
@@ -1264,7 +1383,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         DRNMF_HIP(h, hipStreamSynchronize(stream));
         DRNMF_HIP(h, hipEventElapsedTime(&prof_ms[0], pev[0], pev[1]));
         DRNMF_HIP(h, hipEventElapsedTime(&prof_ms[1], pev[1], pev[2]));
-        prof_ms[2] = (float)T * (float)(W.gram ? K : 2 * K - 1) + 1.f;   // launches of the sequential pass
+        prof_ms[2] = (float)T * (float)(W.gram ? K : (nonlin ? 3 * K + 1 : 2 * K - 1)) + 1.f;   // launches of the sequential pass
         for (auto& e : pev) (void)hipEventDestroy(e);
     }
     return DRNMF_OK;
@@ -1278,9 +1397,28 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
                                        size_t bwd_workspace_bytes, float* d_log_D,
                                        float* d_log_alph, float* d_log_lam1, float* d_log_h0,
                                        void* stream_) {
+    if (h && d && d->divergence != DRNMF_DIV_ED)
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
+                   "cell_backward is the reference's (Euclidean) cell; KL / beta: drnmf_cell_backward_ista");
     return cell_backward_impl(h, d, x, params, log_h0, u0_diag, u0_off, uk_off, hall, d_out,
                               fwd_workspace, fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes,
                               d_log_D, d_log_alph, d_log_lam1, d_log_h0, stream_, nullptr);
+}
+
+extern "C" int32_t drnmf_cell_backward_ista(drnmf_handle_t h, const drnmf_cell_desc_t* d,
+                                            const float* x, const void* params, const float* log_h0,
+                                            float beta, const float* hall, const float* d_out,
+                                            const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                            void* bwd_workspace, size_t bwd_workspace_bytes,
+                                            float* d_log_D, float* d_log_alph, float* d_log_lam1,
+                                            float* d_log_h0, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (!d || (d->divergence != DRNMF_DIV_KL && d->divergence != DRNMF_DIV_BETA))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG,
+                   "cell_backward_ista: d->divergence must be DRNMF_DIV_KL or DRNMF_DIV_BETA");
+    return cell_backward_impl(h, d, x, params, log_h0, 1.f, 0.f, 0.f, hall, d_out, fwd_workspace,
+                              fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes, d_log_D,
+                              d_log_alph, d_log_lam1, d_log_h0, stream_, nullptr, beta);
 }
 
 extern "C" int32_t drnmf_cell_backward_profile(
@@ -1291,6 +1429,8 @@ extern "C" int32_t drnmf_cell_backward_profile(
     float* d_log_h0, void* stream_, float* out_ms_host) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!out_ms_host) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_backward_profile: NULL out_ms_host");
+    if (d && d->divergence != DRNMF_DIV_ED)
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "cell_backward_profile brackets the Euclidean cell's BPTT");
     return cell_backward_impl(h, d, x, params, log_h0, u0_diag, u0_off, uk_off, hall, d_out,
                               fwd_workspace, fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes,
                               d_log_D, d_log_alph, d_log_lam1, d_log_h0, stream_, out_ms_host);

@@ -668,9 +668,12 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
 // there by cell_b in its no-input mode).  g = x/x^ - 1 (KL) or x x^(beta-2) - x^(beta-1)
 // (enhance.py:431, 450); padded bins are forced to 0 (0/0 otherwise).  Also the frame-counter
 // hand-over of the frame's first kernel (see cell_forward_impl).
+// xsave (training forward): x^ of this (frame, layer) is kept, packed as it is, at
+// xsave + t * xsave_tstride (the pointer already carries the layer's offset) for the BPTT.
 __global__ void __launch_bounds__(256)
 resid_div_kernel(const float* __restrict__ xp, float* __restrict__ r, const int* t_rd, int* t_wr,
-                 int div, float beta, int F, int Fp, int Bp) {
+                 int div, float beta, int F, int Fp, int Bp, float* __restrict__ xsave,
+                 size_t xsave_tstride) {
     const int t = *t_rd;
     if (t_wr && blockIdx.x == 0 && threadIdx.x == 0) *t_wr = t;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // one block = one 16 x 16 tile
@@ -680,6 +683,7 @@ resid_div_kernel(const float* __restrict__ xp, float* __restrict__ r, const int*
     const int c = 4 * (pos & 3) + (pos >> 6);
     const int f = 16 * ft + c;
     const float xv = xp[(size_t)t * Bp * Fp + i], xe = r[i];
+    if (xsave) xsave[(size_t)t * xsave_tstride + i] = xe;
     float g = 0.f;
     if (f < F) {
         if (div == DRNMF_DIV_KL) g = xv / xe - 1.f;
@@ -1393,6 +1397,11 @@ extern "C" int32_t drnmf_cell_forward_ista(drnmf_handle_t h, const drnmf_cell_de
             hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
                                rs_part, tA, d->N, W.Np, W.Bp, W.numA);
         DRNMF_HIP(h, hipMemsetAsync(psum, 0, (size_t)W.Bp * 4, stream));   // read (times 0) by cell_a
+        if (d->return_all_hidden) {      // the BPTT reads these (times 0) as the reference cell's does
+            DRNMF_HIP(h, hipMemsetAsync(ws + W.off_psum_all, 0, (size_t)d->T * W.Bp * 4, stream));
+            hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream, valid,
+                               (unsigned char*)(ws + W.off_seen), d->T, W.Bp);
+        }
         DRNMF_HIP(h, hipGetLastError());
     }
 
@@ -1469,7 +1478,9 @@ extern "C" int32_t drnmf_cell_forward_ista(drnmf_handle_t h, const drnmf_cell_de
             int* twr = (k == 0) ? tA : nullptr;
             int dv = div;
             float bt = beta;
-            void* kr[9] = {&xpp, &rp, &trd, &twr, &dv, &bt, &F, &Fp, &Bp};
+            float* xsv = W.off_xhat ? (float*)(ws + W.off_xhat) + (size_t)k * Bp * Fp : nullptr;
+            size_t xst = (size_t)K * Bp * Fp;
+            void* kr[11] = {&xpp, &rp, &trd, &twr, &dv, &bt, &F, &Fp, &Bp, &xsv, &xst};
             DRNMF_HIP(h, emit((void*)&resid_div_kernel, grid_r, 256, kr));
             CellAArgs a = make_a(k);
             CellAParams ka(a);

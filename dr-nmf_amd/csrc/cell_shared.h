@@ -384,6 +384,8 @@ struct Workspace {
                            // front, one launch for the whole sequence)
     size_t off_rsave;      // training forward (all hidden layers, fp32, factored): residuals r_k, k >= 1,
                            // row-major [K-1][B*T][Fp] for the BPTT's weight gradients; 0 = absent
+    size_t off_xhat;       // KL / beta cell, training forward: x^_k = h_in Dn_k^T of every (frame, layer),
+                           // tile-packed [T][K][Bp][Fp] (the BPTT needs dg/dx^ there); 0 = absent
 };
 
 Workspace workspace_layout(const drnmf_cell_desc_t* d) {
@@ -481,6 +483,11 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         // (the padding bins of every row must read as zero in the gradient GEMMs: when Fp > F the
         // forward clears the buffer once per call)
         W.off_rsave = take((size_t)(d->K - 1) * d->B * d->T * W.Fp * 4);
+    }
+    W.off_xhat = 0;
+    if (nonlin && d->return_all_hidden) {
+        (void)take(256);                                      // (an offset of 0 means "absent")
+        W.off_xhat = take((size_t)d->T * d->K * W.Bp * W.Fp * 4);
     }
     W.off_t = take(256 + 1024);     // frame counters (256 B) + the persistent chains' sync lines (cell_gram_persist.h)
     W.total = o;

@@ -13,8 +13,9 @@ every other configuration of the layer.  Training likewise: the fused BPTT for t
 trainable set (log_D, log_alph, log_lam1, log_h0), the dense-matrix BPTT (csrc/cell_dense_bwd.hip)
 for everything else the reference can train -- log_U1 / log_Uk, caller maps, free weights, other
 activations -- with torch autograd carrying the matrix gradients through the caller's maps.  There
-is no CPU/oracle fallback: what the kernels do not cover (dropout / regularizers in training, the
-KL / beta extension's BPTT) raises NotImplementedError.
+is no CPU/oracle fallback: what the kernels do not cover (dropout / regularizers in training)
+raises NotImplementedError.  The KL / beta extension of the cell trains through its own BPTT
+(drnmf_cell_backward_ista).
 """
 from collections import OrderedDict
 
@@ -575,9 +576,6 @@ class SimpleDeepRNN(_Layer):
     def forward_train(self, x, mask_value=None):
         """Forward that keeps every layer's hidden state: returns hall [B,T,K*N] (the last N
         columns are the layer output) and leaves the workspace ready for `backward`."""
-        if self.divergence != 'ed':
-            raise NotImplementedError("the KL / beta variant of the cell (an extension, the "
-                                      "reference has no such network) is forward only")
         if self._train_blockers:
             raise NotImplementedError('training with %s is not implemented' %
                                       ', '.join(self._train_blockers))
@@ -595,13 +593,20 @@ class SimpleDeepRNN(_Layer):
         # from the stored hiddens (mixed precision; the rounding is treated as the identity)
         desc = ops.make_desc(B, T, self.input_dim, self.output_dim, self.K_layers, nD, nA,
                              int(self._alt[lab['log_alph'][0]].numel()), nL, True,
-                             operand_f16=self.operand_dtype == 'float16')
+                             operand_f16=self.operand_dtype == 'float16',
+                             divergence=self.divergence)
         key = ('train', B, T)
         if key not in self._ws:
             self._ws.clear()
             self._ws[key] = ops.cell_workspace(desc, x.device)
-        hall = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
-                                workspace=self._ws[key])
+        if self.divergence != 'ed':
+            # the KL / beta variant (an extension): ista_kl / ista_beta (enhance.py:421-456) run
+            # recurrently; its BPTT is drnmf_cell_backward_ista
+            hall = ops.cell_forward_ista(x, mask_value, self._params_block, desc, self.log_h0,
+                                         beta=self.beta, workspace=self._ws[key])
+        else:
+            hall = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
+                                    workspace=self._ws[key])
         self._train_ctx = (desc, key, mask_value)
         return hall
 
@@ -612,7 +617,7 @@ class SimpleDeepRNN(_Layer):
             return self._backward_dense(x, hall, d_out)
         desc, key, _ = self._train_ctx
         return ops.cell_backward(x, self._params_block, desc, self.log_h0, self._u, hall, d_out,
-                                 self._ws[key], grads=grads, profile=profile)
+                                 self._ws[key], grads=grads, profile=profile, beta=self.beta)
 
     # -- training on the dense-matrix path ---------------------------------------------------
     # Whatever maps_from_alt produce (build_alt's maps with a trainable log_U1 / log_Uk, a caller's
@@ -882,9 +887,8 @@ class UnfoldedSNMFModel(object):
         self.opt = dict(lr=float(lr), clipnorm=float(clipnorm), decay=float(decay),
                         b1=float(beta_1), b2=float(beta_2), eps=float(epsilon), iterations=0)
         cell = self.cell
-        if cell.divergence != 'ed':
-            raise NotImplementedError('the KL / beta variant of the cell (an extension; the '
-                                      'reference has no such network) is forward only')
+        if cell.divergence != 'ed' and any(k in ('log_U1', 'log_Uk') for k in cell.keys_trainable):
+            raise NotImplementedError('the KL / beta variant of the cell has no U term to train')
         if cell._train_blockers:
             raise NotImplementedError('training with %s is not implemented' %
                                       ', '.join(cell._train_blockers))

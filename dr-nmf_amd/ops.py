@@ -385,9 +385,11 @@ def snmf_cost_head_backward(x_raw, hidden, kernel_clean, kernel_noise, A, Bn, w,
     return sums, d_hidden, dkc, dkn
 
 
-def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=None, profile=None):
+def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=None, profile=None,
+                  beta=None):
     """BPTT through the cell (forward must have been run with return_all_hidden=True on the same
-    workspace).  Returns dict(d_log_D [n_D,F,N], d_log_alph [n_alph,alph_len], d_log_lam1 [n_lam],
+    workspace).  A KL / beta descriptor (desc.divergence) goes to drnmf_cell_backward_ista with
+    `beta` (u is ignored: that cell has no U term).  Returns dict(d_log_D [n_D,F,N], d_log_alph [n_alph,alph_len], d_log_lam1 [n_lam],
     d_log_h0 [N]); `grads` may supply preallocated output tensors.  `profile` (a dict, bench.py
     only) switches to drnmf_cell_backward_profile, which synchronises and fills chain_ms /
     batched_ms / chain_launches."""
@@ -418,7 +420,15 @@ def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=
             fwd_workspace.numel(), _capi.ptr(bws), nbytes,
             _capi.ptr(out["d_log_D"]), _capi.ptr(out["d_log_alph"]),
             _capi.ptr(out["d_log_lam1"]), _capi.ptr(out["d_log_h0"]), _stream())
-    if profile is not None:
+    if desc.divergence != _capi.DIV_ED:
+        rc = L.drnmf_cell_backward_ista(
+            h, C.byref(desc), _capi.ptr(x), _capi.ptr(params), _capi.ptr(log_h0),
+            float(1.5 if beta is None else beta), _capi.ptr(hall), _capi.ptr(d_out),
+            _capi.ptr(fwd_workspace), fwd_workspace.numel(), _capi.ptr(bws), nbytes,
+            _capi.ptr(out["d_log_D"]), _capi.ptr(out["d_log_alph"]), _capi.ptr(out["d_log_lam1"]),
+            _capi.ptr(out["d_log_h0"]), _stream())
+        _capi.check(rc, h, "drnmf_cell_backward_ista")
+    elif profile is not None:
         res = (C.c_float * 3)()
         rc = L.drnmf_cell_backward_profile(*(args + (res,)))
         _capi.check(rc, h, "drnmf_cell_backward_profile")
@@ -603,8 +613,13 @@ class SnmfTrainer(object):
                                           _capi.ptr(self.ws), self.nbytes, _stream())
         _capi.check(rc, self.h, "drnmf_snmf_train_init")
 
-    def step(self, sparsity, w_update_mask=None, update_w=True):
-        obj = torch.empty(2, dtype=torch.float32, device=self.V.device)
+    def step(self, sparsity, w_update_mask=None, update_w=True, obj=None):
+        """obj: a 2-element float32 device tensor (e.g. a row of a preallocated [max_iter, 2] log)
+        that receives [div, cost]; allocated here when None.  Nothing is synchronised."""
+        if obj is None:
+            obj = torch.empty(2, dtype=torch.float32, device=self.V.device)
+        elif obj.numel() != 2 or obj.dtype != torch.float32 or not obj.is_contiguous():
+            raise ValueError("obj must be a contiguous float32 tensor of 2 elements")
         m = None
         if w_update_mask is not None:
             m = w_update_mask.to(device=self.V.device, dtype=torch.uint8).contiguous()

@@ -53,19 +53,34 @@ def sparse_nmf_on_chunk(V, params, rng, device, verbose=False):
     tr = ops.SnmfTrainer(t(V.T), t(w0), t(h0.T), beta=beta)
     mask = torch.from_numpy(w_ind.astype(np.uint8)).to(device)
     update_w = bool(w_ind.any())
-    divs, costs, last = [], [], np.inf
+    # The objective of every iteration lands in a device log and is read ONCE at the end: with
+    # conv_eps == 0 (enhance.py:842 and every shipped configuration; sparse_nmf_gpu.m:287-296 only
+    # tests convergence when conv_eps > 0) the loop never waits for the device.  With conv_eps > 0
+    # the log is inspected after every iteration, as the reference does (the run stops AT the
+    # iteration that meets the criterion); params['conv_check_every'] = n (an extension) inspects it
+    # every n iterations instead and may therefore run up to n - 1 iterations longer.
+    log = torch.zeros((max(max_iter, 1), 2), dtype=torch.float32, device=device)
+    check = 1 if verbose else max(1, int(params.get('conv_check_every', 1)))
+    done = 0
     for it in range(max_iter):
-        obj = tr.step(sparsity, mask, update_w).cpu().numpy()      # one sync per iteration
-        divs.append(float(obj[0]))
-        costs.append(float(obj[1]))
+        tr.step(sparsity, mask, update_w, obj=log[it])
+        done = it + 1
         if verbose:
-            print('iteration %d div = %.3e cost = %.3e' % (it + 1, obj[0], obj[1]))
-        if it > 0 and conv_eps > 0 and abs(costs[-1] - last) / last < conv_eps:   # :287-296
-            break
-        last = costs[-1]
+            o = log[it].cpu().numpy()
+            print('iteration %d div = %.3e cost = %.3e' % (it + 1, o[0], o[1]))
+        if conv_eps > 0 and it > 0 and (done % check == 0 or done == max_iter):
+            c = log[:done, 1].cpu().numpy().astype(np.float64)     # one read per `check` iterations
+            lo = max(1, done - check)
+            rel = np.abs(c[lo:done] - c[lo - 1:done - 1]) / c[lo - 1:done - 1]   # :287-296
+            hit = np.nonzero(rel < conv_eps)[0]
+            if hit.size:
+                if check == 1:
+                    done = lo + int(hit[0]) + 1
+                break
+    objs = log[:done].cpu().numpy()
     W = tr.W.cpu().numpy().astype(V.dtype)
     H = tr.H.cpu().numpy().T.astype(V.dtype)
-    return W, H, {'cost': np.array(costs), 'div': np.array(divs)}
+    return W, H, {'cost': objs[:, 1].astype(np.float64), 'div': objs[:, 0].astype(np.float64)}
 
 
 def sparse_nmf(V, params, verbose=False, save_H=True, device=None, max_frame_batch_size=700000):

@@ -66,8 +66,8 @@ typedef struct drnmf_cell_desc {
                                 * is the fp32 BPTT of that forward (mixed precision: the prepared
                                 * block carries fp32 packings beside the fp16 ones)            */
     int32_t divergence;        /* DRNMF_DIV_ED (0): the reference's cell.  DRNMF_DIV_KL / _BETA: the
-                                * warm-started ISTA cell of drnmf_cell_forward_ista (extension,
-                                * forward only)                                                  */
+                                * warm-started ISTA cell of drnmf_cell_forward_ista /
+                                * drnmf_cell_backward_ista (extension)                           */
 } drnmf_cell_desc_t;
 
 int32_t drnmf_version(void);
@@ -266,6 +266,18 @@ int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const 
                             const void* fwd_workspace, size_t fwd_workspace_bytes,
                             void* bwd_workspace, size_t bwd_workspace_bytes, float* d_log_D,
                             float* d_log_alph, float* d_log_lam1, float* d_log_h0, void* stream);
+
+/* BPTT of the KL / beta variant of the cell (drnmf_cell_forward_ista run with return_all_hidden = 1 on
+ * the same x / params / workspace; the iteration differentiated is ista_kl / ista_beta,
+ * enhance.py:421-456): same inputs and outputs as drnmf_cell_backward, `beta` as in the forward.
+ * Every layer -- layer 0 included -- is a full step h <- relu(h_in + (g(x, h_in Dn^T) Dn) / alpha + b)
+ * from its input (layer 0 from the recurrent state), with no U term. */
+int32_t drnmf_cell_backward_ista(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                 const void* params, const float* log_h0, float beta,
+                                 const float* hall, const float* d_out, const void* fwd_workspace,
+                                 size_t fwd_workspace_bytes, void* bwd_workspace,
+                                 size_t bwd_workspace_bytes, float* d_log_D, float* d_log_alph,
+                                 float* d_log_lam1, float* d_log_h0, void* stream);
 
 /* Measurement aid (bench.py only; no reference counterpart): the same backward with HIP events at
  * its phase boundaries; SYNCHRONISES the stream and returns

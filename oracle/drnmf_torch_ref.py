@@ -13,9 +13,12 @@ def unit_cols(logD):
 
 
 def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, square=False,
-               normalise=True, snmf_cost_l1_weight=None):
+               normalise=True, snmf_cost_l1_weight=None, divergence='ed', beta=1.5):
     """x, y: (B,T,F) float64 tensors; w: (B,T) sample weights (= validity mask in the reference).
-    alt: dict name -> tensor (requires_grad where wanted).  Returns (loss, mask, h)."""
+    alt: dict name -> tensor (requires_grad where wanted).  Returns (loss, mask, h).
+    divergence 'kl' | 'beta': the KL / beta variant of the cell (oracle.cell_forward_ista_warm: every
+    layer, layer 0 included, a full ista_kl / ista_beta step from its input -- enhance.py:421-456 --
+    and no U term)."""
     B, T, F = x.shape
     N = log_h0.shape[0]
     r = N // 2
@@ -37,11 +40,26 @@ def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, s
         p = state
         ps = p.sum(1, keepdim=True)
         xt = xm[:, t]
-        h = torch.relu(u0d * p + u0o * (ps - p) + (xt @ Dns[0]) * ias[0] - lams[0] * ias[0])
-        for k in range(1, K):
-            Dn, ia, lam = Dns[k], ias[k], lams[k]
-            rr = xt - h @ Dn.t()
-            h = torch.relu(h + (rr @ Dn) * ia - lam * ia + uko * ps)
+        if divergence == 'ed':
+            h = torch.relu(u0d * p + u0o * (ps - p) + (xt @ Dns[0]) * ias[0] - lams[0] * ias[0])
+            for k in range(1, K):
+                Dn, ia, lam = Dns[k], ias[k], lams[k]
+                rr = xt - h @ Dn.t()
+                h = torch.relu(h + (rr @ Dn) * ia - lam * ia + uko * ps)
+        else:
+            h = p
+            vrow = valid[:, t][:, None]
+            for k in range(K):
+                Dn, ia, lam = Dns[k], ias[k], lams[k]
+                xe = h @ Dn.t()
+                # a masked row's result is discarded below, but 0 / 0 there would still poison the
+                # gradients (0 * nan): keep the discarded branch finite
+                xe = torch.where(vrow, xe, torch.ones_like(xe))
+                if divergence == 'kl':
+                    rr = xt / xe - 1.0                                   # enhance.py:431
+                else:
+                    rr = xt * xe ** (beta - 2.0) - xe ** (beta - 1.0)    # enhance.py:450
+                h = torch.relu(h + (rr @ Dn) * ia - lam * ia)
         v = valid[:, t][:, None]
         out_prev = torch.where(v, h, out_prev)
         state = torch.where(v, h, state)

@@ -819,7 +819,7 @@ def test_kl_beta_cell_entry_points_are_kept_apart(dev):
 
 def test_kl_cell_through_the_layer_surface(dev):
     """build_unfolded_snmf(..., divergence='kl') (extension key): the model predicts with the KL
-    cell under the unchanged mask head; training is refused."""
+    cell under the unchanged mask head and trains (gradients: tests/test_gpu_train.py)."""
     from drnmf_amd import layers
     B, T, F, r, K = 5, 7, 33, 10, 3
     P = O.synth_problem(B, T, F, r, seed=4, ragged=True, density=0.3)
@@ -839,8 +839,9 @@ def test_kl_cell_through_the_layer_surface(dev):
                                  divergence="kl")
     ref, _, _ = O.head_forward(h, wd["kc"], wd["kn"])
     assert np.mean((irm - ref) ** 2) <= MASK_MSE_TOL
-    with pytest.raises(NotImplementedError):
-        model.compile(lr=1e-3)
+    model.compile(lr=1e-3)                       # the KL / beta cell has its own BPTT
+    wmask = (P["X"] != -1.0).any(-1).astype(np.float32)
+    assert np.isfinite(model.train_on_batch(P["X"], P["Y"], wmask))
     with pytest.raises(ValueError):
         layers.build_unfolded_snmf(dict(p, divergence="is"), device=dev)
 

@@ -24,10 +24,12 @@ def dev():
 
 
 def _setup(B, T, F, r, K, untied, untie_alph=False, square=False, seed=5, masked_head=False,
-           trainable=("log_D", "log_alph")):
+           trainable=("log_D", "log_alph"), divergence="ed", beta=1.5):
     from drnmf_amd import layers
     np.random.seed(seed)          # log_h0's 'uniform' initialiser draws from the global generator
-    P = O.synth_problem(B, T, F, r, seed=seed, ragged=True, density=0.15)
+    P = O.synth_problem(B, T, F, r, seed=seed, ragged=True, density=0.3 if divergence != "ed" else 0.15)
+    if divergence != "ed":       # keep x^ away from 0 (ista_kl / ista_beta divide by it, enhance.py:431,450)
+        P["X"] = np.where(P["X"] == -1.0, -1.0, P["X"] + 0.1).astype(np.float32)
     if masked_head:
         P["X"][0, :2] = -1.0
         P["Y"][0, :2] = -1.0
@@ -35,8 +37,12 @@ def _setup(B, T, F, r, K, untied, untie_alph=False, square=False, seed=5, masked
     p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
              W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=list(untied),
              params_trainable=list(trainable), untie_alph=untie_alph)
+    if divergence != "ed":       # small steps: the KL / beta iteration must not drive h (hence x^) to 0
+        p.update(alph=2.0 * N, lam1=0.05)
     if square:
         p["transform_before_irm"] = "square"
+    if divergence != "ed":
+        p.update(divergence=divergence, beta=beta)
     model = layers.build_unfolded_snmf(p)
     rng = np.random.default_rng(seed)
     w = model.get_weights()
@@ -47,7 +53,7 @@ def _setup(B, T, F, r, K, untied, untie_alph=False, square=False, seed=5, masked
     return model, P, wmask
 
 
-def _autograd(model, P, wmask, K, square, snmf_cost_l1_weight=None):
+def _autograd(model, P, wmask, K, square, snmf_cost_l1_weight=None, divergence="ed", beta=1.5):
     names = ["log_h0"] + list(model.cell._alt.keys()) + ["kc", "kn"]
     wd = {n: torch.tensor(a, dtype=torch.float64, requires_grad=True)
           for n, a in zip(names, model.get_weights())}
@@ -57,7 +63,8 @@ def _autograd(model, P, wmask, K, square, snmf_cost_l1_weight=None):
     w = torch.tensor(wmask, dtype=torch.float64)
     loss, mask, hs = TR.model_loss(x, y, w, alt, model.cell.maps_from_alt.labels_per_k, K,
                                    wd["log_h0"], wd["kc"], wd["kn"], square=square,
-                                   normalise=False, snmf_cost_l1_weight=snmf_cost_l1_weight)
+                                   normalise=False, snmf_cost_l1_weight=snmf_cost_l1_weight,
+                                   divergence=divergence, beta=beta)
     loss.backward()
     return float(loss.detach()), {n: (t.grad.numpy() if t.grad is not None else None)
                          for n, t in wd.items()}, float((w != 0).sum())
@@ -147,6 +154,50 @@ def test_long_sequence_gradients_match_autograd(dev, cfg):
         assert err <= G_TOL, "%s: rel err %.3e (max ref %.3e)" % (n, err, scale)
         checked += 1
     assert checked >= 4
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, T=6, F=21, r=6, K=3, untied=("log_D", "log_alph"), divergence="kl"),
+    dict(B=4, T=5, F=33, r=8, K=1, untied=(), divergence="kl"),
+    dict(B=2, T=7, F=40, r=10, K=4, untied=(), trainable=("log_D", "log_alph", "log_lam1"),
+         divergence="beta", beta=1.5),
+    dict(B=5, T=4, F=65, r=16, K=2, untied=("log_D", "log_alph"), untie_alph=True, divergence="beta",
+         beta=0.5),
+    dict(B=18, T=9, F=257, r=20, K=2, untied=("log_D", "log_alph"), divergence="kl"),
+    dict(B=3, T=140, F=21, r=6, K=3, untied=("log_D", "log_alph"), divergence="kl"),     # > 2 graph blocks
+    dict(B=6, T=70, F=33, r=8, K=2, untied=("log_D", "log_alph"), divergence="beta", beta=3.0,
+         masked_head=True),
+])
+def test_kl_beta_cell_gradients_match_autograd(dev, cfg):
+    """BPTT of the KL / beta variant of the cell (drnmf_cell_backward_ista) against torch-CPU fp64
+    autograd of the oracle restatement of the same recurrence (ista_kl / ista_beta, enhance.py:421-456,
+    run per frame from the previous frame's output)."""
+    cfg = dict(cfg)
+    K = cfg["K"]
+    div, beta = cfg["divergence"], cfg.get("beta", 1.5)
+    model, P, wmask = _setup(**cfg)
+    model.compile(lr=1e-3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    flat = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(wmask)).clone()
+    torch.cuda.synchronize()
+    ref_loss, ref, cnt = _autograd(model, P, wmask, K, False, divergence=div, beta=beta)
+    assert np.isfinite(ref_loss)
+    assert abs(float(flat[-3]) - ref_loss) <= 2e-5 * abs(ref_loss) + 1e-9
+    assert float(flat[-2]) == cnt
+    name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
+    checked = 0
+    for n, _ in model._train_items:
+        g = model._gview[n].cpu().numpy()
+        r_ = ref[name_map.get(n, n)]
+        assert r_ is not None, n
+        scale = max(np.max(np.abs(r_)), 1e-12)
+        err = np.max(np.abs(g - r_)) / scale
+        assert err <= G_TOL, "%s: rel err %.3e (max ref %.3e)" % (n, err, scale)
+        checked += 1
+    assert checked >= 4
+    # and a few Adam steps reduce the loss
+    losses = [model.train_on_batch(P["X"], P["Y"], wmask) for _ in range(6)]
+    assert losses[-1] < losses[0]
 
 
 def test_train_on_batch_matches_reference_adam_step_and_learns(dev):
