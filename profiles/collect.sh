@@ -31,6 +31,16 @@ stats fwd "$B" --forward-only --steps 1 --warmup 1 --no-cpu-baseline --no-extras
 stats ista "$ROOT/tools/ista_profile.py" 32768 513 2000 25
 stats c5 "$ROOT/tools/c5_profile.py" 16
 stats train_c3 "$ROOT/tools/train_profile.py" 32 500 257 1000 5 3
+# the other shipped dictionary size (r = 100): persistent Gram chains (cell_gram_persist.h), forward + BPTT
+stats train_r100 "$ROOT/tools/train_profile.py" 32 500 257 100 5 10
+# small-shape lines alone, unprofiled (C1 + the r = 100 / r = 1000 training steps), persistent chains on / off
+python3 "$ROOT/tools/small_shapes.py" 20 > "$OUT/small_shapes.json" 2> "$OUT/small_shapes.err"
+DRNMF_PERSIST=0 python3 "$ROOT/tools/small_shapes.py" 20 > "$OUT/small_shapes_persist0.json" 2>> "$OUT/small_shapes.err"
+# N > 1 path of bench.py on the one GPU of this box: two ranks over gloo, torch all-reduce selected
+# EXPLICITLY (RCCL refuses two ranks on one device); the only multi-rank run a 1-GPU box allows
+DRNMF_BENCH_BACKEND=gloo DRNMF_BENCH_DEVICE=0 DRNMF_DP_BACKEND=torch timeout 900 python3 -m torch.distributed.run \
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 "$B" --gpus 2 --frames 400 \
+    --steps 2 --warmup 1 --no-extras --no-cpu-baseline > "$OUT/n2_gloo_one_gpu.json" 2> "$OUT/n2_gloo_one_gpu.err"
 # 5. PMC passes, 20 frames of the headline forward (cell + head only)
 SMALL="--forward-only --frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch" -o p -- python3 "$B" $SMALL \
