@@ -545,15 +545,16 @@ struct EpiP2 {      // partial[split] -= acc
 // ran 63 workgroups for a whole layer: 0.4 ms at C2.)
 __global__ void __launch_bounds__(256)
 dlogd_sum_kernel(float* __restrict__ P, const float* __restrict__ Dn, float* __restrict__ cpart,
-                 int F, int N, int Np, int splits, size_t stride) {
+                 int F, int N, int Np, int splits, size_t stride, int bpt) {
+    // bpt = bins per thread: 4 (16 bins per workgroup), or 1 for narrow dictionaries, whose handful
+    // of workgroups would otherwise walk 64 split partials x 4 bins each (N = 200: 17 workgroups, 78 us)
     __shared__ f32x4 cs[4][64];
     const int qn = threadIdx.x & 63, fl = threadIdx.x >> 6;
     const int n = (blockIdx.x * 64 + qn) * 4;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = blockIdx.y * 16 + fl * 4 + i;
+        for (int i = 0; i < bpt; ++i) {
+            const int f = (blockIdx.y * 4 + fl) * bpt + i;
             if (f >= F) break;
             const size_t o = (size_t)f * Np + n;
             f32x4 g = *(const f32x4*)(P + o);
@@ -572,15 +573,14 @@ dlogd_sum_kernel(float* __restrict__ P, const float* __restrict__ Dn, float* __r
 __global__ void __launch_bounds__(256)
 dlogd_apply_kernel(const float* __restrict__ P, const float* __restrict__ Dn,
                    const float* __restrict__ cpart, float* __restrict__ dlogD, int F, int N, int Np,
-                   int ngroups, int accumulate) {
+                   int ngroups, int accumulate, int bpt) {
     const int qn = threadIdx.x & 63, fl = threadIdx.x >> 6;
     const int n = (blockIdx.x * 64 + qn) * 4;
     if (n >= N) return;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     for (int gq = 0; gq < ngroups; ++gq) c += *(const f32x4*)(cpart + (size_t)gq * Np + n);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = blockIdx.y * 16 + fl * 4 + i;
+    for (int i = 0; i < bpt; ++i) {
+        const int f = (blockIdx.y * 4 + fl) * bpt + i;
         if (f >= F) break;
         const size_t o = (size_t)f * Np + n;
         const f32x4 g = *(const f32x4*)(P + o), dn = *(const f32x4*)(Dn + o);
@@ -794,6 +794,97 @@ __global__ void __launch_bounds__(256) colreduce4_kernel(const ColRedArgs a) {
     *(f32x4*)(o + (size_t)3 * a.Np) = s2;
 }
 
+// The same sums for NARROW dictionaries (N / 4 <= 64 atom quads): the 256 threads of a workgroup are
+// 64 quads x 4 row lanes -- lane rl takes the rows r0 + rl, r0 + rl + 4, ... of the split -- and the four
+// partial sums meet in LDS in a fixed order.  (With one thread per quad an N = 200 layer ran 50 threads
+// per workgroup through 62 dependent rows each: 72 us.)
+__global__ void __launch_bounds__(256) colreduce4_rows_kernel(const ColRedArgs a) {
+    __shared__ f32x4 acc[4][4][64];
+    const int qn = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = qn * 4;
+    const int sp = blockIdx.y;
+    const bool live = n < a.N;
+    const int64_t BT = (int64_t)a.B * a.T;
+    const int64_t per = (BT + CR_SPLITS - 1) / CR_SPLITS;
+    const int64_t r0 = sp * per;
+    int64_t r1 = r0 + per;
+    if (r1 > BT) r1 = BT;
+    const int KN = a.K * a.N;
+    f32x4 sb = {0.f, 0.f, 0.f, 0.f}, sg = sb, s1 = sb, s2 = sb;
+    if (live) {
+        const f32x4 bk = *(const f32x4*)(a.bias + n);
+        f32x4 h0v = {0.f, 0.f, 0.f, 0.f};
+        if (a.k == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = a.log_h0[n + e];
+                h0v[e] = (z > 20.f) ? z : log1pf(expf(z));
+            }
+        }
+        const bool tail = a.rt != nullptr, tail2 = tail && a.k >= 1;
+        const float* dzp = a.dz_all + (size_t)a.k * a.N + n;
+        const float* hpp = a.hall + (size_t)(a.k >= 1 ? a.k - 1 : 0) * a.N + n;
+        constexpr int U = 4;
+        for (int64_t bt0 = r0 + rl; bt0 < r1; bt0 += 4 * U) {
+            f32x4 dzv[U], hpv[U];
+            float rtv[U], drv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int64_t bt = bt0 + 4 * u;
+                bt = bt < r1 ? bt : r1 - 1;
+                dzv[u] = *(const f32x4*)(dzp + bt * KN);
+                if (tail) rtv[u] = a.rt[bt * a.ldr];
+                if (tail2) {
+                    hpv[u] = *(const f32x4*)(hpp + bt * KN);
+                    drv[u] = a.drt[bt * a.ldr];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t bt = bt0 + 4 * u;
+                if (bt >= r1) break;
+                if (tail2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s2[e] = fmaf(drv[u], hpv[u][e], s2[e]);
+                }
+                const f32x4 dz = dzv[u];
+                if (dz[0] == 0.f && dz[1] == 0.f && dz[2] == 0.f && dz[3] == 0.f) continue;
+                const int b = (int)(bt / a.T), t = (int)(bt - (int64_t)b * a.T);
+                const float ps = a.psum_all[(size_t)t * a.Bp + b];
+                const f32x4 hk = *(const f32x4*)(a.hall + bt * KN + (size_t)a.k * a.N + n);
+                f32x4 base;
+                if (a.k == 0) {
+                    f32x4 p = h0v;
+                    if (a.seen[(size_t)t * a.Bp + b])
+                        p = *(const f32x4*)(a.hall + (bt - 1) * KN + (size_t)(a.K - 1) * a.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) base[e] = a.u0d * p[e] + a.u0o * (ps - p[e]) + bk[e];
+                } else {
+                    const f32x4 hp = tail2 ? hpv[u]
+                                           : *(const f32x4*)(a.hall + bt * KN + (size_t)(a.k - 1) * a.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) base[e] = hp[e] + bk[e] + a.uko * ps;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (dz[e] == 0.f) continue;
+                    if (tail) s1[e] = fmaf(rtv[u], dz[e], s1[e]);
+                    sb[e] += dz[e];
+                    sg[e] = fmaf(dz[e], hk[e] - base[e], sg[e]);
+                }
+            }
+        }
+    }
+    acc[0][rl][qn] = sb; acc[1][rl][qn] = sg; acc[2][rl][qn] = s1; acc[3][rl][qn] = s2;
+    __syncthreads();
+    if (rl == 0 && live) {
+        float* o = a.part + (size_t)sp * CR_SLOTS * a.Np + n;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+            *(f32x4*)(o + (size_t)sl * a.Np) = (acc[sl][0][qn] + acc[sl][1][qn]) + (acc[sl][2][qn] + acc[sl][3][qn]);
+    }
+}
+
 // stage 1 of the scalar gradients: the CR_SPLITS partial sums of every atom, added in split order
 // (one thread per atom; slot 0 of `part` receives the totals).  With an odd-bin row (Ptail != null)
 // its gradient ia[n] S1[n] - S2[n] goes where the GEMM partials of that row would have been: split 0
@@ -815,6 +906,37 @@ colreduce_fold_kernel(float* __restrict__ part, int N, int Np, float* __restrict
     part[(size_t)Np + n] = sg;
     if (Ptail) {
         Ptail[n] = ia[n] * s1 - s2;
+        for (int s = 1; s < splits; ++s) Ptail[s * pstride + n] = 0.f;
+    }
+}
+
+// The same for narrow dictionaries: 64 atoms x 4 split lanes per workgroup (one thread per atom walked
+// 256 splits x 4 slots of dependent loads: 30 us for N = 200); fixed combination order.
+__global__ void __launch_bounds__(256)
+colreduce_fold_lanes_kernel(float* __restrict__ part, int N, int Np, float* __restrict__ Ptail,
+                            const float* __restrict__ ia, int splits, size_t pstride) {
+    __shared__ float acc[4][4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float sb = 0.f, sg = 0.f, s1 = 0.f, s2 = 0.f;
+    if (n < N)
+        for (int s = sl; s < CR_SPLITS; s += 4) {
+            const float* p = part + (size_t)s * CR_SLOTS * Np + n;
+            sb += p[0];
+            sg += p[(size_t)Np];
+            s1 += p[(size_t)2 * Np];
+            s2 += p[(size_t)3 * Np];
+        }
+    acc[0][sl][c] = sb; acc[1][sl][c] = sg; acc[2][sl][c] = s1; acc[3][sl][c] = s2;
+    __syncthreads();
+    if (sl != 0 || n >= N) return;
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (acc[k][0][c] + acc[k][1][c]) + (acc[k][2][c] + acc[k][3][c]);
+    part[n] = t[0];
+    part[(size_t)Np + n] = t[1];
+    if (Ptail) {
+        Ptail[n] = ia[n] * t[2] - t[3];
         for (int s = 1; s < splits; ++s) Ptail[s * pstride + n] = 0.f;
     }
 }
@@ -1346,27 +1468,36 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         ca.seen = seen; ca.log_h0 = log_h0; ca.part = crp;
         ca.u0d = u0_diag; ca.u0o = u0_off; ca.uko = uk_off;
         ca.k = k; ca.B = B; ca.T = T; ca.N = N; ca.K = K; ca.Bp = W.Bp; ca.Np = W.Np;
-        if (N % 4 == 0)   // (Np, K*N, the buffers' bases: multiples of 4 floats then)
+        if (N % 4 == 0 && N / 4 <= 64)
+            hipLaunchKernelGGL(colreduce4_rows_kernel, dim3(1, CR_SPLITS), dim3(256), 0, stream, ca);
+        else if (N % 4 == 0)   // (Np, K*N, the buffers' bases: multiples of 4 floats then)
             hipLaunchKernelGGL(colreduce4_kernel, dim3((N / 4 + 255) / 256, CR_SPLITS), dim3(256), 0,
                                stream, ca);
         else
             hipLaunchKernelGGL(colreduce_kernel, dim3((N + 255) / 256, CR_SPLITS), dim3(256), 0,
                                stream, ca);
         const int ka = d->n_alph == 1 ? 0 : k, kl = d->n_lam == 1 ? 0 : k;
-        hipLaunchKernelGGL(colreduce_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, crp,
-                           N, W.Np, odd ? P + (size_t)(F - 1) * W.Np : (float*)nullptr, ia_of(k),
-                           nsplit, pstr);
+        if (N <= 512)
+            hipLaunchKernelGGL(colreduce_fold_lanes_kernel, dim3((N + 63) / 64), dim3(256), 0, stream,
+                               crp, N, W.Np, odd ? P + (size_t)(F - 1) * W.Np : (float*)nullptr,
+                               ia_of(k), nsplit, pstr);
+        else
+            hipLaunchKernelGGL(colreduce_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, crp,
+                               N, W.Np, odd ? P + (size_t)(F - 1) * W.Np : (float*)nullptr, ia_of(k),
+                               nsplit, pstr);
         const int kd = d->n_D == 1 ? 0 : k;
         if (N % 4 == 0) {
             // (cpart: the split >= 2 slots of the column-reduction partials, dead after the fold)
             float* cpart = crp + (size_t)2 * CR_SLOTS * W.Np;
-            const int ngroups = (F + 15) / 16;
+            // 16 bins per workgroup, or 4 where that leaves fewer than 128 workgroups
+            const int bpt = ((N / 4 + 63) / 64) * ((F + 15) / 16) < 128 ? 1 : 4;
+            const int ngroups = (F + 4 * bpt - 1) / (4 * bpt);
             const dim3 dgrid((N / 4 + 63) / 64, ngroups);
             hipLaunchKernelGGL(dlogd_sum_kernel, dgrid, dim3(256), 0, stream, P, Dn_rm, cpart, F, N,
-                               W.Np, nsplit, pstr);
+                               W.Np, nsplit, pstr, bpt);
             hipLaunchKernelGGL(dlogd_apply_kernel, dgrid, dim3(256), 0, stream, P, Dn_rm, cpart,
                                d_log_D + (size_t)kd * F * N, F, N, W.Np, ngroups,
-                               (d->n_D == 1 && k > 0) ? 1 : 0);
+                               (d->n_D == 1 && k > 0) ? 1 : 0, bpt);
         } else {
             hipLaunchKernelGGL(dlogd_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, P, Dn_rm,
                                d_log_D + (size_t)kd * F * N, F, N, W.Np, nsplit, pstr,
