@@ -302,3 +302,49 @@ def test_persistent_chains_from_concurrent_streams(dev, monkeypatch):
     # and the handle still works (no timeout was recorded)
     again = TP._run_cell(dev, *probs[0], K)[0]
     assert np.array_equal(again, serial[0])
+
+
+def test_fuzz_persistent_chains_bit_identical(dev, monkeypatch):
+    """Seeded sweep of the shapes the persistent chains accept (1-8 row tiles, 1-32 output tiles, K = 2..6,
+    T on both sides of the 64-frame blocks and of the all-frames-resident switch, ragged, all-hidden):
+    forward outputs and every gradient bit for bit against the launch-per-layer-step graphs."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as TP
+    from drnmf_amd import layers
+    rng = np.random.default_rng(303)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    for it in range(14):
+        B = int(rng.choice([1, 5, 16, 17, 40, 100, 128]))
+        T = int(rng.choice([1, 2, 63, 64, 65, 129, 200]))
+        F = int(rng.choice([17, 33, 65]))
+        r = int(rng.choice([4, 8, 20, 60, 100, 250]))
+        K = int(rng.integers(2, 7))
+        if B * T * r > 600000:
+            T = max(1, 600000 // (B * r))
+        ah = bool(rng.integers(0, 2))
+        P, alt, labels, N = TP._problem(B, T, F, r, K, untied=("log_D", "log_alph"), ragged=B > 1,
+                                        seed=100 + it)
+        outs = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("DRNMF_GRAM", "1")
+            monkeypatch.setenv("DRNMF_PERSIST", mode)
+            outs[mode] = TP._run_cell(dev, P, alt, labels, N, K, return_all_hidden=ah)[0].copy()
+        assert np.array_equal(outs["0"], outs["1"]), dict(B=B, T=T, F=F, r=r, K=K, ah=ah, it=it)
+        if it % 2:
+            continue
+        # gradients through the model surface
+        Pm = O.synth_problem(B, T, F, r, seed=200 + it, ragged=True, density=0.15)
+        p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+                 W=Pm["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+                 params_trainable=["log_D", "log_alph", "log_lam1"])
+        w = (Pm["X"] != -1.0).any(-1).astype(np.float32)
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("DRNMF_PERSIST", mode)
+            np.random.seed(5)
+            model = layers.build_unfolded_snmf(p, device=dev)
+            model.compile(lr=1e-3)
+            res[mode] = model.loss_and_grads(t(Pm["X"]), t(Pm["Y"]), t(w)).cpu().numpy().copy()
+        assert np.array_equal(res["0"], res["1"]), dict(B=B, T=T, F=F, r=r, K=K, it=it)
