@@ -612,14 +612,21 @@ static inline bool persist_shape_ok(int numM, int numO, int K) {
     if (K < 2 || K > PERSIST_MAX_K || numO > PERSIST_MAX_TILES || numM > PERSIST_MAX_CHAINS) return false;
     if (const char* e = getenv("DRNMF_PERSIST"))
         if (atoi(e) == 0) return false;
-    static int per_cu = -1;
+    static int per_cu = -1, n_cu = 0;
     if (per_cu < 0) {
-        int a = 0, b = 0;
+        int a = 0, b = 0, dev = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gram_persist_kernel<4>, 64 * (NW_G + 1), persist_fwd_lds(PERSIST_MAX_K, true)) != hipSuccess) a = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gram_persist_bwd_kernel<4>, 64 * (NW_G + 1), 0) != hipSuccess) b = 0;
         per_cu = a < b ? a : b;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n_cu = 0;
+        (void)hipGetLastError();
     }
-    return per_cu >= 1;       // 32 CUs per XCD x >= 1 workgroup: a chain of <= 32 always fits
+    // one workgroup per CU suffices where chain m really lands on XCD m's 32 CUs (the whole MI355X as one
+    // device); on a smaller partition (fewer CUs than 8 x 32) every participant of every chain must
+    // still fit the device at once
+    return per_cu >= 1 && numM * numO <= n_cu * per_cu;
 }
 
 void* pick_persist_fwd(int NAC) {

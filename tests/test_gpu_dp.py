@@ -348,3 +348,37 @@ def test_fuzz_persistent_chains_bit_identical(dev, monkeypatch):
             model.compile(lr=1e-3)
             res[mode] = model.loss_and_grads(t(Pm["X"]), t(Pm["Y"]), t(w)).cpu().numpy().copy()
         assert np.array_equal(res["0"], res["1"]), dict(B=B, T=T, F=F, r=r, K=K, it=it)
+
+
+def test_persistent_chains_next_to_a_busy_stream(dev, monkeypatch):
+    """the chains' in-kernel barriers with ANOTHER stream occupying the CUs (here a
+    stream of large GEMMs, as an RCCL kernel or a second model would): the persistent launches must
+    complete -- late if their workgroups have to wait for CUs, never wrong -- and leave no timeout."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as TP
+    from drnmf_amd import ops
+    monkeypatch.setenv("DRNMF_GRAM", "1")
+    monkeypatch.setenv("DRNMF_PERSIST", "1")
+    B, T, F, r, K = 32, 256, 33, 100, 4
+    P, alt, labels, N = TP._problem(B, T, F, r, K, untied=("log_D", "log_alph"), ragged=True, seed=77)
+    ref, params, desc = TP._run_cell(dev, P, alt, labels, N, K)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    x, lh0, u = t(P["X"]), t(P["log_h0"]), O.u_scalars(alt, np.float32)
+    a = torch.randn((8192, 8192), device=dev)
+    b = torch.randn((8192, 8192), device=dev)
+    torch.cuda.synchronize()
+    busy, work = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outs = []
+    for rep in range(3):
+        with torch.cuda.stream(busy):
+            for _ in range(6):
+                c = a @ b                                   # ~1.1 TFLOP each: the chip is full for milliseconds
+        with torch.cuda.stream(work):
+            outs.append(ops.cell_forward(x, -1.0, params, desc, lh0, u))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), ref)
+    again = TP._run_cell(dev, P, alt, labels, N, K)[0]      # no DRNMF_ERR_TIMEOUT pending
+    assert np.array_equal(again, ref)
