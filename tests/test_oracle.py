@@ -292,3 +292,29 @@ def test_torch_dense_cell_matches_numpy_oracle():
                                torch.tensor(b), torch.tensor(h0), return_all_hidden=ah,
                                activation=act).numpy()
             assert np.max(np.abs(got - ref)) < 1e-12
+
+
+@pytest.mark.parametrize("divergence,beta", [("kl", 1.5), ("beta", 0.5), ("beta", 1.5), ("beta", 3.0)])
+def test_torch_kl_beta_cell_matches_numpy_oracle(divergence, beta):
+    """oracle/drnmf_torch_ref.model_loss(divergence=...) -- the autograd reference of the KL / beta
+    cell's BPTT -- computes the same hidden states as cell_forward_ista_warm (which
+    test_warm_ista_cell_is_the_reference_iteration_run_recurrently pins to the reference's own
+    ista_kl / ista_beta), ragged lengths included."""
+    import torch
+    from oracle import drnmf_torch_ref as TR
+    B, T, F, r, K = 3, 7, 21, 6, 3
+    P = O.synth_problem(B, T, F, r, seed=5, ragged=True, density=0.3)
+    P["X"] = np.where(P["X"] == -1.0, -1.0, P["X"] + 0.1).astype(np.float32)
+    N = 2 * r
+    params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=np.float32(2.0 * N), lam1=np.float32(0.05))
+    alt, labels = O.build_alt(N, K, params, ("log_D", "log_alph"))
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    kc, kn = t64(np.log(1e-7 + P["W"][:, :r]).T), t64(np.log(1e-7 + P["W"][:, r:]).T)
+    w = t64((P["X"] != -1.0).any(-1).astype(np.float64))
+    loss, _, hs = TR.model_loss(t64(P["X"]), t64(P["Y"]), w, {k: t64(v) for k, v in alt.items()},
+                                labels, K, t64(P["log_h0"]), kc, kn, divergence=divergence, beta=beta)
+    ref = O.cell_forward_ista_warm(P["X"], O.maps_factored(alt, labels, K), P["log_h0"],
+                                   divergence=divergence, beta=beta)
+    assert np.isfinite(float(loss)) and np.isfinite(ref).all()
+    np.testing.assert_allclose(hs.numpy(), ref, rtol=1e-10, atol=1e-12)
