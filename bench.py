@@ -959,6 +959,9 @@ def main():
         extra["config1_single_utterance"] = safe(config1_bench, torch, dev)
         if not a.no_slab:
             extra["inference_slab_250"] = safe(slab_bench, torch, dev, F, r, K, T)
+            # the same slab for the shipped small model (params_unfolded_snmf_*.yaml: N_fft = 512, r = 100,
+            # K = 5): 16 persistent row-tile chains, two per XCD (csrc/cell_gram_persist.h)
+            extra["inference_slab_250_shipped_r100"] = safe(slab_bench, torch, dev, 257, 100, 5, 500)
             extra["reference_op_graph_dense_kernel"] = safe(dense_graph_bench, torch, dev, F, r, K, B)
         if not a.no_config5:
             extra["config5_shape"] = safe(config5_bench, torch, dev)

@@ -970,7 +970,7 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             a.cp_mask = cp_mask;
             DRNMF_HIP(h, hipMemsetAsync(bar, 0, PERSIST_SYNC_BYTES, stream));   // arrivals, abort, XCC masks
             void* kp[1] = {&a};
-            DRNMF_HIP(h, hipLaunchKernel(pick_persist_fwd(NAC), dim3(8u * (unsigned)numO),
+            DRNMF_HIP(h, hipLaunchKernel(pick_persist_fwd(NAC), dim3(8u * (unsigned)(numO * persist_rounds(numM))),
                                          dim3(64 * (NW_G + 1)), kp,
                                          persist_fwd_lds(K, d->return_all_hidden != 0), stream));
             int32_t rc = compute_block(j + 2);

@@ -7,8 +7,9 @@
 // layer-step from a hipGraph).  Batch rows never interact (custom_layers.py:337-338, 346-348), so
 // every 16-row tile is an INDEPENDENT chain: its numO <= 32 workgroups (one per 16-atom output tile)
 // are dealt to ONE XCD (workgroup ids go round the 8 XCDs: chain m takes the ids = m mod 8 of a grid
-// of 8 x numO), synchronise among themselves only, and exchange their activations through that XCD's
-// L2.  tools/probes/xcd_local_probe.hip (profiles/r03b_xcd_local_probe.txt): barrier 0.5-0.6 us, an
+// of 8 x numO; chains 8 .. 15 -- the reference predicts in slabs of 250 utterances, enhance.py:1189 --
+// take a second round of ids and share the XCDs with the first while both fit its 32 CUs),
+// synchronise among themselves only, and exchange their activations through that XCD's L2.  tools/probes/xcd_local_probe.hip (profiles/r03b_xcd_local_probe.txt): barrier 0.5-0.6 us, an
 // exchange phase 1.33 us with plain producer stores + L1-bypassing loads (1.62 with write-through
 // stores), against 2.4 us with a launch per phase; the same structure over the whole chip does NOT
 // pay (profiles/r03a_chain_probe.txt).
@@ -33,9 +34,9 @@
 namespace {
 
 constexpr int PERSIST_MAX_TILES = 32;           // output tiles per chain (N <= 512)
-constexpr int PERSIST_MAX_CHAINS = 8;           // row tiles (B <= 128): one XCD each
+constexpr int PERSIST_MAX_CHAINS = 16;          // row tiles (B <= 256): one XCD each, a second round sharing them
 constexpr unsigned PERSIST_SPIN_LIMIT = 1u << 21;   // polls (~0.5 us each) before a chain gives up
-constexpr int PERSIST_SYNC_BYTES = 1024;        // 8 chains x 64-byte line {arrivals, abort, XCC mask}, + spare
+constexpr int PERSIST_SYNC_BYTES = 1024;        // 16 chains x 64-byte line {arrivals, abort, XCC mask}
 
 __device__ __forceinline__ float ld1_sc1(const float* p) {
     const unsigned u = __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -151,7 +152,10 @@ struct GramPersistArgs {
 // compile-time count keeps the operand loads and MFMAs one straight line.
 template <int NS>
 __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const GramPersistArgs a) {
-    const int m = blockIdx.x & 7;                           // chain = row tile, dealt to XCD m
+    // chain = row tile m, dealt to XCD m % 8; a second round of chains (m >= 8: the reference's
+    // 250-utterance inference slabs) shares the XCDs with the first
+    const int slot = (int)(blockIdx.x >> 3) / a.numO;
+    const int m = (blockIdx.x & 7) + 8 * slot;
     if (m >= a.numM) return;
     __shared__ __attribute__((aligned(16))) float red[NW_G * 16 * 17];
     __shared__ float part[32][17];
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
     // round trip into the epilogue of every phase of a frame in which any of the 16 rows is masked
     // (ragged batches: measured 2.25 against 1.65 us per phase)
     extern __shared__ float oprev[];
-    const int ot = blockIdx.x >> 3;                         // output tile (grid = 8 * numO)
+    const int ot = (int)(blockIdx.x >> 3) - slot * a.numO;  // output tile (grid = 8 * numO * rounds)
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KL = a.K - 1, nphase = a.nfr * KL;
@@ -406,12 +410,13 @@ struct GramPersistBwdArgs {
 
 template <int NS>
 __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_bwd_kernel(const GramPersistBwdArgs a) {
-    const int m = blockIdx.x & 7;
+    const int slot = (int)(blockIdx.x >> 3) / a.numO;       // (see gram_persist_kernel)
+    const int m = (blockIdx.x & 7) + 8 * slot;
     if (m >= a.numM) return;
     __shared__ __attribute__((aligned(16))) float red[NW_G * 16 * 17];
     __shared__ float sm[16][17];
     __shared__ int ctl[2];
-    const int ot = blockIdx.x >> 3;
+    const int ot = (int)(blockIdx.x >> 3) - slot * a.numO;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.K, nphase = a.T * K;
@@ -606,10 +611,12 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_bwd_kernel(const
 // Whether a Gram-form call may run as persistent chains: tile counts, and every chain's workgroups
 // resident together on one XCD's 32 CUs (checked once per process against the occupancy API with a
 // margin of one workgroup per CU -- the API can answer one too many, MI355X_MICROARCH.md).
+static inline int persist_rounds(int numM) { return (numM + 7) / 8; }
 constexpr int PERSIST_MAX_K = 48;               // [K][256] floats of previous outputs in LDS
 static inline size_t persist_fwd_lds(int K, bool all_hidden) { return (size_t)(all_hidden ? K : 1) * 256 * 4; }
 static inline bool persist_shape_ok(int numM, int numO, int K) {
     if (K < 2 || K > PERSIST_MAX_K || numO > PERSIST_MAX_TILES || numM > PERSIST_MAX_CHAINS) return false;
+    if (persist_rounds(numM) * numO > PERSIST_MAX_TILES) return false;   // an XCD's chains fit its 32 CUs
     if (const char* e = getenv("DRNMF_PERSIST"))
         if (atoi(e) == 0) return false;
     static int per_cu = -1, n_cu = 0;

@@ -469,7 +469,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_h16_1 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_r16 = take(W.half ? (size_t)W.Bp * W.Fp * 2 : 0);
     W.cp_frames = 2 * GRAM_TB;
-    if (W.gram && W.numO <= 32 && W.Bp / ROWS <= 8 && d->T > 2 * GRAM_TB &&
+    if (W.gram && W.numO <= 32 && W.Bp / ROWS <= 16 && d->T > 2 * GRAM_TB &&
         (size_t)d->T * d->K * W.Bp * W.Np * 4 <= ((size_t)1 << 30))
         W.cp_frames = d->T;
     if (const char* e = getenv("DRNMF_CP_FULL"))      // tuning aid: 0 keeps the ring of two blocks

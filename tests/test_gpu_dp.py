@@ -201,6 +201,8 @@ def test_gram_and_factored_forms_agree(dev, monkeypatch):
     dict(B=32, T=130, F=65, r=250, K=3),         # two chains x 32 output tiles, > 2 blocks of frames
     dict(B=128, T=66, F=33, r=24, K=5, ah=True), # eight chains (one per XCD) x 2 tiles, all-hidden
     dict(B=100, T=10, F=21, r=100, K=2),         # seven chains, the last with 4 live rows
+    dict(B=250, T=70, F=33, r=100, K=3),         # the reference's inference slab: 16 chains, two per XCD
+    dict(B=200, T=9, F=21, r=120, K=4, ah=True), # 13 chains x 15 tiles
 ])
 def test_persistent_gram_kernel_is_bit_identical(dev, monkeypatch, cfg):
     """gram_persist_kernel (cell_gram_persist.h): one launch per block of frames, every 16-row tile an
@@ -236,6 +238,7 @@ def test_persistent_gram_kernel_is_bit_identical(dev, monkeypatch, cfg):
     dict(B=32, T=131, F=65, r=100, K=5),          # the shipped r = 100 batch: two chains x 13 tiles
     dict(B=128, T=20, F=33, r=24, K=4),           # eight chains
     dict(B=5, T=9, F=21, r=250, K=3),             # N = 500: 32 tiles per chain
+    dict(B=250, T=12, F=33, r=100, K=3),          # 16 chains, two per XCD
 ])
 def test_persistent_gram_bptt_is_bit_identical(dev, monkeypatch, cfg):
     """gram_persist_bwd_kernel (cell_gram_persist.h): the BPTT's whole sequential pass in one launch of
