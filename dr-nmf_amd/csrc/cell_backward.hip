@@ -1072,7 +1072,7 @@ BwdWs bwd_layout(const drnmf_cell_desc_t* d, const Workspace& W) {
     const int nparts = W.gram ? W.numO : W.numA;
     L.off_z0s = take((size_t)2 * nparts * W.Bp * 4);
     L.off_dps = take((size_t)2 * nparts * W.Bp * 4);
-    L.off_cnt = take(256 + 1024);   // frame counters + the persistent chains' sync lines
+    L.off_cnt = take(256 + 65536);   // frame counters + the persistent chains' sync lines
     L.off_dh0 = take((size_t)(W.Bp / ROWS) * W.Np * 4);
     L.off_dzall = take((size_t)BT * d->K * d->N * 4);
     // d r_k of every layer from the sequential pass; the Gram form recomputes one layer at a time

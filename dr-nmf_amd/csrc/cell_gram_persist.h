@@ -36,7 +36,8 @@ namespace {
 constexpr int PERSIST_MAX_TILES = 32;           // output tiles per chain (N <= 512)
 constexpr int PERSIST_MAX_CHAINS = 16;          // row tiles (B <= 256): one XCD each, a second round sharing them
 constexpr unsigned PERSIST_SPIN_LIMIT = 1u << 21;   // polls (~0.5 us each) before a chain gives up
-constexpr int PERSIST_SYNC_BYTES = 1024;        // 16 chains x 64-byte line {arrivals, abort, XCC mask}
+constexpr int PERSIST_LINE_WORDS = 1024;        // a chain's sync words {arrivals, abort, XCC mask} sit 4 KB apart
+constexpr int PERSIST_SYNC_BYTES = 16 * PERSIST_LINE_WORDS * 4;   // 16 chains
 
 __device__ __forceinline__ float ld1_sc1(const float* p) {
     const unsigned u = __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KL = a.K - 1, nphase = a.nfr * KL;
-    unsigned* line = a.bar + 16 * m;
+    unsigned* line = a.bar + PERSIST_LINE_WORDS * m;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     if (w == NW_G) {
         // ---- the synchronising wave: as many workgroup barriers per phase as the others ------------
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_bwd_kernel(const
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.K, nphase = a.T * K;
-    unsigned* line = a.bar + 16 * m;
+    unsigned* line = a.bar + PERSIST_LINE_WORDS * m;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     if (w == NW_G) {
         persist_census(line);

@@ -489,7 +489,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         (void)take(256);                                      // (an offset of 0 means "absent")
         W.off_xhat = take((size_t)d->T * d->K * W.Bp * W.Fp * 4);
     }
-    W.off_t = take(256 + 1024);     // frame counters (256 B) + the persistent chains' sync lines (cell_gram_persist.h)
+    W.off_t = take(256 + 65536);     // frame counters (256 B) + the persistent chains' sync lines (cell_gram_persist.h)
     W.total = o;
     return W;
 }
