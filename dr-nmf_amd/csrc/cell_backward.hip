@@ -1294,6 +1294,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         pa.host_flag = h->persist_flag;
         pa.u0d = u0_diag; pa.u0o = u0_off; pa.uko = uk_off;
         pa.B = B; pa.T = T; pa.N = N; pa.K = K; pa.Bp = W.Bp; pa.Np = W.Np; pa.numO = W.numO; pa.numM = numM;
+        pa.nwait = persist_nwait(W.numO);
         void* kp[1] = {&pa};
         DRNMF_HIP(h, hipLaunchKernel(pick_persist_bwd(W.Np / 16), dim3(8u * (unsigned)(W.numO * persist_rounds(numM))),
                                      dim3(64 * (NW_G + 1)), kp, 0, stream));

@@ -968,6 +968,7 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             a.all_hidden = d->return_all_hidden ? 1 : 0;
             a.t0 = t0; a.nfr = t1 - t0;
             a.cp_mask = cp_mask;
+            a.nwait = persist_nwait(numO);
             DRNMF_HIP(h, hipMemsetAsync(bar, 0, PERSIST_SYNC_BYTES, stream));   // arrivals, abort, XCC masks
             void* kp[1] = {&a};
             DRNMF_HIP(h, hipLaunchKernel(pick_persist_fwd(NAC), dim3(8u * (unsigned)(numO * persist_rounds(numM))),

@@ -146,6 +146,8 @@ struct GramPersistArgs {
     int B, T, N, K, Bp, Np, numO, numM, out_width, all_hidden;
     int t0, nfr;
     int cp_mask;             // as GramFwdArgs
+    int nwait;               // arrivals a barrier waits for: numO (numO + 1 under DRNMF_PERSIST_FAULT=1, the
+                             // fault injection of tests/test_gpu_dp.py: the chains then time out)
 };
 
 // NS = chunk slots any wave owns = ceil(Np / 16 / 8) (workgroup-uniform, 1..4): the slots beyond would
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_kernel(const Gra
             if (k == 1) { wg_sync(); wg_sync(); }           // row-sum reduction of a frame's first phase
             wg_sync();                                      // cross-wave reduction
             wg_sync();                                      // (1) the phase's stores are acknowledged
-            persist_arrive_and_wait(line, (unsigned)(p + 1) * (unsigned)a.numO, ctl, a.host_flag, p == 0);
+            persist_arrive_and_wait(line, (unsigned)(p + 1) * (unsigned)a.nwait, ctl, a.host_flag, p == 0);
             wg_sync();                                      // (2) release
             if (ctl[0]) return;
             k = (k == a.K - 1) ? 1 : k + 1;
@@ -407,6 +409,7 @@ struct GramPersistBwdArgs {
     unsigned* host_flag;
     float u0d, u0o, uko;
     int B, T, N, K, Bp, Np, numO, numM;
+    int nwait;               // as GramPersistArgs
 };
 
 template <int NS>
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_bwd_kernel(const
         for (int p = 0; p < nphase; ++p) {
             if (k != K) wg_sync();                          // cross-wave reduction of a contraction phase
             wg_sync();                                      // (1)
-            persist_arrive_and_wait(line, (unsigned)(p + 1) * (unsigned)a.numO, ctl, a.host_flag, p == 0);
+            persist_arrive_and_wait(line, (unsigned)(p + 1) * (unsigned)a.nwait, ctl, a.host_flag, p == 0);
             wg_sync();                                      // (2)
             if (ctl[0]) return;
             k = (k == 1) ? K : k - 1;
@@ -613,6 +616,11 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_bwd_kernel(const
 // resident together on one XCD's 32 CUs (checked once per process against the occupancy API with a
 // margin of one workgroup per CU -- the API can answer one too many, MI355X_MICROARCH.md).
 static inline int persist_rounds(int numM) { return (numM + 7) / 8; }
+// test aid: DRNMF_PERSIST_FAULT=1 makes every barrier wait for one arrival that never comes
+static inline int persist_nwait(int numO) {
+    const char* e = getenv("DRNMF_PERSIST_FAULT");
+    return numO + ((e && atoi(e) == 1) ? 1 : 0);
+}
 constexpr int PERSIST_MAX_K = 48;               // [K][256] floats of previous outputs in LDS
 static inline size_t persist_fwd_lds(int K, bool all_hidden) { return (size_t)(all_hidden ? K : 1) * 256 * 4; }
 static inline bool persist_shape_ok(int numM, int numO, int K) {

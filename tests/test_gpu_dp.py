@@ -385,3 +385,31 @@ def test_persistent_chains_next_to_a_busy_stream(dev, monkeypatch):
         assert np.array_equal(o.cpu().numpy(), ref)
     again = TP._run_cell(dev, P, alt, labels, N, K)[0]      # no DRNMF_ERR_TIMEOUT pending
     assert np.array_equal(again, ref)
+
+
+def test_persistent_timeout_is_reported_not_swallowed(dev, monkeypatch):
+    """a persistent launch whose barrier can never complete (fault injection: every barrier
+    waits for one arrival too many) must give up after its bounded spin, and the NEXT cell call on the
+    handle must fail with DRNMF_ERR_TIMEOUT instead of a wrong result going out silently; the call after
+    that works again."""
+    import os
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as TP
+    from drnmf_amd import _capi
+    monkeypatch.setenv("DRNMF_GRAM", "1")
+    monkeypatch.setenv("DRNMF_PERSIST", "1")
+    B, T, F, r, K = 3, 4, 21, 6, 2
+    P, alt, labels, N = TP._problem(B, T, F, r, K, untied=("log_D", "log_alph"), seed=9)
+    good = TP._run_cell(dev, P, alt, labels, N, K)[0].copy()
+    monkeypatch.setenv("DRNMF_PERSIST_FAULT", "1")
+    t0 = time.time()
+    TP._run_cell(dev, P, alt, labels, N, K)               # enqueues; the kernel times out on the device
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 60.0                         # bounded, not a hang
+    monkeypatch.delenv("DRNMF_PERSIST_FAULT")
+    with pytest.raises(_capi.DrnmfError, match="timed out"):
+        TP._run_cell(dev, P, alt, labels, N, K)
+    again = TP._run_cell(dev, P, alt, labels, N, K)[0]     # the flag is reported once
+    assert np.array_equal(again, good)
