@@ -51,6 +51,11 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o p -- python3 "$B" $SMALL \
     > /dev/null 2> "$OUT/pmc_sq.err"
 python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_summary.json" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq"
+# 6. the persistent chains of the shipped r = 100 training step: wave-cycle split and matrix-pipe time
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_r100" -o p -- python3 "$ROOT/tools/train_profile.py" 32 500 257 100 5 3 \
+    > /dev/null 2> "$OUT/pmc_r100.err"
+python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_r100_summary.json" "$OUT/pmc_r100"
 # keep the merge-back small: the raw per-dispatch CSVs are large
 find "$OUT" -name '*counter_collection.csv' -size +8M -delete
 find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
