@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
             dz[e] = h2[e] > 0.f ? dh : 0.f;
         }
         if (pair) {
-            *(f32x2*)(a.dz_all + ro * KN + (size_t)(a.K - 1) * a.N + n) = dz;
+            st_save(a.dz_all + ro * KN + (size_t)(a.K - 1) * a.N + n, dz);
         } else if (lrow) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -194,7 +194,7 @@ struct BwdAArgs {
     float* dGp_out;          // packed dG_{k-1}
     const float* hall;
     float* dz_all;
-    float* dR;               // [B*T][Fp] row-major d r_k of this layer
+    float* dR;               // [B*T][Fp] row-major d r_k of this layer (MFMA bin tiles in tile_unpermute order)
     float* dz0s_part;
     float* dps_part;
     const int* c_rd;
@@ -317,7 +317,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     // workgroup of the row tile holds all of it; chunk c is stored by atom block c mod numA so
     // that no single workgroup carries the whole copy (it used to be block 0: the launch then
     // waited for that one straggler).
-    float* const dr_row = a.dR + ((size_t)(row0 + j) * a.T + t) * Fp + q;
+    float* const dr_row = a.dR + ((size_t)(row0 + j) * a.T + t) * Fp + 4 * q;   // (tile_unpermute order)
     const bool dr_lane = row0 + j < a.B;
     auto compute_chunk = [&](int base, int g) {
         f32x4 r4 = av[g][0];
@@ -362,10 +362,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
         f32x4 r4 = drv[0];
 #pragma unroll
         for (int ks = 1; ks < KS; ++ks) r4 += drv[ks];
-        if (dr_lane) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) dr_row[16 * ab + 4 * s] = r4[s];
-        }
+        if (dr_lane) st_save(dr_row + 16 * ab, r4);
     }
 #endif
     if (live) {
@@ -374,10 +371,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
             f32x4 r4 = *(const f32x4*)(arow + 256 * c);
 #pragma unroll
             for (int ks = 1; ks < KS; ++ks) r4 += *(const f32x4*)(arow + 256 * c + (size_t)ks * pstride);
-            if (dr_lane) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) dr_row[16 * c + 4 * s] = r4[s];
-            }
+            if (dr_lane) st_save(dr_row + 16 * c, r4);
         }
     }
 
@@ -424,14 +418,14 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
 #ifndef DRNMF_EXP_NODZ
     if (!K0 && rg < a.B) {     // one 8-byte store where the pair is whole and aligned (n is even)
         float* dzo = a.dz_all + ((size_t)rg * a.T + t) * KN + (size_t)(a.k - 1) * a.N + n;
-        if (n + 1 < a.N && (a.N & 1) == 0) *(f32x2*)dzo = dzn;
+        if (n + 1 < a.N && (a.N & 1) == 0) st_save(dzo, dzn);
         else {
             if (n < a.N) dzo[0] = dzn[0];
             if (n + 1 < a.N) dzo[1] = dzn[1];
         }
     }
 #endif
-    *(f32x2*)(a.dzp_out + hoff) = dzn;
+    st_xchg(a.dzp_out + hoff, dzn);
     f32x2 dG = {dzn[0] * ia[0], dzn[1] * ia[1]};
     if (a.dGp_out) *(f32x2*)(a.dGp_out + hoff) = dG;       // (nullptr: cell_b reads dz, scale_pack_kernel)
     if (a.k >= 2) {
@@ -516,13 +510,17 @@ struct EpiStore {   // C = acc
         C[row * ldc + col] = acc;
     }
 };
+// (perm_rows: the A operand's columns below it are in the chain kernels' saved order, common.h
+// tile_unpermute -- output row m of the product is bin tile_unpermute(m))
 struct EpiP1 {      // partial[split] = acc * ia[n]
     float* P;
     const float* ia;
     int Np;
     size_t stride;
+    int perm_rows;
     __device__ float pre(int, int, int n) const { return ia[n]; }
     __device__ void operator()(int split, int m, int n, float acc, float pv) const {
+        if (m < perm_rows) m = tile_unpermute(m);
         P[split * stride + (size_t)m * Np + n] = acc * pv;
     }
 };
@@ -530,10 +528,13 @@ struct EpiP2 {      // partial[split] -= acc
     float* P;
     int Np;
     size_t stride;
+    int perm_rows;
     __device__ float pre(int split, int m, int n) const {
+        if (m < perm_rows) m = tile_unpermute(m);
         return P[split * stride + (size_t)m * Np + n];
     }
     __device__ void operator()(int split, int m, int n, float acc, float pv) const {
+        if (m < perm_rows) m = tile_unpermute(m);
         P[split * stride + (size_t)m * Np + n] = pv - acc;
     }
 };
@@ -1414,6 +1415,8 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         hipLaunchKernelGGL(unpack_dn_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                            stream, Dp_of(k), Dn_rm, W.Fp, W.Np);
         const float* Aop = xpad;
+        const int perm_all = 16 * nft;       // the chain kernels' saved copies: every MFMA bin tile
+        int perm1 = 0;
         if (nonlin) {
             // R_k = g(X, X^_k) of EVERY layer, layer 0 included, from the x^ the forward kept
             const size_t tot2 = (size_t)BT * W.Fp;
@@ -1424,6 +1427,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         } else if (k >= 1 && W.off_rsave != 0) {
             // the forward left r_k of every frame in its workspace (cell_a_kernel, Rsave)
             Aop = (const float*)(fw + W.off_rsave) + (size_t)(k - 1) * BT * W.Fp;
+            perm1 = perm_all;
         } else if (k >= 1) {
             gemm::Operands g1{hall + (size_t)(k - 1) * N, Dn_rm, BT, F, N, KN, W.Np};
             DRNMF_HIP(h, gemm::launch(g1, EpiResid{x, Rk, F, W.Fp}, stream));
@@ -1436,7 +1440,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         gemm_tn::Operands t1{Aop, dz_all + (size_t)k * N, BT, Mg, N, W.Fp, KN};
         const int nsplit = tn_splits(Mg, N, BT);
         const float* dRk_tail = nullptr;
-        DRNMF_HIP(h, gemm_tn::launch(t1, EpiP1{P, ia_of(k), W.Np, pstr}, nsplit, stream));
+        DRNMF_HIP(h, gemm_tn::launch(t1, EpiP1{P, ia_of(k), W.Np, pstr, perm1}, nsplit, stream));
         if (k >= 1) {
             const float* dRk = dR_all + (size_t)k * BT * W.Fp;
             if (W.gram) {
@@ -1450,7 +1454,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                 dRk = dR_all;
             }
             gemm_tn::Operands t2{dRk, hall + (size_t)(k - 1) * N, BT, Mg, N, W.Fp, KN};
-            DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, nsplit, stream));
+            DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr, W.gram ? 0 : perm_all}, nsplit, stream));
             dRk_tail = dRk + (F - 1);
         } else if (nonlin) {
             // layer 0 of the KL / beta cell contracts the STATE p_t: - d x^_0^T P, P row-major [B*T][N]
@@ -1459,7 +1463,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
             hipLaunchKernelGGL(state_matrix_kernel, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0,
                                stream, hall, seen, log_h0, Pst, B, T, N, K, W.Bp);
             gemm_tn::Operands t2{dR_all, Pst, BT, Mg, N, W.Fp, N};
-            DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr}, nsplit, stream));
+            DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr, perm_all}, nsplit, stream));
         }
         ColRedArgs ca;
         ca.rt = odd ? Aop + (F - 1) : nullptr;

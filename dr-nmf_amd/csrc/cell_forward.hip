@@ -74,8 +74,9 @@ struct CellAArgs {
     int ablate;              // measurement aid (DRNMF_ABLATE_A): bit 0 = dictionary loads read chunk 0,
                              // bit 1 = residual loads read chunk 0 (fp16 mode; results are garbage)
     float* Rsave;            // training (all-hidden, fp32, k >= 1): this layer's residual r_k of every
-                             // frame, row-major [B*T][Fp], for the weight gradients of the BPTT
-                             // (saves its recomputation as a frame-parallel GEMM); else NULL
+                             // frame, row-major [B*T][Fp] with the columns of every MFMA bin tile in
+                             // the saved order (common.h tile_unpermute), for the weight gradients of
+                             // the BPTT (saves its recomputation as a frame-parallel GEMM); else NULL
     int out_width, out_off, write_out;
 };
 
@@ -440,9 +441,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             for (int ks = 1; ks < KS; ++ks) r4 += rsv[rb][ks];
             const int row = (mb0 + rb) * ROWS + j;
             if (row < a.B) {
-                float* dst = a.Rsave + ((size_t)row * a.T + t) * Fp + 16 * ab + q;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) dst[4 * s] = r4[s];
+                st_save(a.Rsave + ((size_t)row * a.T + t) * Fp + 16 * ab + 4 * q, r4);   // (tile_unpermute order)
             }
         }
     }
@@ -519,7 +518,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             // valid step)
             float* orow = a.out + ((size_t)rg * a.T + t) * a.out_width + a.out_off;
             if (vld[rb] && n + 1 < a.N && ((a.N | a.out_width | a.out_off) & 1) == 0) {
-                *(f32x2*)(orow + n) = hn;       // one 8-byte store (n is even): the usual case
+                st_save(orow + n, hn);          // one 8-byte store (n is even): the usual case
             } else {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -542,7 +541,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             if ((tid & 15) == 0)
                 a.rs_part[((size_t)((t + 1) & 1) * a.numA + ab) * a.Bp + rg] = s;
         } else {
-            *(f32x2*)(a.h_out + hoff) = hn;
+            st_xchg(a.h_out + hoff, hn);
             if (HALF)   // Hp16 block (mb, ab): slot q = ec/8, e = ec%8 (cell_shared.h)
                 *(f16x2*)(a.h16_out + ((size_t)(mb0 + rb) * (Np / 32) + ab) * 512 +
                           ((ec >> 3) * 16 + erow) * 8 + (ec & 7)) = f16x2{(f16)hn[0], (f16)hn[1]};
@@ -569,9 +568,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 for (int ks = 1; ks < KS; ++ks) r4 += *(const f32x4*)(src + (size_t)ks * pstride);
                 const int row = (mb0 + rb) * ROWS + j;
                 if (row < a.B) {
-                    float* dst = a.Rsave + ((size_t)row * a.T + t) * Fp + 16 * c + q;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) dst[4 * s] = r4[s];
+                    st_save(a.Rsave + ((size_t)row * a.T + t) * Fp + 16 * c + 4 * q, r4);
                 }
             }
         }

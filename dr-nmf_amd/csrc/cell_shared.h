@@ -299,7 +299,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
                        ((ecol & 3) * 16 + erow) * 8 + (ft & 1) * 4 + (ecol >> 2);
             *r16 = (f16)((a.xp != nullptr) ? xv[rb] - s : s);
         } else {
-            a.rpart[(size_t)ks * a.Bp * Fp + eoff + rb * estep] = (a.xp != nullptr) ? xv[rb] - s : s;
+            st_xchg(a.rpart + (size_t)ks * a.Bp * Fp + eoff + rb * estep, (a.xp != nullptr) ? xv[rb] - s : s);
         }
     }
     DRNMF_STAMP(0, 5);
@@ -383,7 +383,8 @@ struct Workspace {
                            // or, for the shapes the persistent chains serve, all T (one product up
                            // front, one launch for the whole sequence)
     size_t off_rsave;      // training forward (all hidden layers, fp32, factored): residuals r_k, k >= 1,
-                           // row-major [K-1][B*T][Fp] for the BPTT's weight gradients; 0 = absent
+                           // row-major [K-1][B*T][Fp] (MFMA bin tiles in tile_unpermute order) for the
+                           // BPTT's weight gradients; 0 = absent
     size_t off_xhat;       // KL / beta cell, training forward: x^_k = h_in Dn_k^T of every (frame, layer),
                            // tile-packed [T][K][Bp][Fp] (the BPTT needs dg/dx^ there); 0 = absent
 };

@@ -13,6 +13,72 @@
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
+// Stores of the training chain's SAVED copies (all-hidden output, residual copy, dz / d r copies): read
+// by the time-batched phase only, never by the next launch -- nontemporal (streamed through the L2
+// instead of sitting there dirty until the end-of-kernel write-back).  Same-box A/B at the headline
+// shape (tools/ab_builds.sh, profiles/r03e_ab_stores.txt): ordinary stores 1041-1045 ms per step,
+// nontemporal 1018-1022, write-through (sc0 sc1) 1060-1063.  -DDRNMF_EXP_STSAVE=0|2: the other two.
+#ifndef DRNMF_EXP_STSAVE
+#define DRNMF_EXP_STSAVE 1
+#endif
+__device__ __forceinline__ void st_save(float* p, float v) {
+#if DRNMF_EXP_STSAVE == 1
+    __builtin_nontemporal_store(v, p);
+#elif DRNMF_EXP_STSAVE == 2
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_save(float* p, f32x2 v) {
+#if DRNMF_EXP_STSAVE == 1
+    __builtin_nontemporal_store(v, (f32x2*)p);
+#elif DRNMF_EXP_STSAVE == 2
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *(f32x2*)p = v;
+#endif
+}
+__device__ __forceinline__ void st_save(float* p, f32x4 v) {
+#if DRNMF_EXP_STSAVE == 1
+    __builtin_nontemporal_store(v, (f32x4*)p);
+#elif DRNMF_EXP_STSAVE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *(f32x4*)p = v;
+#endif
+}
+// Column order of the saved residual / d r copies inside every 16-bin MFMA tile: position 4q + s holds
+// bin 4s + q -- a lane of the chain kernels owns the bins {q, q+4, q+8, q+12} of its row (Rp packing),
+// which are then ONE 16-byte store.  An involution; the weight-gradient GEMMs undo it on their output
+// row index (tile_unpermute).
+__host__ __device__ __forceinline__ int tile_unpermute(int m) {
+    return (m & ~15) | ((m & 3) << 2) | ((m >> 2) & 3);
+}
+// Exchange stores (read by the NEXT launch): nontemporal too (1013-1017 ms with, 1018-1022 without;
+// the inference forward does not change).  -DDRNMF_EXP_STX=0: ordinary, 1: write-through.
+#ifndef DRNMF_EXP_STX
+#define DRNMF_EXP_STX 2
+#endif
+__device__ __forceinline__ void st_xchg(float* p, float v) {
+#if DRNMF_EXP_STX == 1
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif DRNMF_EXP_STX == 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_xchg(float* p, f32x2 v) {
+#if DRNMF_EXP_STX == 1
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif DRNMF_EXP_STX == 2
+    __builtin_nontemporal_store(v, (f32x2*)p);
+#else
+    *(f32x2*)p = v;
+#endif
+}
+
 // v_mfma_f32_16x16x4_f32: D[i][j] += sum_{k<4} A[i][k] B[k][j]
 //   lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
 //   result register v of lane l is D[i = 4*(l>>4) + v][j = l&15].
