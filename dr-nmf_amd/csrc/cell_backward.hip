@@ -82,9 +82,16 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
     f32x2 g = {0.f, 0.f}, dout2 = {0.f, 0.f}, h2 = {0.f, 0.f};
     unsigned char vt = 0;
     const size_t ro = top ? ((size_t)rg * a.T + t) : 0;
+    f32x2 ia = {0.f, 0.f}, dtl[MAX_TAIL];
+#pragma unroll
+    for (int i = 0; i < MAX_TAIL; ++i) dtl[i] = f32x2{0.f, 0.f};
     if (top) {
         vt = a.valid[(size_t)t * a.Bp + rg];
         g = *(const f32x2*)(a.gq + hoff);
+        ia = *(const f32x2*)(a.ia_last + n);
+#pragma unroll
+        for (int i = 0; i < MAX_TAIL; ++i)
+            if (i < a.ntail) dtl[i] = *(const f32x2*)(a.Dtail_top + (size_t)i * a.Np + n);
         if (pair) {
             dout2 = *(const f32x2*)(a.d_out + ro * a.N + n);
             h2 = *(const f32x2*)(a.hall + ro * KN + (size_t)(a.K - 1) * a.N + n);
@@ -152,13 +159,12 @@ __global__ void __launch_bounds__(256) bwd_edge_kernel(const EdgeArgs a) {
         *(f32x2*)(a.gq + hoff) = g;
         *(f32x2*)(a.dstate + hoff) = ds;
         *(f32x2*)(a.dzp_top + hoff) = dz;
-        const f32x2 ia = *(const f32x2*)(a.ia_last + n);
         f32x2 dG = {dz[0] * ia[0], dz[1] * ia[1]};
         if (a.dGp_top) *(f32x2*)(a.dGp_top + hoff) = dG;   // (Gram chain only, see scale_pack_kernel)
 #pragma unroll
         for (int i = 0; i < MAX_TAIL; ++i) {
             if (i >= a.ntail) continue;
-            const f32x2 dt = *(const f32x2*)(a.Dtail_top + (size_t)i * a.Np + n);
+            const f32x2 dt = dtl[i];
             const float sq = row16_sum(dG[0] * dt[0] + dG[1] * dt[1]);
             if ((tid & 15) == 0) a.dq_out[((size_t)i * a.Bp + rg) * a.numA + ab] = sq;
         }
@@ -282,6 +288,12 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     const int KN = a.K * a.N;
     const f32x2 dzk = *(const f32x2*)(a.dzp_in + hoff);
     const f32x2 ia = *(const f32x2*)(a.ia_prev + n);
+    // this row's running sum(dz_k) term (read-modify-write once per launch): its load goes out here,
+    // with everything else -- at its point of use it was a dependent round trip, behind a wait for every
+    // store of the epilogue, on the tail of each launch
+    const size_t po = (size_t)(cnt & 1) * a.numA * a.Bp + (size_t)ab * a.Bp + rg;
+    float dps_old = 0.f;
+    if ((tid & 15) == 0) dps_old = a.dps_part[po];
     f32x2 hprev = {0.f, 0.f};
     if (K0) hprev = f32x2{1.f, 1.f};
     else {
@@ -352,6 +364,13 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
         }
     }
 
+    // Every load of this kernel was requested ahead of the last operand chunk and loads return in
+    // order: all of them are here.  Said explicitly, because the compiler otherwise waits for the
+    // early epilogue operands (tail rows, partials) where it first uses them -- behind the epilogue's
+    // conditional stores, with a count that is safe for the path issuing the FEWEST stores, i.e. on
+    // the common path it sat out nearly every store's acknowledgement (s_waitcnt vmcnt(1) before the
+    // last tail partial).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
     // the d r copy, outside the MFMA loop (a wave-uniform branch inside it costs several %): the
     // chunks c = ab (mod numA) are stored by the wave that owns them.  The first one was requested
     // before the operand stream (its data is there by now: loads return in order) -- re-read here
@@ -440,8 +459,7 @@ bwd_a_kernel(const float* drpart_, const float* Dn_, const int* c_rd_, int Bp_, 
     s = row16_sum(s);
     s0 = row16_sum(s0);
     if ((tid & 15) == 0) {
-        const size_t po = (size_t)(cnt & 1) * a.numA * a.Bp + (size_t)ab * a.Bp + rg;
-        a.dps_part[po] += a.uko * s;
+        a.dps_part[po] = dps_old + a.uko * s;
         if (a.k == 1) a.dz0s_part[po] = s0;
     }
 }

@@ -340,10 +340,12 @@ __global__ void __launch_bounds__(64 * NW_G) gram_bwd_kernel(const GramBwdArgs a
     const size_t hoff = ((size_t)m * NAC + ot) * 256 + hp_pos(erow, ecol);
     const int KN = a.K * a.N;
     const bool in = rg < a.B && n < a.N;
-    float dzk = 0.f, iap = 0.f, hprev = 0.f;
+    float dzk = 0.f, iap = 0.f, hprev = 0.f, dps_old = 0.f;
+    const size_t po = ((size_t)(cnt & 1) * a.numO + ot) * a.Bp + rg;
     if (ethr) {
         dzk = a.dzp_in[hoff];
         iap = a.ia_prev[n];
+        if (ecol == 0) dps_old = a.dps_part[po];   // (read-modify-write: the read goes out with the rest)
     }
     auto mid = [&]() {
         const int t_ = a.T - 1 - cnt;
@@ -358,8 +360,7 @@ __global__ void __launch_bounds__(64 * NW_G) gram_bwd_kernel(const GramBwdArgs a
     a.dGp_out[hoff] = dzn * iap;
     const float sk = row16_sum(dzk), s0 = row16_sum(dzn);
     if (ecol == 0) {
-        const size_t po = ((size_t)(cnt & 1) * a.numO + ot) * a.Bp + rg;
-        a.dps_part[po] = fmaf(a.uko, sk, a.dps_part[po]);
+        a.dps_part[po] = fmaf(a.uko, sk, dps_old);
         if (a.k == 1) a.dz0s_part[po] = s0;
     }
 }
