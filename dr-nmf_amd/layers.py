@@ -13,7 +13,7 @@ every other configuration of the layer.  Training likewise: the fused BPTT for t
 trainable set (log_D, log_alph, log_lam1, log_h0), the dense-matrix BPTT (csrc/cell_dense_bwd.hip)
 for everything else the reference can train -- log_U1 / log_Uk, caller maps, free weights, other
 activations -- with torch autograd carrying the matrix gradients through the caller's maps.  There
-is no CPU/oracle fallback: what the kernels do not cover (dropout / regularizers in training)
+is no CPU/oracle fallback: what the kernels do not cover (dropout_U in training)
 raises NotImplementedError.  The KL / beta extension of the cell trains through its own BPTT
 (drnmf_cell_backward_ista).
 """
@@ -271,7 +271,8 @@ class SimpleDeepRNN(_Layer):
         super(SimpleDeepRNN, self).__init__(**kwargs)
         # extension (not in the reference): 'kl' / 'beta' run the reference's
         # ista_kl / ista_beta iteration (enhance.py:421-456) recurrently instead of the Euclidean
-        # cell -- K full ISTA steps per frame warm-started from the previous frame; inference only
+        # cell -- K full ISTA steps per frame warm-started from the previous frame; trains through
+        # its own BPTT (drnmf_cell_backward_ista)
         if divergence not in ops.DIVERGENCES:
             raise ValueError("divergence must be 'ed', 'kl' or 'beta'")
         self.divergence, self.beta = divergence, float(beta)
@@ -319,14 +320,19 @@ class SimpleDeepRNN(_Layer):
         if self._generic and operand_dtype != 'float32':
             raise NotImplementedError("operand_dtype='float16' exists for the fused build_alt "
                                       "configuration only")
-        # dropout is the identity outside the training phase (K.in_train_phase,
-        # custom_layers.py:377-395) and regularizers only add to the training loss: inference is
-        # unaffected, training with them is not implemented
+        # Dropout is the identity outside the training phase (K.in_train_phase,
+        # custom_layers.py:377-395).  In training the reference applies ONLY dropout_U: the layer sets
+        # consume_less = 'gpu' (custom_layers.py:169), so get_constants never builds the dropout_W
+        # mask (custom_layers.py:386: B_W = 1) -- dropout_W is accepted and has no effect, as there.
+        # dropout_U (a per-sequence mask on prev_output in every U_k term) is not implemented.
+        # Regularizers belong to the FREE matrices only (custom_layers.py:245-269: add_weight(...,
+        # regularizer=...) is reached where maps_from_alt has no map for W / U / b; S has none): with
+        # build_alt's maps -- everything enhance.py constructs -- there is nothing for them to act
+        # on; on free weights the model adds their penalty and its gradient (UnfoldedSNMFModel.
+        # _add_regularizers).
         self._train_blockers = []
-        if dropout_W or dropout_U:
-            self._train_blockers.append('dropout')
-        if W_regularizer or U_regularizer or b_regularizer:
-            self._train_blockers.append('regularizers')
+        if dropout_U:
+            self._train_blockers.append('dropout_U')
 
     # -- Keras protocol --------------------------------------------------------------------
     def compute_output_shape(self, input_shape):                          # custom_layers.py:175-185
@@ -991,6 +997,47 @@ class UnfoldedSNMFModel(object):
         self._flat[-ns:-ns + 2].copy_(sums)
         self._flat[-1] = float(x.shape[0] * x.shape[1]) if live else 0.0
 
+    @staticmethod
+    def _reg_coeffs(reg):
+        """(l1, l2) of a Keras-style regularizer: an object with .l1 / .l2 (keras.regularizers.L1L2),
+        a dict {'l1':, 'l2':} (its get_config) or a pair."""
+        if reg is None:
+            return 0.0, 0.0
+        if isinstance(reg, dict):
+            return float(reg.get('l1', 0.0)), float(reg.get('l2', 0.0))
+        if isinstance(reg, (tuple, list)):
+            return float(reg[0]), float(reg[1])
+        return float(getattr(reg, 'l1', 0.0)), float(getattr(reg, 'l2', 0.0))
+
+    def _regularized_items(self):
+        """[(weight name, tensor, l1, l2)]: the cell's free W_k / U_k / b_k matrices under its
+        W_ / U_ / b_regularizer (custom_layers.py:245-269); empty for build_alt's configuration."""
+        cell, out = self.cell, []
+        regs = {'W_': cell.W_regularizer, 'U_': cell.U_regularizer, 'b_': cell.b_regularizer}
+        for n, p in self._train_items:
+            for prefix, reg in regs.items():
+                l1, l2 = self._reg_coeffs(reg)
+                if n.startswith(prefix) and n in getattr(cell, '_free', {}) and (l1 or l2):
+                    out.append((n, p, l1, l2))
+        return out
+
+    def _regularization_loss(self):
+        tot = 0.0
+        for _, p, l1, l2 in self._regularized_items():
+            tot += l1 * float(p.abs().sum()) + l2 * float((p * p).sum())
+        return tot
+
+    def _add_regularizers(self, scale):
+        """Adds d/dw [l1 |w| + l2 w^2] of every regularized weight to the flat gradient -- divided
+        by `scale`, the factor the optimiser step applies to the DATA gradient sums (the penalty is
+        not a sum over frames; it enters once, after the all-reduce) -- and returns the penalty
+        (Keras: total_loss = loss + sum of layer.losses)."""
+        tot = 0.0
+        for n, p, l1, l2 in self._regularized_items():
+            self._gview[n].add_((l1 * torch.sign(p) + (2.0 * l2) * p) / scale)
+            tot += l1 * float(p.abs().sum()) + l2 * float((p * p).sum())
+        return tot
+
     def apply_gradients(self, flat):
         """Adam step from the (already all-reduced) flat buffer; returns the normalised loss."""
         o = self.opt
@@ -1001,6 +1048,7 @@ class UnfoldedSNMFModel(object):
             # weighted_masked_objective with a propagated mask: one more division by
             # p = mean(mask) = count / frames (global numbers under data parallelism)
             scale *= rows / max(cnt, 1.0)
+        reg_loss = self._add_regularizers(scale)     # (before the clip: Keras clips the total gradient)
         if o['clipnorm'] > 0:                       # global-norm clip [K2.0.4-memory]
             norm = float(np.sqrt(ops.sumsq(flat[:-ns]))) * scale
             if norm > o['clipnorm']:
@@ -1024,7 +1072,7 @@ class UnfoldedSNMFModel(object):
             # round trip to re-examine U's structure after every step)
             self.cell._dense_now = True
             self.cell._dense_block_valid = False
-        return sse * scale
+        return sse * scale + reg_loss
 
     def train_on_batch(self, x, y, sample_weight=None, _live=True):
         """One optimiser step.  x, y: (B,T,F); sample_weight: (B,T) (the data mask,
@@ -1057,7 +1105,7 @@ class UnfoldedSNMFModel(object):
         scale = 1.0 / max(cnt, 1.0)
         if getattr(self, 'loss_norm', 'masked_mean') == 'keras204':
             scale *= rows / max(cnt, 1.0)
-        return sse * scale
+        return sse * scale + (self._regularization_loss() if hasattr(self, '_train_items') else 0.0)
 
     def fit(self, x, y, sample_weight=None, batch_size=32, epochs=1, validation_data=None,
             shuffle=True, seed=7654, verbose=0, callbacks=None, resident_bytes=64 << 30):

@@ -426,3 +426,78 @@ def test_generic_layer_trains_free_weights(dev):
         ref = L[n].grad.numpy()
         err = np.max(np.abs(gv.cpu().numpy() - ref)) / max(np.max(np.abs(ref)), 1e-30)
         assert err <= G_TOL, "%s: max|dg|/max|g| = %.3e" % (n, err)
+
+
+def test_model_regularizers_on_free_weights_and_dropout_w_is_inert(dev):
+    """W_/U_/b_regularizer act on the cell's FREE matrices only (custom_layers.py:245-269) -- penalty
+    added to the loss, its gradient to the (already normalised) data gradient -- and dropout_W never
+    takes effect in the reference (consume_less = 'gpu', custom_layers.py:169, 386): a model with a
+    free U under l1 + l2 and dropout_W = 0.3 gives the data gradients of the same model without them,
+    plus exactly the penalty terms; build_alt's configuration has nothing to regularize."""
+    from drnmf_amd import layers
+    B, T, F, r, K = 3, 5, 12, 4, 2
+    N = 2 * r
+    rng = np.random.default_rng(21)
+    A = (0.2 * rng.random((F, N))).astype(np.float32)
+    c = (-0.05 * rng.random((N,))).astype(np.float32)
+    maps = {"W": lambda a: a["A"], "b": lambda a: a["c"]}
+    Wn = rng.random((F, N)).astype(np.float32)
+    X = _ragged_x(rng, B, T, F)
+    Y = (0.5 * np.abs(X)).astype(np.float32)
+    valid = np.any(X != -1.0, axis=-1).astype(np.float32)
+
+    def make(reg, drop):
+        np.random.seed(3)
+        cell = layers.SimpleDeepRNN(N, activation="relu", K_layers=K, alt_params={"A": A.copy(), "c": c.copy()},
+                                    keys_trainable=["A"], maps_from_alt=maps, U_regularizer=reg,
+                                    b_regularizer=reg, dropout_W=drop,
+                                    flag_connect_input_to_layers=True, flag_nonnegative=True,
+                                    return_sequences=True, input_shape=(T, F), device=dev)
+        cell.build((None, T, F))
+        clean = layers.DenseNonNegW(F, use_bias=False, weights=[np.log(1e-7 + Wn[:, :r]).T], device=dev)
+        noise = layers.DenseNonNegW(F, use_bias=False, weights=[np.log(1e-7 + Wn[:, r:]).T], device=dev)
+        lay = [layers.InputLayer((T, F)), layers.Masking(mask_value=-1., input_shape=(T, F)), cell,
+               layers.TimeDistributed(clean, name='clean_est'), layers.TimeDistributed(noise, name='noise_est'),
+               layers.DivideAbyAplusB()]
+        m = layers.UnfoldedSNMFModel(lay, cell, clean, noise, -1., False)
+        return m.compile(lr=1e-3, clipnorm=0.0)
+
+    t = lambda a: torch.from_numpy(a).to(dev)
+    plain = make(None, 0.0)
+    reg = make({"l1": 0.01, "l2": 0.1}, 0.3)
+    reg.set_weights(plain.get_weights())
+    items = reg._regularized_items()
+    assert sorted(n for n, _, _, _ in items) == ["U_0", "U_1"]      # b is mapped, S carries no regularizer
+    g0 = plain.loss_and_grads(t(X), t(Y), t(valid)).clone()
+    g1 = reg.loss_and_grads(t(X), t(Y), t(valid)).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1)                                      # same data gradients, dropout_W inert
+    before = {n: reg._gview[n].clone() for n, _ in reg._train_items}
+    pen = reg._add_regularizers(0.25)
+    want_pen = 0.0
+    for n, _ in reg._train_items:
+        d = (reg._gview[n] - before[n]).cpu().numpy()
+        if n in ("U_0", "U_1"):
+            w = dict(reg.cell.trainable_weight_items())[n].cpu().numpy().astype(np.float64)
+            ref = (0.01 * np.sign(w) + 0.2 * w) / 0.25
+            assert np.max(np.abs(d - ref)) <= 1e-5 * np.max(np.abs(ref)), n
+            want_pen += 0.01 * np.abs(w).sum() + 0.1 * (w * w).sum()
+        else:
+            assert not d.any(), n
+    assert abs(pen - want_pen) <= 1e-5 * want_pen
+    # whole steps: the regularized loss is the plain one plus the penalty, and it trains
+    l0 = plain.train_on_batch(X, Y, valid)
+    reg.set_weights(make(None, 0.0).get_weights())
+    l1 = reg.train_on_batch(X, Y, valid)
+    assert abs((l1 - l0) - want_pen) <= 1e-4 * max(want_pen, abs(l0))
+    assert np.isfinite([reg.train_on_batch(X, Y, valid) for _ in range(3)]).all()
+    # build_alt's configuration: no free matrices, nothing regularized; dropout_U still refuses to train
+    P = O.synth_problem(2, 4, 9, 3, seed=2)
+    p = dict(input_dim=9, hidden_dim=6, output_dim=9, mask_value=-1., maxseq=4, K_layers=2, W=P["W"],
+             alph=2.0, lam1=0.3, params_untied=["log_D"], params_trainable=["log_D"])
+    m = layers.build_unfolded_snmf(p, device=dev)
+    m.cell.U_regularizer = {"l2": 1.0}
+    m.compile()
+    assert m._regularized_items() == []
+    cell = layers.SimpleDeepRNN(N, dropout_U=0.2, device=dev)
+    assert cell._train_blockers == ['dropout_U']
