@@ -55,10 +55,12 @@ __device__ __forceinline__ void st_save(float* p, f32x4 v) {
 __host__ __device__ __forceinline__ int tile_unpermute(int m) {
     return (m & ~15) | ((m & 3) << 2) | ((m >> 2) & 3);
 }
-// Exchange stores (read by the NEXT launch): nontemporal too (1013-1017 ms with, 1018-1022 without;
-// the inference forward does not change).  -DDRNMF_EXP_STX=0: ordinary, 1: write-through.
+// Exchange stores (read by the NEXT launch): ordinary.  Nontemporal (-DDRNMF_EXP_STX=2) gains 0.3 % on
+// the headline training step (1013-1017 ms against 1018-1022) and nothing on its inference forward, but
+// costs large batches their L2 hits: B = 250 inference 8.60 -> 9.00 us per launch, B = 128 6.06 -> 6.13
+// (tools/ab_shapes.sh, profiles/r03e_ab_stores.txt).  1: write-through (slower everywhere).
 #ifndef DRNMF_EXP_STX
-#define DRNMF_EXP_STX 2
+#define DRNMF_EXP_STX 0
 #endif
 __device__ __forceinline__ void st_xchg(float* p, float v) {
 #if DRNMF_EXP_STX == 1
