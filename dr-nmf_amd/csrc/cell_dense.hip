@@ -37,6 +37,8 @@ struct DenseArgs {
     int nP, nH, nX;          // 16-wide chunks of the contraction per segment (nH = 0: layer 0)
     int act;                 // DRNMF_ACT_*
     int out_width, out_off;
+    const float* drop;       // [B][N] recurrent dropout mask B_U (custom_layers.py:377-384: 0 or 1/(1-p),
+                             // one per sequence and atom, constant over frames and layers); ones without
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -155,10 +157,17 @@ __global__ void __launch_bounds__(64 * NW) dense_step_kernel(const DenseArgs a) 
     }
     if (!live) return;
     if (IS_LAST) {
+        // The state buffer holds prev_output * B_U: the step uses the previous output only through
+        // (prev_output * B_U) U_k (custom_layers.py:361); the output itself (above) stays unmasked.
         const float* so = a.state + (size_t)(t & 1) * sstride + hblk;
         float* sn = a.state + (size_t)((t + 1) & 1) * sstride + hblk;
-        sn[pos0] = vld ? hn[0] : so[pos0];
-        sn[pos1] = vld ? hn[1] : so[pos1];
+        float m0 = 1.f, m1 = 1.f;
+        if (rg < a.B) {
+            if (n < a.N) m0 = a.drop[(size_t)rg * a.N + n];
+            if (n + 1 < a.N) m1 = a.drop[(size_t)rg * a.N + n + 1];
+        }
+        sn[pos0] = vld ? hn[0] * m0 : so[pos0];
+        sn[pos1] = vld ? hn[1] * m1 : so[pos1];
     } else {
         a.h_out[hblk + pos0] = hn[0];
         a.h_out[hblk + pos1] = hn[1];
@@ -169,13 +178,19 @@ __global__ void __launch_bounds__(64 * NW) dense_step_kernel(const DenseArgs a) 
 // (stateful mode, custom_layers.py:296-318), in the packed A-operand order; frame counters = 0.
 __global__ void __launch_bounds__(256)
 dense_init_state_kernel(const float* __restrict__ h0, const float* __restrict__ init,
-                        float* __restrict__ state, int* tptr, int B, int N, int Np, int Bp) {
+                        float* __restrict__ state, int* tptr, int B, int N, int Np, int Bp,
+                        const float* __restrict__ drop_in, float* __restrict__ drop) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { tptr[0] = 0; tptr[16] = 0; }
     if (i >= (size_t)Bp * Np) return;
     const int b = (int)(i / Np), n = (int)(i % Np);
     float v = 0.f;
-    if (b < B && n < N) v = init ? init[(size_t)b * N + n] : h0[n];
+    if (b < B && n < N) {
+        // (the workspace's copy of the mask: the graphs' kernel arguments stay the same call to call)
+        const float m = drop_in ? drop_in[(size_t)b * N + n] : 1.f;
+        drop[(size_t)b * N + n] = m;
+        v = (init ? init[(size_t)b * N + n] : h0[n]) * m;
+    }
     state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + rp_pos(b & 15, n & 15)] = v;
 }
 
@@ -226,7 +241,7 @@ struct DenseLayout {
     int Bp, Fp, Np, numA, nX;
     size_t L0, L1;           // stacked rows of layer 0 / of layers k > 0
     size_t off_bias, params_total;
-    size_t off_xp, off_valid, off_h0, off_h1, off_state, off_t, ws_total;
+    size_t off_xp, off_valid, off_h0, off_h1, off_state, off_t, off_drop, ws_total;
     size_t m_off(int k) const { return k == 0 ? 0 : (L0 + (size_t)(k - 1) * L1) * Np * 4; }
 };
 
@@ -249,6 +264,7 @@ DenseLayout dense_layout(const drnmf_dense_desc_t* d) {
     D.off_h1 = take((size_t)D.Bp * D.Np * 4);
     D.off_state = take((size_t)2 * D.Bp * D.Np * 4);
     D.off_t = take(256);
+    D.off_drop = take((size_t)d->B * d->N * 4);
     D.ws_total = o;
     return D;
 }
@@ -312,16 +328,19 @@ extern "C" int32_t drnmf_dense_prepare_params(drnmf_handle_t h, const drnmf_dens
     return DRNMF_OK;
 }
 
-extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_desc_t* d,
-                                            const float* x, float mask_value, const void* params,
-                                            const float* h0, const float* initial_state,
-                                            float* final_state, float* h_out, void* workspace,
-                                            size_t workspace_bytes, void* stream_) {
+static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d, const float* x,
+                                  float mask_value, const void* params, const float* h0,
+                                  const float* initial_state, float* final_state, float* h_out,
+                                  void* workspace, size_t workspace_bytes, void* stream_,
+                                  const float* drop_u) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_dense_desc(h, d);
     if (rc) return rc;
     if (!x || !params || !h_out || !workspace || (!h0 && !initial_state))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_forward: NULL pointer argument");
+    if (drop_u && final_state)
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "dense_cell_forward: the state kept under recurrent dropout "
+                   "is the MASKED previous output; final_state is not available (training phase only)");
     const DenseLayout D = dense_layout(d);
     if (workspace_bytes < D.ws_total)
         DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "dense_cell_forward: workspace %zu < required %zu",
@@ -345,7 +364,8 @@ extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_
                            stream, x, xp, valid, mask_value, d->B, d->T, d->F, D.Bp, D.Fp);
         const size_t tot = (size_t)D.Bp * D.Np;
         hipLaunchKernelGGL(dense_init_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256),
-                           0, stream, h0, initial_state, state, tA, d->B, d->N, D.Np, D.Bp);
+                           0, stream, h0, initial_state, state, tA, d->B, d->N, D.Np, D.Bp, drop_u,
+                           (float*)(ws + D.off_drop));
         DRNMF_HIP(h, hipGetLastError());
     }
 
@@ -373,6 +393,7 @@ extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_
         a.act = d->activation;
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
+        a.drop = (const float*)(ws + D.off_drop);
         return a;
     };
     // waves per workgroup by contraction length (16-wide chunks).  Measured on MI355X, us per
@@ -470,4 +491,26 @@ extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_
         DRNMF_HIP(h, hipGetLastError());
     }
     return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                            const float* x, float mask_value, const void* params,
+                                            const float* h0, const float* initial_state,
+                                            float* final_state, float* h_out, void* workspace,
+                                            size_t workspace_bytes, void* stream_) {
+    return dense_forward_impl(h, d, x, mask_value, params, h0, initial_state, final_state, h_out,
+                              workspace, workspace_bytes, stream_, nullptr);
+}
+
+// Training phase with recurrent dropout (dropout_U, custom_layers.py:361, 377-384): drop_u [B][N] = the
+// mask B_U the caller drew (0 or 1/(1-p)); prev_output * B_U enters every U_k product.
+extern "C" int32_t drnmf_dense_cell_forward_dropout(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                                    const float* x, float mask_value,
+                                                    const void* params, const float* h0,
+                                                    const float* drop_u, float* h_out,
+                                                    void* workspace, size_t workspace_bytes,
+                                                    void* stream_) {
+    if (h && !drop_u) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_forward_dropout: NULL mask");
+    return dense_forward_impl(h, d, x, mask_value, params, h0, nullptr, nullptr, h_out, workspace,
+                              workspace_bytes, stream_, drop_u);
 }

@@ -87,6 +87,7 @@ struct DzArgs {
     const float* G_st;       // [B][N]
     const float* dH;         // [B][N]: d h_k from layer k+1's product (k < K-1)
     const unsigned char* valid;
+    const float* drop;       // [B][N] recurrent dropout mask (state = prev_output * B_U) or nullptr
     int B, T, N, K, ow, k, t, act, slice_off;   // slice_off < 0: this layer is not part of the output
 };
 __global__ void __launch_bounds__(256) dense_dz_kernel(const DzArgs a) {
@@ -103,7 +104,8 @@ __global__ void __launch_bounds__(256) dense_dz_kernel(const DzArgs a) {
     }
     float dz = 0.f;
     if (v) {
-        const float g = gop + (a.k == a.K - 1 ? a.G_st[i] : a.dH[i]);
+        const float gst = a.k == a.K - 1 ? a.G_st[i] * (a.drop ? a.drop[i] : 1.f) : 0.f;
+        const float g = gop + (a.k == a.K - 1 ? gst : a.dH[i]);
         const float hk = a.hall[bt * ((size_t)a.K * a.N) + (size_t)a.k * a.N + n];
         dz = g * act_grad_from_output(hk, a.act);
         if (gp) *gp = 0.f;
@@ -137,12 +139,13 @@ struct EpiDenseBwd {
 __global__ void __launch_bounds__(256)
 dense_gather_p_kernel(const float* __restrict__ hall, const float* __restrict__ h0,
                       const unsigned char* __restrict__ seen, float* __restrict__ P, int64_t BT,
-                      int N, int K) {
+                      int N, int K, int T, const float* __restrict__ drop) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)BT * N) return;
     const int64_t bt = (int64_t)(i / N);
     const int n = (int)(i % N);
-    P[i] = seen[bt] ? hall[(size_t)(bt - 1) * K * N + (size_t)(K - 1) * N + n] : h0[n];
+    const float v = seen[bt] ? hall[(size_t)(bt - 1) * K * N + (size_t)(K - 1) * N + n] : h0[n];
+    P[i] = drop ? v * drop[(size_t)(bt / T) * N + n] : v;      // (what U_k multiplied: the masked state)
 }
 
 struct EpiPart {
@@ -179,11 +182,12 @@ dense_colsum_kernel(const float* __restrict__ dz, float* __restrict__ part, int6
 }
 
 __global__ void __launch_bounds__(256)
-dense_rowsum_kernel(const float* __restrict__ G, float* __restrict__ out, int B, int N) {
+dense_rowsum_kernel(const float* __restrict__ G, float* __restrict__ out, int B, int N,
+                    const float* __restrict__ drop) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += G[(size_t)b * N + n];
+    for (int b = 0; b < B; ++b) s += G[(size_t)b * N + n] * (drop ? drop[(size_t)b * N + n] : 1.f);
     out[n] = s;
 }
 
@@ -220,13 +224,14 @@ extern "C" size_t drnmf_dense_backward_workspace_bytes(const drnmf_dense_desc_t*
     return bwd_ws(d).total;
 }
 
-extern "C" int32_t drnmf_dense_cell_backward(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+static int32_t dense_backward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
                                              const float* x, float mask_value, const float* U,
                                              const float* S, const float* W, const float* b,
                                              const float* h0, const float* hall,
                                              const float* d_out, float* dU, float* dS, float* dW,
                                              float* db, float* dh0, void* workspace,
-                                             size_t workspace_bytes, void* stream_) {
+                                             size_t workspace_bytes, void* stream_,
+                                             const float* drop_u) {
     (void)b;
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0 || d->K <= 0)
@@ -274,7 +279,7 @@ extern "C" int32_t drnmf_dense_cell_backward(drnmf_handle_t h, const drnmf_dense
         for (int k = K - 1; k >= 0; --k) {
             DzArgs a;
             a.hall = hall; a.d_out = d_out; a.dz_all = dz_all; a.G_op = G_op; a.G_st = G_st;
-            a.dH = dHb[k & 1]; a.valid = valid;
+            a.dH = dHb[k & 1]; a.valid = valid; a.drop = drop_u;
             a.B = B; a.T = T; a.N = N; a.K = K; a.ow = ow; a.k = k; a.t = t; a.act = d->activation;
             a.slice_off = d->return_all_hidden ? k * N : (k == K - 1 ? 0 : -1);
             hipLaunchKernelGGL(dense_dz_kernel, dim3(egrid), dim3(256), 0, stream, a);
@@ -287,13 +292,13 @@ extern "C" int32_t drnmf_dense_cell_backward(drnmf_handle_t h, const drnmf_dense
         }
     }
     hipLaunchKernelGGL(dense_rowsum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, G_st, dh0,
-                       B, N);
+                       B, N, drop_u);
 
     // ---- time-batched weight gradients -----------------------------------------------------------
     {
         const size_t tot = (size_t)BT * N;
         hipLaunchKernelGGL(dense_gather_p_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                           stream, hall, h0, seen, P_all, BT, N, K);
+                           stream, hall, h0, seen, P_all, BT, N, K, T, drop_u);
     }
     int splits = DB_SPLITS;
     while (splits > 1 && BT / splits < 64) splits >>= 1;
@@ -321,4 +326,27 @@ extern "C" int32_t drnmf_dense_cell_backward(drnmf_handle_t h, const drnmf_dense
     }
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_dense_cell_backward(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                             const float* x, float mask_value, const float* U,
+                                             const float* S, const float* W, const float* b,
+                                             const float* h0, const float* hall,
+                                             const float* d_out, float* dU, float* dS, float* dW,
+                                             float* db, float* dh0, void* workspace,
+                                             size_t workspace_bytes, void* stream_) {
+    return dense_backward_impl(h, d, x, mask_value, U, S, W, b, h0, hall, d_out, dU, dS, dW, db, dh0,
+                               workspace, workspace_bytes, stream_, nullptr);
+}
+
+// BPTT of drnmf_dense_cell_forward_dropout with the same mask drop_u [B][N]: the state gradient
+// reaches the previous output through B_U, dU_k contracts the masked state, d h0 sums B_U * G_st.
+extern "C" int32_t drnmf_dense_cell_backward_dropout(
+    drnmf_handle_t h, const drnmf_dense_desc_t* d, const float* x, float mask_value, const float* U,
+    const float* S, const float* W, const float* b, const float* h0, const float* drop_u,
+    const float* hall, const float* d_out, float* dU, float* dS, float* dW, float* db, float* dh0,
+    void* workspace, size_t workspace_bytes, void* stream_) {
+    if (h && !drop_u) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_backward_dropout: NULL mask");
+    return dense_backward_impl(h, d, x, mask_value, U, S, W, b, h0, hall, d_out, dU, dS, dW, db, dh0,
+                               workspace, workspace_bytes, stream_, drop_u);
 }

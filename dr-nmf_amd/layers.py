@@ -13,8 +13,8 @@ every other configuration of the layer.  Training likewise: the fused BPTT for t
 trainable set (log_D, log_alph, log_lam1, log_h0), the dense-matrix BPTT (csrc/cell_dense_bwd.hip)
 for everything else the reference can train -- log_U1 / log_Uk, caller maps, free weights, other
 activations -- with torch autograd carrying the matrix gradients through the caller's maps.  There
-is no CPU/oracle fallback: what the kernels do not cover (dropout_U in training)
-raises NotImplementedError.  The KL / beta extension of the cell trains through its own BPTT
+is no CPU/oracle fallback: what the kernels do not cover raises NotImplementedError (dropout_U
+trains on the dense-matrix path).  The KL / beta extension of the cell trains through its own BPTT
 (drnmf_cell_backward_ista).
 """
 from collections import OrderedDict
@@ -324,15 +324,23 @@ class SimpleDeepRNN(_Layer):
         # custom_layers.py:377-395).  In training the reference applies ONLY dropout_U: the layer sets
         # consume_less = 'gpu' (custom_layers.py:169), so get_constants never builds the dropout_W
         # mask (custom_layers.py:386: B_W = 1) -- dropout_W is accepted and has no effect, as there.
-        # dropout_U (a per-sequence mask on prev_output in every U_k term) is not implemented.
+        # dropout_U (custom_layers.py:361: (prev_output * B_U) U_k in every layer, one mask per
+        # sequence and atom for the whole call, 377-384) trains on the dense-matrix path
+        # (drnmf_dense_cell_forward_dropout / _backward_dropout): forward_train draws the mask with
+        # torch's device generator (the reference's comes from Theano's RNG; `_drop_u_mask` lets a
+        # caller supply one).
         # Regularizers belong to the FREE matrices only (custom_layers.py:245-269: add_weight(...,
         # regularizer=...) is reached where maps_from_alt has no map for W / U / b; S has none): with
         # build_alt's maps -- everything enhance.py constructs -- there is nothing for them to act
         # on; on free weights the model adds their penalty and its gradient (UnfoldedSNMFModel.
         # _add_regularizers).
         self._train_blockers = []
-        if dropout_U:
-            self._train_blockers.append('dropout_U')
+        if dropout_U and not (0.0 < float(dropout_U) < 1.0):
+            raise ValueError("dropout_U must lie in [0, 1)")
+        if dropout_U and (divergence != 'ed' or operand_dtype != 'float32'):
+            raise NotImplementedError("dropout_U trains on the dense-matrix path: the Euclidean cell "
+                                      "with fp32 operands")
+        self._drop_u_mask = None     # test hook: a (B,N) mask to use instead of a fresh draw
 
     # -- Keras protocol --------------------------------------------------------------------
     def compute_output_shape(self, input_shape):                          # custom_layers.py:175-185
@@ -587,7 +595,7 @@ class SimpleDeepRNN(_Layer):
                                       ', '.join(self._train_blockers))
         if not self.built:
             self.build(tuple(x.shape))
-        if self._dense_now or getattr(self, '_train_dense', False):
+        if self._dense_now or getattr(self, '_train_dense', False) or self.dropout_U:
             return self._forward_train_dense(x, mask_value)
         B, T, F = x.shape
         self.prepare(B, T)
@@ -682,12 +690,23 @@ class SimpleDeepRNN(_Layer):
         if key not in self._ws:
             self._ws.clear()
             self._ws[key] = ops.dense_workspace(desc, x.device)
-        hall = ops.dense_cell_forward(x, mask_value, block, desc, c(h0), workspace=self._ws[key])
-        self._train_ctx = ('dense', leaves, (U, S, W, b, h0), mask_value)
+        drop = None
+        if self.dropout_U:
+            # get_constants (custom_layers.py:377-384): K.dropout(ones(B, N), p) = Bernoulli(1-p) / (1-p)
+            drop = self._drop_u_mask
+            if drop is None:
+                keep = 1.0 - float(self.dropout_U)
+                drop = torch.bernoulli(torch.full((B, self.output_dim), keep, dtype=torch.float32,
+                                                  device=x.device)) / keep
+            else:
+                drop = torch.as_tensor(drop, dtype=torch.float32, device=x.device).contiguous()
+        hall = ops.dense_cell_forward(x, mask_value, block, desc, c(h0), workspace=self._ws[key],
+                                      drop_u=drop)
+        self._train_ctx = ('dense', leaves, (U, S, W, b, h0), mask_value, drop)
         return hall
 
     def _backward_dense(self, x, hall, d_out):
-        _, leaves, (U, S, W, b, h0), mask_value = self._train_ctx
+        _, leaves, (U, S, W, b, h0), mask_value, drop = self._train_ctx
         B, T, F = x.shape
         N, K = self.output_dim, self.K_layers
         all_hidden = d_out.shape[-1] == K * N and K > 1
@@ -695,7 +714,7 @@ class SimpleDeepRNN(_Layer):
                                    self.activation, all_hidden)
         c = lambda v: None if v is None else v.detach().contiguous()
         g = ops.dense_cell_backward(x, mask_value, desc, c(U), c(S), c(W), c(b), c(h0), hall, d_out,
-                                    workspace=getattr(self, '_dense_bwd_ws', None))
+                                    workspace=getattr(self, '_dense_bwd_ws', None), drop_u=drop)
         self._dense_bwd_ws = g['workspace']
         outs, grads = [], []
         for t, gt in ((U, g['dU']), (S, g['dS']), (W, g['dW']), (b, g['db']), (h0, g['dh0'])):
@@ -706,7 +725,7 @@ class SimpleDeepRNN(_Layer):
             torch.autograd.backward(outs, grads)
         by_name = OrderedDict((n, (l.grad if l.grad is not None else torch.zeros_like(l)))
                               for n, l in leaves.items())
-        self._train_ctx = ('dense', None, None, None)
+        self._train_ctx = ('dense', None, None, None, None)
         return {'by_name': by_name}
 
     def grad_slices(self):
@@ -909,6 +928,11 @@ class UnfoldedSNMFModel(object):
             covered = set(w for w, _, _ in cell.grad_slices())
             if any(k in cell.keys_trainable and k not in covered for k in cell._alt):
                 cell._train_dense = True
+        # (a step may move the matrices away from what the fused inference kernels assume -- unless
+        # the dense path was chosen for recurrent dropout alone: those kernels carry B_U)
+        cell._dense_after_step = cell._train_dense
+        if cell.dropout_U:
+            cell._train_dense = True
         if cell._train_dense:
             if cell.operand_dtype != 'float32':
                 raise NotImplementedError("operand_dtype='float16' trains on the fused path only")
@@ -1067,7 +1091,7 @@ class UnfoldedSNMFModel(object):
         # from log_U1 / log_Uk, which compile() refuses to train: re-deriving them here would cost
         # two N x N device-to-host copies and a host pass per step
         self.cell._params_block_valid = False
-        if getattr(self.cell, '_train_dense', False):
+        if getattr(self.cell, '_dense_after_step', getattr(self.cell, '_train_dense', False)):
             # the matrices have moved: inference runs on the dense kernel from now on (no host
             # round trip to re-examine U's structure after every step)
             self.cell._dense_now = True

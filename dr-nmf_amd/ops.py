@@ -176,10 +176,18 @@ def dense_workspace(desc, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
+def _check_drop_u(drop_u, desc):
+    drop_u = _f32c(drop_u, "drop_u")
+    if tuple(drop_u.shape) != (desc.B, desc.N):
+        raise ValueError("drop_u must be a (B,N) = (%d,%d) mask" % (desc.B, desc.N))
+    return drop_u
+
+
 def dense_cell_forward(x, mask_value, params, desc, h0, out=None, workspace=None,
-                       initial_state=None, final_state=None):
+                       initial_state=None, final_state=None, drop_u=None):
     """General SimpleDeepRNN.step on dense per-layer matrices: x [B,T,F] -> h [B,T,N] (or
-    [B,T,K*N]).  h0 [N] is the initial state itself."""
+    [B,T,K*N]).  h0 [N] is the initial state itself.  drop_u [B,N]: the training phase's recurrent
+    dropout mask B_U (custom_layers.py:377-384), 0 or 1/(1-p)."""
     L = _capi.lib()
     h = _capi.handle(_dev_index(x))
     x, h0 = _f32c(x, "x"), _f32c(h0, "h0")
@@ -200,6 +208,15 @@ def dense_cell_forward(x, mask_value, params, desc, h0, out=None, workspace=None
                                or not st.is_contiguous()):
             raise ValueError("states must be contiguous float32 (B,N) tensors")
     mv = float("nan") if mask_value is None else float(mask_value)
+    if drop_u is not None:
+        if initial_state is not None or final_state is not None:
+            raise ValueError("recurrent dropout belongs to the training phase: no stateful pointers")
+        drop_u = _check_drop_u(drop_u, desc)
+        rc = L.drnmf_dense_cell_forward_dropout(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
+                                                _capi.ptr(h0), _capi.ptr(drop_u), _capi.ptr(out),
+                                                _capi.ptr(workspace), workspace.numel(), _stream())
+        _capi.check(rc, h, "drnmf_dense_cell_forward_dropout")
+        return out
     rc = L.drnmf_dense_cell_forward(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
                                     _capi.ptr(h0), _capi.ptr(initial_state),
                                     _capi.ptr(final_state), _capi.ptr(out), _capi.ptr(workspace),
@@ -208,7 +225,8 @@ def dense_cell_forward(x, mask_value, params, desc, h0, out=None, workspace=None
     return out
 
 
-def dense_cell_backward(x, mask_value, desc, U, S, W, b, h0, hall, d_out, workspace=None):
+def dense_cell_backward(x, mask_value, desc, U, S, W, b, h0, hall, d_out, workspace=None,
+                        drop_u=None):
     """BPTT of the dense step (drnmf_dense_cell_backward): hall [B,T,K*N] is the forward's
     all-hidden output, d_out the gradient w.r.t. the returned output ([B,T,N], or [B,T,K*N] when
     desc.return_all_hidden).  Returns dict(dU [K,N,N], dS [K-1,N,N] | None, dW [K,F,N] | None,
@@ -237,6 +255,16 @@ def dense_cell_backward(x, mask_value, desc, U, S, W, b, h0, hall, d_out, worksp
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     mv = float("nan") if mask_value is None else float(mask_value)
+    if drop_u is not None:
+        drop_u = _check_drop_u(drop_u, desc)
+        rc = L.drnmf_dense_cell_backward_dropout(
+            h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(U), _capi.ptr(S), _capi.ptr(W), _capi.ptr(b),
+            _capi.ptr(h0), _capi.ptr(drop_u), _capi.ptr(hall), _capi.ptr(d_out), _capi.ptr(g["dU"]),
+            _capi.ptr(g["dS"]), _capi.ptr(g["dW"]), _capi.ptr(g["db"]), _capi.ptr(g["dh0"]),
+            _capi.ptr(workspace), workspace.numel(), _stream())
+        _capi.check(rc, h, "drnmf_dense_cell_backward_dropout")
+        g["workspace"] = workspace
+        return g
     rc = L.drnmf_dense_cell_backward(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(U), _capi.ptr(S),
                                      _capi.ptr(W), _capi.ptr(b), _capi.ptr(h0), _capi.ptr(hall),
                                      _capi.ptr(d_out), _capi.ptr(g["dU"]), _capi.ptr(g["dS"]),

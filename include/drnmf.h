@@ -205,6 +205,23 @@ int32_t drnmf_dense_cell_backward(drnmf_handle_t h, const drnmf_dense_desc_t* d,
                                   const float* hall, const float* d_out, float* dU, float* dS,
                                   float* dW, float* db, float* dh0, void* workspace,
                                   size_t workspace_bytes, void* stream);
+/* Training phase with recurrent dropout -- dropout_U, custom_layers.py:361 ((prev_output * B_U) U_k in
+ * every layer) and 377-384 (get_constants: B_U = K.dropout(ones(B, N), dropout_U), one mask per
+ * sequence and atom for the whole call).  drop_u [B][N] is that mask, drawn by the caller (0 or
+ * 1/(1-p)); everything else as drnmf_dense_cell_forward / _backward without the stateful pointers.
+ * (dropout_W never takes effect in the reference: the layer sets consume_less = 'gpu',
+ * custom_layers.py:169, 386.) */
+int32_t drnmf_dense_cell_forward_dropout(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                         const float* x, float mask_value, const void* params,
+                                         const float* h0, const float* drop_u, float* h_out,
+                                         void* workspace, size_t workspace_bytes, void* stream);
+int32_t drnmf_dense_cell_backward_dropout(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                          const float* x, float mask_value, const float* U,
+                                          const float* S, const float* W, const float* b,
+                                          const float* h0, const float* drop_u, const float* hall,
+                                          const float* d_out, float* dU, float* dS, float* dW,
+                                          float* db, float* dh0, void* workspace,
+                                          size_t workspace_bytes, void* stream);
 
 /* ---- mask head: replaces the H_clean/H_noise slices, TimeDistributed(DenseNonNegW) x2
  * (custom_layers.py:23-29; enhance.py:277-292), the optional 'square' transform

@@ -92,10 +92,11 @@ _ACT = {
 
 
 def dense_cell(x, Uk, Sk, Wk, bk, h0, mask_value=-1.0, return_all_hidden=False,
-               connect_input=True, activation='relu'):
+               connect_input=True, activation='relu', drop_u=None):
     """torch twin of oracle.cell_forward_dense (custom_layers.py:343-375 under K.rnn's masked scan),
     for reference gradients w.r.t. the step's matrices.  Uk [K,N,N], Sk [K-1,N,N], Wk [K,F,N],
-    bk [K,N], h0 [N] = the initial state itself."""
+    bk [K,N], h0 [N] = the initial state itself.  drop_u [B,N]: the recurrent dropout mask B_U of
+    the training phase, multiplying prev_output in every U_k product (custom_layers.py:361, 377-384)."""
     B, T, F = x.shape
     K, N = Uk.shape[0], Uk.shape[1]
     act = _ACT[activation]
@@ -106,7 +107,7 @@ def dense_cell(x, Uk, Sk, Wk, bk, h0, mask_value=-1.0, return_all_hidden=False,
     out_prev = torch.zeros(B, width, dtype=x.dtype)
     outs = []
     for t in range(T):
-        p = state
+        p = state if drop_u is None else state * drop_u
         hidden = []
         for k in range(K):
             pre = p @ Uk[k]

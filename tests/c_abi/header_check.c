@@ -26,4 +26,5 @@ fn_t drnmf_all_exports[] = {
     REF(drnmf_cell_backward_profile), REF(drnmf_comm_unique_id), REF(drnmf_comm_init),
     REF(drnmf_comm_destroy), REF(drnmf_comm_info), REF(drnmf_allreduce_grads),
     REF(drnmf_broadcast_params), REF(drnmf_cell_launches_per_frame),
+    REF(drnmf_dense_cell_forward_dropout), REF(drnmf_dense_cell_backward_dropout),
 };

@@ -491,7 +491,7 @@ def test_model_regularizers_on_free_weights_and_dropout_w_is_inert(dev):
     l1 = reg.train_on_batch(X, Y, valid)
     assert abs((l1 - l0) - want_pen) <= 1e-4 * max(want_pen, abs(l0))
     assert np.isfinite([reg.train_on_batch(X, Y, valid) for _ in range(3)]).all()
-    # build_alt's configuration: no free matrices, nothing regularized; dropout_U still refuses to train
+    # build_alt's configuration: no free matrices, nothing regularized
     P = O.synth_problem(2, 4, 9, 3, seed=2)
     p = dict(input_dim=9, hidden_dim=6, output_dim=9, mask_value=-1., maxseq=4, K_layers=2, W=P["W"],
              alph=2.0, lam1=0.3, params_untied=["log_D"], params_trainable=["log_D"])
@@ -499,5 +499,85 @@ def test_model_regularizers_on_free_weights_and_dropout_w_is_inert(dev):
     m.cell.U_regularizer = {"l2": 1.0}
     m.compile()
     assert m._regularized_items() == []
-    cell = layers.SimpleDeepRNN(N, dropout_U=0.2, device=dev)
-    assert cell._train_blockers == ['dropout_U']
+
+
+def test_recurrent_dropout_trains_on_the_dense_path(dev):
+    """dropout_U (custom_layers.py:361, 377-384): one Bernoulli(1-p) / (1-p) mask per sequence and atom
+    multiplies prev_output in every U_k product of the training phase.  With a given mask the layer's
+    forward and every gradient equal torch fp64 autograd of the oracle's op graph carrying the same
+    mask; a fresh draw has the right values and rate; inference ignores dropout; build_alt's model
+    trains with it on the dense kernels and keeps predicting on the fused ones."""
+    from drnmf_amd import layers
+    from oracle import drnmf_torch_ref as R
+    B, T, F, N, K = 5, 6, 12, 16, 3
+    rng = np.random.default_rng(9)
+    A = (0.2 * rng.standard_normal((F, N))).astype(np.float32)
+    c = (0.1 * rng.standard_normal((N,))).astype(np.float32)
+    maps = {"W": lambda a: a["A"], "b": lambda a: a["c"]}
+    np.random.seed(2)
+    cell = layers.SimpleDeepRNN(N, activation="tanh", K_layers=K, alt_params={"A": A, "c": c},
+                                keys_trainable=["A", "c"], maps_from_alt=maps, dropout_U=0.4,
+                                dropout_W=0.5, flag_connect_input_to_layers=True,
+                                flag_nonnegative=False, return_sequences=True, device=dev)
+    X = _ragged_x(rng, B, T, F)
+    x = torch.from_numpy(X).to(dev)
+    cell.build(tuple(x.shape))
+    w2 = cell.get_weights()
+    w2[0] = (0.3 * rng.standard_normal(N)).astype(np.float32)
+    cell.set_weights(w2)
+    names = [n[len(cell.name) + 1:] for n in cell.weight_names]
+    w = dict(zip(names, cell.get_weights()))
+    mask = ((rng.random((B, N)) < 0.6) / 0.6).astype(np.float32)
+    Rw = rng.standard_normal((B, T, N)).astype(np.float32)
+    cell._drop_u_mask = mask
+    hall = cell.forward_train(x, mask_value=-1.)
+    g = cell.backward(x, hall, torch.from_numpy(Rw).to(dev))["by_name"]
+    torch.cuda.synchronize()
+
+    td = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    L = {n: td(w[n]) for n in names}
+    Us = torch.stack([L["U_%d" % k] for k in range(K)])
+    Ss = torch.stack([L["S_%dto%d" % (k - 1, k)] for k in range(1, K)])
+
+    def ref(drop):
+        return R.dense_cell(torch.tensor(X.astype(np.float64)), Us, Ss, torch.stack([L["A"]] * K),
+                            torch.stack([L["c"]] * K), L["h0"], activation="tanh", drop_u=drop)
+    out = ref(torch.tensor(mask.astype(np.float64)))
+    _check(hall[..., (K - 1) * N:].cpu().numpy(), out.detach().numpy())
+    (out * torch.tensor(Rw.astype(np.float64))).sum().backward()
+    for n, gv in g.items():
+        want = L[n].grad.numpy()
+        err = np.max(np.abs(gv.cpu().numpy() - want)) / max(np.max(np.abs(want)), 1e-30)
+        assert err <= G_TOL, "%s: max|dg|/max|g| = %.3e" % (n, err)
+    # the mask matters (a test that passes without it proves nothing) ...
+    assert np.max(np.abs(out.detach().numpy() - ref(None).detach().numpy())) > 1e-3
+    # ... and inference does not see it (K.in_train_phase)
+    _check(cell.call(x, mask_value=-1.).cpu().numpy(), ref(None).detach().numpy())
+    # a fresh draw: values 0 or 1/(1-p), keep rate 1-p
+    cell._drop_u_mask = None
+    torch.manual_seed(5)
+    big = layers.SimpleDeepRNN(64, activation="tanh", K_layers=1, dropout_U=0.25, return_sequences=True,
+                               flag_connect_input_to_layers=True, device=dev)
+    xb = torch.rand((64, 2, 8), device=dev)
+    big.build(tuple(xb.shape))
+    big.forward_train(xb, mask_value=-1.)
+    m = big._train_ctx[4].cpu().numpy()
+    assert m.shape == (64, 64) and np.all((m == 0) | (np.abs(m - 1 / 0.75) < 1e-6))
+    assert abs((m > 0).mean() - 0.75) < 0.03
+
+    # build_alt's model: trains (dense kernels carry B_U), inference stays on the fused kernels
+    P = O.synth_problem(4, 6, 21, 6, seed=33, ragged=True, density=0.15)
+    p = dict(input_dim=21, hidden_dim=12, output_dim=21, mask_value=-1., maxseq=6, K_layers=3, W=P["W"],
+             alph=3.0, lam1=0.3, params_untied=["log_D", "log_alph"], params_trainable=["log_D", "log_alph"])
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.cell.dropout_U = 0.3
+    model.compile(lr=1e-3)
+    assert model.cell._train_dense and not model.cell._dense_after_step
+    valid = np.any(P["X"] != -1.0, axis=-1).astype(np.float32)
+    Y = (0.5 * np.abs(P["X"])).astype(np.float32)
+    losses = [model.train_on_batch(P["X"], Y, valid) for _ in range(4)]
+    assert np.isfinite(losses).all()
+    assert not model.cell._dense_now
+    assert np.all(np.isfinite(model.predict_on_batch(P["X"])))
+    with pytest.raises(ValueError):
+        layers.SimpleDeepRNN(N, dropout_U=1.5, device=dev)
