@@ -230,7 +230,7 @@ def train_bench(torch, dev, steps=20, warmup=5, shape=(32, 500, 257, 1000, 5), r
             "cell_forward_ms": fwd_ms, "bptt_sequential_ms": bp["chain_ms"],
             "bptt_time_batched_ms": bp["batched_ms"], "steps": steps, "warmup": warmup,
             "timing": "HIP events",
-            "loss_first": losses[0], "loss_last": losses[-1]}
+            "loss_first": float(losses[0]), "loss_last": float(losses[-1])}
 
 
 def slab_bench(torch, dev, F, r, K, T, slab=250):
@@ -867,7 +867,7 @@ def main():
             "whole_step_tflops_algorithmic": flops_step / (ev_ms / a.steps * 1e-3) / 1e12,
             "whole_step_frac_of_f32_mfma_peak":
                 flops_step / (ev_ms / a.steps * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "loss_first": train["losses"][0], "loss_last": train["losses"][-1],
+            "loss_first": float(train["losses"][0]), "loss_last": float(train["losses"][-1]),
         }
     elif train is not None:
         out = {"metric": "STFT frames/sec (fwd+bwd), %d-bin x %d-frame, K=%d unrolls" % (F, T, K),
@@ -875,7 +875,8 @@ def main():
                "warmup": a.warmup, "error": train["error"]}
 
     # release the training state (hall, dz, dR: ~60 GB at the headline shape) before the rest
-    model._opt_state = model._flat = model._gview = None
+    model._opt_state = model._flat = model._gview = model._mflat = model._vflat = None
+    model._adam_table = None
     model.cell._ws.clear()
     del Y
     torch.cuda.empty_cache()

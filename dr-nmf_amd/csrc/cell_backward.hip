@@ -1298,7 +1298,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
 
     // Gram form with few tiles: the whole sequential pass as ONE launch of independent persistent
     // chains, one per row tile (cell_gram_persist.h); same arithmetic as the graphs below.
-    const bool persist = W.gram && persist_shape_ok(numM, W.numO, K) && persist_admit(h, stream);
+    const bool persist = W.gram && persist_shape_ok(h, numM, W.numO, K) && persist_admit(h, stream);
     if (persist) {
         GramPersistBwdArgs pa;
         memset(&pa, 0, sizeof(pa));

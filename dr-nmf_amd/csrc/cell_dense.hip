@@ -400,7 +400,7 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
     // layer-step with 4 / 8 / 16 waves: F=513 N=2000 B=64: 17.6 / 17.2 / 19.3; F=257 N=2000 B=32:
     // 14.9 / 13.8 / 16.8; F=257 N=200 B=32: 4.8 / 5.2 / 6.0
     int nw = (D.Np / 16) * 2 + D.nX >= 128 ? 8 : 4;
-    if (const char* e = getenv("DRNMF_DENSE_NW")) {   // tuning aid
+    if (const char* e = tune_env("DRNMF_DENSE_NW")) {   // tuning aid
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16) nw = v;
     }
@@ -413,7 +413,7 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
     int fpg = 400 / K;
     fpg = fpg < 1 ? 1 : (fpg > 64 ? 64 : fpg);
     if (fpg > d->T) fpg = d->T;
-    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr;
+    const bool use_graph = tune_env("DRNMF_NO_GRAPH") == nullptr;
     if (!use_graph) {
         for (int t = 0; t < d->T; ++t) {
             for (int k = 0; k < K; ++k) {

@@ -705,12 +705,12 @@ template <int KS, int RB, bool AH, bool HALF>
 void* a_func_g(int per_wave, bool first, bool last, bool qred = false) {
     // G operand slots; operand registers G * (4*KS*RB + 8)
     if (per_wave <= 2) return a_func<2, KS, RB, AH, HALF>(first, last, qred);
-    if (HALF && per_wave >= 8 && getenv("DRNMF_G8"))   // tuning aid: 8 operand slots
+    if (HALF && per_wave >= 8 && tune_env("DRNMF_G8"))   // tuning aid: 8 operand slots
         return a_func<8, KS, RB, AH, HALF>(first, last, qred);
     // (8 slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch)
     // two groups per wave (F = 513), one row block, fp32: epilogue operand loads behind the first chunk
     bool late = RB == 1 && !HALF && per_wave > 4 && per_wave <= 8;
-    if (const char* e = getenv("DRNMF_LATE"))   // tuning aid: 0 = never, 2 = whenever instantiated
+    if (const char* e = tune_env("DRNMF_LATE"))   // tuning aid: 0 = never, 2 = whenever instantiated
         late = atoi(e) == 2 ? (RB == 1 && !HALF && per_wave > 2) : (late && atoi(e) != 0);
     if (late && !qred) return a_func<4, KS, RB, AH, HALF, (RB == 1 && !HALF)>(first, last);
     return a_func<4, KS, RB, AH, HALF>(first, last, qred);
@@ -745,6 +745,10 @@ void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_h
 }
 
 }  // namespace
+
+void persist_query_occupancy(int device, int* per_cu, int* n_cu) {
+    persist_query_occupancy_impl(device, per_cu, n_cu);
+}
 
 #ifdef DRNMF_TIMELINE
 extern "C" int32_t drnmf_debug_persist_timeline(void* out_host, size_t bytes) {
@@ -819,7 +823,7 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     }
     // c_k of one block of GRAM_TB frames into its ring slot (stream-ordered behind the chain of the
     // block that used the slot before)
-    const bool cp_full = W.cp_frames == d->T;       // every frame's c_k resident: one product up front
+    const bool cp_full = W.cp_full;       // every frame's c_k resident: one product up front
     const int cp_mask = cp_full ? 0x7fffffff : 2 * GRAM_TB - 1;
     auto compute_block = [&](int j) -> int32_t {
         if (cp_full && j > 0) return DRNMF_OK;
@@ -936,7 +940,7 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     // (cell_gram_persist.h), one launch per block of frames.  DRNMF_PERSIST=0, a shape outside its
     // limits, or persistent launches of another stream still in flight on this handle keep the
     // launch-per-layer-step graphs.
-    if (persist_shape_ok(numM, numO, K) && persist_admit(h, stream)) {
+    if (persist_shape_ok(h, numM, numO, K) && persist_admit(h, stream)) {
         unsigned* bar = (unsigned*)(ws + W.off_t + 256);
         const int tb = cp_full ? d->T : GRAM_TB;          // frames per launch
         for (int j = 0; j * tb < d->T; ++j) {
@@ -1079,7 +1083,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     // ---- one frame = 2K-1 launches, as a cached hipGraph -------------------------------------
     // measurement aid: DRNMF_ABLATE=1 launches the same grids but every workgroup exits at once
     // (launch/boundary floor of the frame graph; results are garbage)
-    const bool ablate = getenv("DRNMF_ABLATE") != nullptr;
+    const bool ablate = tune_env("DRNMF_ABLATE") != nullptr;
     std::vector<uint64_t> key = {
         (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N, (uint64_t)d->K,
         (uint64_t)d->n_D, (uint64_t)d->return_all_hidden + 2 * (uint64_t)(d->operand_f16 != 0),
@@ -1090,14 +1094,14 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
         key.push_back(b0); key.push_back(b1); key.push_back(b2);
     }
-    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0;
+    const bool use_graph = tune_env("DRNMF_NO_GRAPH") == nullptr && profile_frames <= 0;
     // frames per graph: the kernels advance the device-side frame counters themselves, so a
     // graph may hold several frames' worth of nodes (fewer graph launches from the host)
     // (measured at the C2 shape: 1 / 2 / 4 / 8 / 20 frames per graph -> 251.1k / 253.9k / 255.6k /
     // 256.1k / 256.3k frames/s).  The remainder T mod FPG runs on a one-frame graph.
     int fpg_max = 800 / (2 * d->K - 1);      // ~800 kernel nodes per graph
     fpg_max = fpg_max < 1 ? 1 : (fpg_max > 64 ? 64 : fpg_max);
-    if (const char* e = getenv("DRNMF_FPG")) {
+    if (const char* e = tune_env("DRNMF_FPG")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) fpg_max = v;
     }
@@ -1157,7 +1161,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
         a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
-        a.ablate = getenv("DRNMF_ABLATE_A") ? atoi(getenv("DRNMF_ABLATE_A")) : 0;
+        a.ablate = tune_env("DRNMF_ABLATE_A") ? atoi(tune_env("DRNMF_ABLATE_A")) : 0;
         a.Rsave = (W.off_rsave != 0 && k >= 1)
                       ? (float*)(ws + W.off_rsave) + (size_t)(k - 1) * d->B * d->T * W.Fp : nullptr;
         return a;
@@ -1173,7 +1177,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         b.logKS = 0;
         while ((1 << b.logKS) < W.KS) ++b.logKS;
         b.nch_ks = W.nch_ks;
-        b.ablate = getenv("DRNMF_ABLATE_B") ? atoi(getenv("DRNMF_ABLATE_B")) : 0;
+        b.ablate = tune_env("DRNMF_ABLATE_B") ? atoi(tune_env("DRNMF_ABLATE_B")) : 0;
         b.q_in = (const float*)(ws + W.off_qpart) + (size_t)(k & 1) * W.numA * MAX_TAIL * W.Bp;
         b.qsum = (float*)(ws + W.off_qsum);
         b.numA = W.numA; b.ntail = W.ntail;
@@ -1490,7 +1494,7 @@ extern "C" int32_t drnmf_cell_forward_ista(drnmf_handle_t h, const drnmf_cell_de
         return DRNMF_OK;
     };
 
-    const bool use_graph = getenv("DRNMF_NO_GRAPH") == nullptr;
+    const bool use_graph = tune_env("DRNMF_NO_GRAPH") == nullptr;
     if (!use_graph) {
         for (int t = 0; t < d->T; ++t) {
             rc = frame([&](void* f, dim3 g, unsigned blk, void** kp) {

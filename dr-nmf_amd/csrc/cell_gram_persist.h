@@ -618,31 +618,35 @@ __global__ void __launch_bounds__(64 * (NW_G + 1)) gram_persist_bwd_kernel(const
 static inline int persist_rounds(int numM) { return (numM + 7) / 8; }
 // test aid: DRNMF_PERSIST_FAULT=1 makes every barrier wait for one arrival that never comes
 static inline int persist_nwait(int numO) {
-    const char* e = getenv("DRNMF_PERSIST_FAULT");
+    const char* e = tune_env("DRNMF_PERSIST_FAULT");
     return numO + ((e && atoi(e) == 1) ? 1 : 0);
 }
 constexpr int PERSIST_MAX_K = 48;               // [K][256] floats of previous outputs in LDS
 static inline size_t persist_fwd_lds(int K, bool all_hidden) { return (size_t)(all_hidden ? K : 1) * 256 * 4; }
-static inline bool persist_shape_ok(int numM, int numO, int K) {
+static inline bool persist_shape_ok(drnmf_handle_t h, int numM, int numO, int K) {
     if (K < 2 || K > PERSIST_MAX_K || numO > PERSIST_MAX_TILES || numM > PERSIST_MAX_CHAINS) return false;
     if (persist_rounds(numM) * numO > PERSIST_MAX_TILES) return false;   // an XCD's chains fit its 32 CUs
-    if (const char* e = getenv("DRNMF_PERSIST"))
+    if (const char* e = tune_env("DRNMF_PERSIST"))
         if (atoi(e) == 0) return false;
-    static int per_cu = -1, n_cu = 0;
-    if (per_cu < 0) {
-        int a = 0, b = 0, dev = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gram_persist_kernel<4>, 64 * (NW_G + 1), persist_fwd_lds(PERSIST_MAX_K, true)) != hipSuccess) a = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gram_persist_bwd_kernel<4>, 64 * (NW_G + 1), 0) != hipSuccess) b = 0;
-        per_cu = a < b ? a : b;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            n_cu = 0;
-        (void)hipGetLastError();
-    }
     // one workgroup per CU suffices where chain m really lands on XCD m's 32 CUs (the whole MI355X as one
     // device); on a smaller partition (fewer CUs than 8 x 32) every participant of every chain must
-    // still fit the device at once
-    return per_cu >= 1 && numM * numO <= n_cu * per_cu;
+    // still fit the device at once.  Occupancy and CU count belong to the handle's device
+    // (drnmf_create -> persist_query_occupancy): handles on different devices / partitions differ.
+    return h->persist_per_cu >= 1 && numM * numO <= h->persist_n_cu * h->persist_per_cu;
+}
+// (defined once, in cell_forward.hip)
+static inline void persist_query_occupancy_impl(int device, int* per_cu, int* n_cu) {
+    int a = 0, b = 0, prev = -1;
+    *per_cu = 0;
+    *n_cu = 0;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gram_persist_kernel<4>, 64 * (NW_G + 1), persist_fwd_lds(PERSIST_MAX_K, true)) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gram_persist_bwd_kernel<4>, 64 * (NW_G + 1), 0) != hipSuccess) b = 0;
+    *per_cu = a < b ? a : b;
+    if (hipDeviceGetAttribute(n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) *n_cu = 0;
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    (void)hipGetLastError();
 }
 
 void* pick_persist_fwd(int NAC) {

@@ -357,7 +357,7 @@ static inline bool gram_wanted(const drnmf_cell_desc_t* d) {
     const int Np = pad_n(d->N), Bp = round_up(d->B, ROWS);
     // (no dependence on T: a time prefix of a batch must take the same form)
     bool want = (int64_t)(Bp / ROWS) * Np * Np <= GRAM_MAX_WORK;
-    if (const char* e = getenv("DRNMF_GRAM")) {            // tuning aid: force the choice
+    if (const char* e = tune_env("DRNMF_GRAM")) {            // tuning aid: force the choice
         if (atoi(e) == 0) want = false;
         if (atoi(e) == 1) want = true;
     }
@@ -379,6 +379,8 @@ struct Workspace {
     bool gram;
     int numO;              // output tiles of 16 atoms (= row-sum partials per row)
     size_t off_cp, off_xpad, off_q0, off_q1;
+    bool cp_full;          // the hoisted c_k of ALL T frames are resident (one product up front, one
+                           // persistent launch for the whole sequence); false: ring of two blocks
     int cp_frames;         // frames of hoisted c_k the workspace holds: 2 GRAM_TB (a ring of two blocks)
                            // or, for the shapes the persistent chains serve, all T (one product up
                            // front, one launch for the whole sequence)
@@ -410,7 +412,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         const int groups = round_up(d->B, ROWS * 2) / (ROWS * 2);
         if (groups * W.numA >= 500 && groups * W.nft_main * 2 >= 500) W.RB = 2;
     }
-    if (const char* e = getenv("DRNMF_RB")) {   // tuning aid: force the row blocking
+    if (const char* e = tune_env("DRNMF_RB")) {   // tuning aid: force the row blocking
         const int v = atoi(e);
         if (v == 1 || v == 2) W.RB = v;
     }
@@ -424,7 +426,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
         // measured at F=1025, N=8000, B=64 (once the odd-bin partials were out of cell_a's tail): one row
         // block 10.4 us per launch, two 9.6, four 10.0
         if (groups * W.numA >= 256) W.RBa = 2;
-        if (const char* e = getenv("DRNMF_RBA")) {
+        if (const char* e = tune_env("DRNMF_RBA")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || (v == 4 && !d->return_all_hidden)) W.RBa = v;
         }
@@ -441,7 +443,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     // the smallest count that gives ~192 workgroups -- each extra range is another residual partial
     // for every cell_a workgroup to read)
     while (KS < (W.RB > 1 ? 2 : 4) && tiles * KS < 192 && nchN / (KS * 2) >= 4) KS *= 2;
-    if (const char* e = getenv("DRNMF_KS")) {   // tuning aid: force the number of atom ranges
+    if (const char* e = tune_env("DRNMF_KS")) {   // tuning aid: force the number of atom ranges
         const int v = atoi(e);
         if ((v == 1 || v == 2 || v == 4 || v == 8) && (W.RB == 1 || v <= 2) && nchN / v >= 1) KS = v;
     }
@@ -469,14 +471,13 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     W.off_h16_0 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_h16_1 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_r16 = take(W.half ? (size_t)W.Bp * W.Fp * 2 : 0);
-    W.cp_frames = 2 * GRAM_TB;
-    if (W.gram && W.numO <= 32 && W.Bp / ROWS <= 16 && d->T > 2 * GRAM_TB &&
-        (size_t)d->T * d->K * W.Bp * W.Np * 4 <= ((size_t)1 << 30))
-        W.cp_frames = d->T;
-    if (const char* e = getenv("DRNMF_CP_FULL"))      // tuning aid: 0 keeps the ring of two blocks
-        if (atoi(e) == 0) W.cp_frames = 2 * GRAM_TB;
+    W.cp_full = W.gram && W.numO <= 32 && W.Bp / ROWS <= 16 && d->T > 2 * GRAM_TB &&
+                (size_t)d->T * d->K * W.Bp * W.Np * 4 <= ((size_t)1 << 30);
+    if (const char* e = tune_env("DRNMF_CP_FULL"))      // tuning aid: 0 keeps the ring of two blocks
+        if (atoi(e) == 0) W.cp_full = false;
+    W.cp_frames = W.cp_full ? d->T : 2 * GRAM_TB;
     W.off_cp = take(W.gram ? (size_t)W.cp_frames * d->K * W.Bp * W.Np * 4 : 0);
-    W.off_xpad = take(W.gram ? (size_t)d->B * (W.cp_frames == d->T ? d->T : GRAM_TB) * W.Fp * 4 : 0);
+    W.off_xpad = take(W.gram ? (size_t)d->B * (W.cp_full ? d->T : GRAM_TB) * W.Fp * 4 : 0);
     W.off_q0 = take(W.gram ? (size_t)W.Bp * W.Np * 4 : 0);
     W.off_q1 = take(W.gram ? (size_t)W.Bp * W.Np * 4 : 0);
     W.off_rsave = 0;
@@ -512,7 +513,7 @@ void* pick_b_func_rb(int nch_ks) {
         // cell_b launch against 10.4 with 8 and 9.8 with the dictionary operands up front; 16 waves
         // with every operand of every chunk requested up front: 19 us -- the per-CU miss path
         // degrades when it is flooded)
-        if (per_wave > 8 && per_wave <= 32 && !getenv("DRNMF_NO_ALLB"))
+        if (per_wave > 8 && per_wave <= 32 && !tune_env("DRNMF_NO_ALLB"))
             return (void*)&cell_b_kernel<32, 1, 8, true, QRED>;     // all dictionary operands up front
     }
     return (void*)&cell_b_kernel<8, RB, 8, HALF, QRED>;

@@ -144,12 +144,22 @@ struct drnmf_handle_s {
     hipEvent_t persist_done = nullptr;
     hipStream_t persist_stream = nullptr;
     bool persist_pending = false;
+    // occupancy of the two persistent kernels and the CU count of THIS handle's device / partition,
+    // queried at drnmf_create (params.hip); 0 = the persistent chains are never taken
+    int persist_per_cu = 0, persist_n_cu = 0;
 };
+
+// Tuning / measurement aids are read from the environment ONCE per process (at
+// the first library call that consults one) into a snapshot; drnmf_reload_env() retakes it.  A size
+// query and the call it sizes therefore see the same values even if the environment changes in
+// between.  Returns NULL when the variable was not set.
+const char* tune_env(const char* name);
 
 // cell_gram_persist.h support (params.hip)
 int32_t persist_check_flag(drnmf_handle_t h);             // DRNMF_ERR_TIMEOUT once after a chain gave up
 bool persist_admit(drnmf_handle_t h, hipStream_t stream); // false: another stream's persistent launches may still run
 void persist_mark(drnmf_handle_t h, hipStream_t stream);  // after a call's persistent launches
+void persist_query_occupancy(int device, int* per_cu, int* n_cu);   // cell_forward.hip, at drnmf_create
 
 // Bounded graph cache shared by the forward / backward / dense cells.  Evicting an entry must not
 // synchronise the device (ABI contract: calls only enqueue): the evicted executable may still be
@@ -224,7 +234,7 @@ static inline bool gram_eligible(const drnmf_cell_desc_t* d) {
     if (d->operand_f16 || d->divergence != DRNMF_DIV_ED || d->K < 2 || d->N > GRAM_MAX_N) return false;
     const int64_t Np = pad_n(d->N);
     if (Np * Np <= GRAM_MAX_WORK) return true;
-    const char* e = getenv("DRNMF_GRAM");
+    const char* e = tune_env("DRNMF_GRAM");
     return e && atoi(e) == 1;
 }
 

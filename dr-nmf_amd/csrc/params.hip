@@ -4,7 +4,43 @@
 #include "common.h"
 #include "gemm_tn.h"
 
+#include <map>
+#include <mutex>
+#include <string>
+
 char g_create_err[512] = {0};
+
+// ---- tuning-variable snapshot (common.h) ---------------------------------------------------------
+namespace {
+const char* const kTuneNames[] = {
+    "DRNMF_ABLATE", "DRNMF_ABLATE_A", "DRNMF_ABLATE_B", "DRNMF_CP_FULL", "DRNMF_DENSE_NW", "DRNMF_FPG",
+    "DRNMF_G8", "DRNMF_GRAM", "DRNMF_KS", "DRNMF_LATE", "DRNMF_NO_ALLB", "DRNMF_NO_GRAPH",
+    "DRNMF_PERSIST", "DRNMF_PERSIST_FAULT", "DRNMF_RB", "DRNMF_RBA", "DRNMF_BIG", "DRNMF_SPLIT"};
+std::mutex g_tune_mu;
+// (values are never erased or overwritten in place: a pointer handed out stays valid for the
+// process lifetime; a reload appends a new generation)
+std::vector<std::map<std::string, std::string>*> g_tune_gen;
+void tune_take_locked() {
+    auto* m = new std::map<std::string, std::string>();
+    for (const char* n : kTuneNames)
+        if (const char* v = getenv(n)) (*m)[n] = v;
+    g_tune_gen.push_back(m);
+}
+}  // namespace
+
+const char* tune_env(const char* name) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (g_tune_gen.empty()) tune_take_locked();
+    const auto& m = *g_tune_gen.back();
+    auto it = m.find(name);
+    return it == m.end() ? nullptr : it->second.c_str();
+}
+
+extern "C" int32_t drnmf_reload_env(void) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    tune_take_locked();
+    return DRNMF_OK;
+}
 
 extern "C" int32_t drnmf_version(void) { return DRNMF_VERSION; }
 
@@ -39,13 +75,50 @@ extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
     if (!h) return DRNMF_ERR_HIP;
     h->device = device;
     // (mapped + coherent: a kernel's system-scope store is seen by the host without a synchronise)
-    if (hipHostMalloc((void**)&h->persist_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess)
-        *h->persist_flag = 0u;
+    // (4 KB: the fault word in the first 64 bytes, the report ring of drnmf_host_report_ring behind it)
+    if (hipHostMalloc((void**)&h->persist_flag, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess)
+        memset(h->persist_flag, 0, 4096);
     else {
         h->persist_flag = nullptr;
         (void)hipGetLastError();
     }
+    // occupancy of the persistent chain kernels on THIS device / partition (cell_forward.hip)
+    persist_query_occupancy(device, &h->persist_per_cu, &h->persist_n_cu);
     *out = h;
+    return DRNMF_OK;
+}
+
+// drnmf_check_status: the handle's asynchronous fault word (raised by a persistent chain that gave
+// up), read AND cleared.  Meaningful after the caller has synchronised the stream of the call in
+// question: that call itself returned DRNMF_OK when it was enqueued.
+extern "C" int32_t drnmf_check_status(drnmf_handle_t h) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    return persist_check_flag(h);
+}
+
+// A small ring of 4-float slots in host-mapped, coherent memory that kernels may write (the report of
+// drnmf_adam_step_flat): the host reads a slot after waiting for an event recorded behind the kernel --
+// no device-to-host copy, no stream synchronisation.  Owned by the handle.
+extern "C" int32_t drnmf_host_report_ring(drnmf_handle_t h, float** ring_host, int32_t* slots) {
+    if (!h || !ring_host || !slots) return DRNMF_ERR_INVALID_ARG;
+    if (!h->persist_flag) DRNMF_FAIL(h, DRNMF_ERR_HIP, "host_report_ring: no host-mapped memory on this handle");
+    *ring_host = (float*)((char*)h->persist_flag + 256);
+    *slots = (4096 - 256) / 16;
+    return DRNMF_OK;
+}
+
+// Stream-ordered variant for callers that do not synchronise (the training step): a one-thread kernel
+// takes the fault word (read + clear) and ADDS 1.0f to *dst when it was raised.
+__global__ void status_take_kernel(unsigned* flag, float* dst) {
+    const unsigned v = __hip_atomic_exchange(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (v != 0u) *dst += 1.0f;
+}
+extern "C" int32_t drnmf_status_take_device(drnmf_handle_t h, float* dst_device, void* stream_) {
+    if (!h || !dst_device) return DRNMF_ERR_INVALID_ARG;
+    if (!h->persist_flag) return DRNMF_OK;       // (no fault word: the persistent chains are never taken)
+    hipLaunchKernelGGL(status_take_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, h->persist_flag,
+                       dst_device);
+    DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }
 

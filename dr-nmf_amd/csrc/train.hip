@@ -211,6 +211,59 @@ sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
     if (threadIdx.x == 0) out[blockIdx.x] = (float)s[0];
 }
 
+// One optimiser step over the FLAT gradient / moment buffers (drnmf_adam_step_flat): block b updates
+// blocks[b].count <= 1024 consecutive elements starting at flat offset blocks[b].flat_off, whose
+// parameters live at blocks[b].param (the parameter tensors stay where their owner keeps them).
+// Everything the step's scale depends on is read from DEVICE memory -- the all-reduced tail of the
+// flat buffer [sum w*mse, #frames with w != 0, #frames, fault] and the 256 partial sums of g^2 -- so
+// the host never waits for the gradients: no stream synchronisation, no copy to the host.
+//   scale  = 1 / max(count, 1)                      (loss_norm 1, 'keras204': * frames / max(count, 1))
+//   clip   : norm = sqrt(sum g^2) * scale > clipnorm  ->  scale *= clipnorm / norm
+// A non-zero fault word (a persistent chain of this step timed out on SOME rank: the word is part of
+// the all-reduced buffer) skips the update on every rank; report[1] tells the host.
+__global__ void __launch_bounds__(256)
+adam_flat_kernel(const drnmf_adam_block_t* __restrict__ blocks, const float* __restrict__ g,
+                 float* __restrict__ m, float* __restrict__ v, const float* __restrict__ scalars,
+                 const float* __restrict__ sumsq256, float lr_t, float b1, float b2, float eps,
+                 float clipnorm, int loss_norm, float reg_loss, float* __restrict__ report) {
+    __shared__ double red[256];
+    const float sse = scalars[0], cnt = fmaxf(scalars[1], 1.f), rows = scalars[2];
+    const bool fault = scalars[3] != 0.f;
+    float scale = 1.f / cnt;
+    if (loss_norm == 1) scale *= rows / cnt;
+    const float scale_loss = scale;
+    if (clipnorm > 0.f) {                              // (block-uniform)
+        red[threadIdx.x] = (double)sumsq256[threadIdx.x];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        const float norm = sqrtf((float)red[0]) * scale;
+        if (norm > clipnorm) scale *= clipnorm / norm;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && report) {
+        report[0] = sse * scale_loss + reg_loss;       // the normalised loss of the step
+        report[1] = fault ? 1.f : 0.f;
+        report[2] = scale;
+        report[3] = cnt;
+    }
+    if (fault) return;
+    const drnmf_adam_block_t bk = blocks[blockIdx.x];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = u * 256 + (int)threadIdx.x;
+        if (e >= bk.count) break;
+        const int64_t i = bk.flat_off + e;
+        const float gi = g[i] * scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        bk.param[e] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
 struct LhWs {
     size_t off_E, off_dA, off_dB, off_part, off_P, total;
     int Fp4;
@@ -360,6 +413,26 @@ extern "C" int32_t drnmf_adam_step(drnmf_handle_t h, int64_t n, float* param, co
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream_, param, grad, m, v, n, lr_t, beta1, beta2, eps,
                        grad_scale);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_adam_step_flat(drnmf_handle_t h, int64_t n_blocks,
+                                        const drnmf_adam_block_t* blocks, const float* flat_grad,
+                                        float* flat_m, float* flat_v, const float* scalars4,
+                                        const float* sumsq256, float lr_t, float beta1, float beta2,
+                                        float eps, float clipnorm, int32_t loss_norm, float reg_loss,
+                                        float* report4, void* stream_) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n_blocks <= 0 || n_blocks > 0x7fffffff || !blocks || !flat_grad || !flat_m || !flat_v || !scalars4)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat: bad argument");
+    if (clipnorm > 0.f && !sumsq256)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat: clipnorm > 0 needs the drnmf_sumsq partials");
+    if (loss_norm != 0 && loss_norm != 1)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat: loss_norm must be 0 (masked mean) or 1 (keras204)");
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream_,
+                       blocks, flat_grad, flat_m, flat_v, scalars4, sumsq256, lr_t, beta1, beta2, eps,
+                       clipnorm, (int)loss_norm, reg_loss, report4);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }

@@ -151,12 +151,13 @@ def shard(n_items, r=None, w=None):
     return lo, lo + base + (1 if r < rem else 0)
 
 
-N_SCALARS = 3        # tail of the model's flat buffer: [sum w*mse, count, rows] (layers.UnfoldedSNMFModel.N_SCALARS)
+N_SCALARS = 4        # tail of the model's flat buffer: [sum w*mse, count, rows, fault] (layers.UnfoldedSNMFModel.N_SCALARS)
 
 
 def normalised(flat, n_scalars=N_SCALARS):
     """(gradient / global count, loss) from an all-reduced flat buffer whose last `n_scalars`
-    entries START with [sum w*mse, count] (the model's buffer carries a third, the frame count)."""
+    entries START with [sum w*mse, count] (the model's buffer carries the frame count and the fault word
+    behind them)."""
     if n_scalars < 2:
         raise ValueError("the scalar tail holds at least [sum, count]")
     tail = flat[flat.numel() - n_scalars:]

@@ -24,7 +24,7 @@ import re
 import numpy as np
 import torch
 
-from . import ops
+from . import _capi, ops
 
 
 # ------------------------------------------------------------------------------------------
@@ -764,6 +764,106 @@ def _require_h5py(path):
 
 
 # ------------------------------------------------------------------------------------------
+class DeviceLoss(object):
+    """The loss of one optimiser step, still on its way from the device.
+
+    train_on_batch() only ENQUEUES work (forward, loss, BPTT, all-reduce, one fused Adam launch): the
+    step's normalisation, the global-norm clip and the update itself read their factors from device
+    memory, so the host never waits for the gradients.  The Adam kernel leaves [loss, fault, scale, count]
+    in a slot of the handle's host-mapped report ring; float(loss) waits for the event recorded behind
+    that launch and reads the slot.  Behaves like a number wherever one is needed (float(), arithmetic,
+    comparisons, formatting); a step whose persistent chain timed out raises here -- on every rank of a
+    data-parallel group at the same step, because the fault word is part of the all-reduced buffer."""
+    __slots__ = ('_event', '_slot', '_value', '_device')
+
+    def __init__(self, event, slot, device):
+        self._event, self._slot, self._value, self._device = event, slot, None, device
+
+    def ready(self):
+        return self._value is not None or self._event.query()
+
+    def _get(self):
+        if self._value is None:
+            self._event.synchronize()
+            loss, fault = float(self._slot[0]), float(self._slot[1])
+            if fault != 0.0:
+                raise _capi.DrnmfError(
+                    'train_on_batch: a persistent small-shape chain of this step timed out on at least '
+                    'one rank (DRNMF_ERR_TIMEOUT): the step was SKIPPED on every rank (weights and Adam '
+                    'state unchanged) -- rerun it, or set DRNMF_PERSIST=0')
+            self._value = loss
+        return self._value
+
+    def __float__(self):
+        return self._get()
+
+    item = __float__
+
+    def __repr__(self):
+        return repr(self._get())
+
+    def __format__(self, spec):
+        return format(self._get(), spec)
+
+    def __add__(self, o):
+        return self._get() + float(o)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._get() - float(o)
+
+    def __rsub__(self, o):
+        return float(o) - self._get()
+
+    def __mul__(self, o):
+        return self._get() * float(o)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        return self._get() / float(o)
+
+    def __lt__(self, o):
+        return self._get() < float(o)
+
+    def __le__(self, o):
+        return self._get() <= float(o)
+
+    def __gt__(self, o):
+        return self._get() > float(o)
+
+    def __ge__(self, o):
+        return self._get() >= float(o)
+
+    def __eq__(self, o):
+        return self._get() == float(o)
+
+    def __ne__(self, o):
+        return self._get() != float(o)
+
+    def __hash__(self):
+        return hash(self._get())
+
+    def __neg__(self):
+        return -self._get()
+
+    def __abs__(self):
+        return abs(self._get())
+
+    def __round__(self, n=None):
+        return round(self._get(), n)
+
+    def __rtruediv__(self, o):
+        return float(o) / self._get()
+
+    def __pow__(self, o):
+        return self._get() ** float(o)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self._get(), dtype=dtype or np.float64)
+
+
 class UnfoldedSNMFModel(object):
     """Masking -> SimpleDeepRNN -> [:r]/[r:] -> DenseNonNegW x2 -> (square) -> A/(A+B).
     Exposes the slice of keras.Model that enhance.py uses: layers, get/set_weights,
@@ -882,12 +982,15 @@ class UnfoldedSNMFModel(object):
 
     def predict_on_batch(self, x):
         xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.cell.device)
-        return self.forward(xt).cpu().numpy()
+        out = self.forward(xt).cpu().numpy()
+        ops.check_status(self.cell.device)      # (the copy synchronised: a chain that timed out raises HERE)
+        return out
 
     __call__ = forward
 
     # -- training: loss 'mse_of_masked' + Adam (enhance.py:1040-1073, 1152) -----------------
-    N_SCALARS = 3      # tail of the flat buffer: [sum w*mse, #frames with w != 0, #frames]
+    N_SCALARS = 4      # tail of the flat buffer: [sum w*mse, #frames with w != 0, #frames, fault]
+    PENDING_STEPS = 8  # optimiser steps whose reports may be outstanding before the host looks at one
 
     def compile(self, loss='mse', optimizer='adam', lr=1e-3, clipnorm=0., decay=0., beta_1=0.9,
                 beta_2=0.999, epsilon=1e-8, sample_weight_mode='temporal',
@@ -942,14 +1045,22 @@ class UnfoldedSNMFModel(object):
             self._train_items += [(k, cell._alt[k]) for k in cell._alt
                                   if k in cell.keys_trainable]
         self._train_items += [('kernel_clean', self.clean.kernel), ('kernel_noise', self.noise.kernel)]
-        self._opt_state = {n: (torch.zeros_like(t), torch.zeros_like(t))
-                           for n, t in self._train_items}
         total = sum(int(t.numel()) for _, t in self._train_items)
         self._flat = torch.zeros(total + self.N_SCALARS, dtype=torch.float32, device=cell.device)
-        self._gview, o = {}, 0
+        # Adam moments as flat buffers parallel to the gradient (ONE fused launch per step,
+        # ops.adam_step_flat); _opt_state keeps per-weight views of them
+        self._mflat = torch.zeros(total, dtype=torch.float32, device=cell.device)
+        self._vflat = torch.zeros(total, dtype=torch.float32, device=cell.device)
+        self._gview, self._opt_state, o = {}, {}, 0
         for n, t in self._train_items:
             self._gview[n] = self._flat[o:o + t.numel()].view(t.shape)
+            self._opt_state[n] = (self._mflat[o:o + t.numel()].view(t.shape),
+                                  self._vflat[o:o + t.numel()].view(t.shape))
             o += t.numel()
+        self._adam_table = None          # (table, n_blocks, storage pointers it was built for)
+        self._sumsq = torch.zeros(256, dtype=torch.float32, device=cell.device)
+        self._pending = []               # DeviceLoss of recent steps, oldest first
+        self._step_no = 0
         self.sync_replicas()
         return self
 
@@ -1019,7 +1130,11 @@ class UnfoldedSNMFModel(object):
         # loss_norm='keras204', which must be the GLOBAL batch's, not inflated by the replay)
         ns = self.N_SCALARS
         self._flat[-ns:-ns + 2].copy_(sums)
-        self._flat[-1] = float(x.shape[0] * x.shape[1]) if live else 0.0
+        self._flat[-2] = float(x.shape[0] * x.shape[1]) if live else 0.0
+        # fault word: 1.0 if a persistent chain of THIS step's forward / BPTT gave up (stream-ordered
+        # read-and-clear of the handle's flag; all-reduced with the gradients, so that every rank skips
+        # the update and reports the step -- ADVICE r3)
+        ops.status_take(self._flat[-1:])
 
     @staticmethod
     def _reg_coeffs(reg):
@@ -1062,30 +1177,49 @@ class UnfoldedSNMFModel(object):
             tot += l1 * float(p.abs().sum()) + l2 * float((p * p).sum())
         return tot
 
+    def _adam_blocks(self):
+        """Block table of the fused Adam launch, rebuilt if a weight tensor has been re-bound."""
+        ptrs = tuple(int(t.data_ptr()) for _, t in self._train_items)
+        if self._adam_table is None or self._adam_table[2] != ptrs:
+            table, nb = ops.adam_block_table(self._train_items, self.cell.device)
+            self._adam_table = (table, nb, ptrs)
+        return self._adam_table[0], self._adam_table[1]
+
     def apply_gradients(self, flat):
-        """Adam step from the (already all-reduced) flat buffer; returns the normalised loss."""
+        """Adam step from the (already all-reduced) flat buffer [gradients..., sum w*mse, count, frames,
+        fault]: ONE launch (csrc/train.hip adam_flat_kernel) that derives 1/count, the keras204 factor and
+        the clip scale from device memory and skips the update if the fault word is set.  Nothing here
+        waits for the device; returns the normalised loss as a DeviceLoss (float() it to wait)."""
         o = self.opt
         ns = self.N_SCALARS
-        sse, cnt, rows = (float(v) for v in flat[-ns:].tolist())
-        scale = 1.0 / max(cnt, 1.0)
-        if getattr(self, 'loss_norm', 'masked_mean') == 'keras204':
-            # weighted_masked_objective with a propagated mask: one more division by
-            # p = mean(mask) = count / frames (global numbers under data parallelism)
-            scale *= rows / max(cnt, 1.0)
-        reg_loss = self._add_regularizers(scale)     # (before the clip: Keras clips the total gradient)
-        if o['clipnorm'] > 0:                       # global-norm clip [K2.0.4-memory]
-            norm = float(np.sqrt(ops.sumsq(flat[:-ns]))) * scale
-            if norm > o['clipnorm']:
-                scale *= o['clipnorm'] / norm
+        keras204 = getattr(self, 'loss_norm', 'masked_mean') == 'keras204'
+        reg_loss = 0.0
+        if self._regularized_items():
+            # free-weight configurations with W_/U_/b_regularizer only (never build_alt's): the penalty's
+            # gradient enters scaled by the step's data-gradient scale, which the host must then know
+            sse, cnt, rows = (float(v) for v in flat[-ns:-1].tolist())
+            scale = 1.0 / max(cnt, 1.0)
+            if keras204:
+                scale *= rows / max(cnt, 1.0)
+            reg_loss = self._add_regularizers(scale)     # (before the clip: Keras clips the total gradient)
+        if o['clipnorm'] > 0:                           # global-norm clip [K2.0.4-memory]
+            ops.sumsq_partials(flat[:-ns], out=self._sumsq)
         lr = o['lr']
         if o['decay'] > 0:
             lr *= 1.0 / (1.0 + o['decay'] * o['iterations'])
         t = o['iterations'] + 1
         lr_t = lr * np.sqrt(1.0 - o['b2'] ** t) / (1.0 - o['b1'] ** t)
-        for n, p in self._train_items:
-            m, v = self._opt_state[n]
-            ops.adam_step(p, self._gview[n].contiguous(), m, v, lr_t, o['b1'], o['b2'], o['eps'],
-                          grad_scale=scale)
+        table, nb = self._adam_blocks()
+        ring, base = ops.host_report_ring(self.cell.device)
+        slot = self._step_no % ring.shape[0]
+        self._step_no += 1
+        ops.adam_step_flat(table, nb, flat, self._mflat, self._vflat, flat[-ns:], lr_t, o['b1'], o['b2'],
+                           o['eps'], clipnorm=o['clipnorm'], keras204=keras204, reg_loss=reg_loss,
+                           sumsq256=self._sumsq if o['clipnorm'] > 0 else None,
+                           report=base + 16 * slot)
+        ev = torch.cuda.Event()
+        ev.record()
+        loss = DeviceLoss(ev, ring[slot], self.cell.device)
         o['iterations'] = t
         # the prepared parameter block is stale; the (u0_diag, u0_off, uk_off) scalars are derived
         # from log_U1 / log_Uk, which compile() refuses to train: re-deriving them here would cost
@@ -1096,12 +1230,22 @@ class UnfoldedSNMFModel(object):
             # round trip to re-examine U's structure after every step)
             self.cell._dense_now = True
             self.cell._dense_block_valid = False
-        return sse * scale + reg_loss
+        # Reports are consumed at most PENDING_STEPS late: a fault is then raised from THIS call (the
+        # wait is for a step that finished long ago; it never drains the queue), and a ring slot is
+        # never reused before it was read.
+        self._pending.append(loss)
+        while len(self._pending) > self.PENDING_STEPS:
+            self._pending.pop(0)._get()
+        while self._pending and self._pending[0].ready():
+            self._pending.pop(0)._get()
+        return loss
 
     def train_on_batch(self, x, y, sample_weight=None, _live=True):
         """One optimiser step.  x, y: (B,T,F); sample_weight: (B,T) (the data mask,
-        enhance.py:1148-1152).  Under torch.distributed the flat gradient + (sum, count) are
-        all-reduced (RCCL) before the update, so every rank applies the same step."""
+        enhance.py:1148-1152).  Under torch.distributed the flat gradient + (sum, count, frames, fault)
+        are all-reduced (RCCL) before the update, so every rank applies the same step.  Returns the
+        loss as a DeviceLoss: the call enqueues the step and returns without waiting for it (float()
+        the result, as Keras' train_on_batch would have, to wait)."""
         from . import dp
         dev = self.cell.device
         tt = lambda a: a if isinstance(a, torch.Tensor) else \
@@ -1121,11 +1265,16 @@ class UnfoldedSNMFModel(object):
         x, y = tt(x), tt(y)
         w = tt(sample_weight) if sample_weight is not None else \
             torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
-        s3 = torch.empty(3, dtype=torch.float32, device=dev)
+        s3 = torch.empty(4, dtype=torch.float32, device=dev)
         s3[:2].copy_(ops.loss_forward(y, w, x_raw=x, mask=self.forward(x)))
         s3[2] = float(x.shape[0] * x.shape[1])
+        s3[3] = 0.0
+        ops.status_take(s3[3:])                 # fault word of this forward, all-reduced with the sums
         dp.allreduce_sum_(s3)
-        sse, cnt, rows = s3.tolist()
+        sse, cnt, rows, fault = s3.tolist()
+        if fault != 0.0:
+            raise _capi.DrnmfError('test_on_batch: a persistent small-shape chain timed out on at least '
+                                   'one rank (DRNMF_ERR_TIMEOUT); rerun, or set DRNMF_PERSIST=0')
         scale = 1.0 / max(cnt, 1.0)
         if getattr(self, 'loss_norm', 'masked_mean') == 'keras204':
             scale *= rows / max(cnt, 1.0)
@@ -1146,15 +1295,41 @@ class UnfoldedSNMFModel(object):
         Keras does."""
         from . import dp
         dev = self.cell.device
-        arrs = [a for a in (x, y, sample_weight) if isinstance(a, np.ndarray)]
-        if arrs and sum(a.nbytes for a in arrs) <= resident_bytes:
-            up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev) \
-                if isinstance(a, np.ndarray) else a
-            x, y, sample_weight = up(x), up(y), up(sample_weight)
-        if validation_data is not None and all(isinstance(a, np.ndarray) for a in validation_data) \
-                and sum(a.nbytes for a in validation_data) <= resident_bytes:
-            validation_data = tuple(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
-                                    for a in validation_data)
+        # what may stay resident: at most `resident_bytes` and at most half of the device memory that is
+        # free right now (ADVICE r3: workspaces, other tenants of the GPU); a failed upload falls back to
+        # per-batch copies
+        try:
+            free_now = int(torch.cuda.mem_get_info(dev)[0])
+        except Exception:
+            free_now = 0
+        budget = min(int(resident_bytes), free_now // 2)
+
+        def upload(arrays):
+            """Device copies of the numpy members of `arrays` (one copy per distinct array: the
+            pretraining model passes y = x) if they fit the budget, else None."""
+            nonlocal budget
+            uniq = {}
+            for a in arrays:
+                if isinstance(a, np.ndarray):
+                    uniq.setdefault(id(a), a)
+            need = sum(a.size * 4 for a in uniq.values())
+            if not uniq or need > budget:
+                return None
+            try:
+                dev_of = {k: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+                          for k, a in uniq.items()}
+            except torch.cuda.OutOfMemoryError:
+                torch.cuda.empty_cache()
+                return None
+            budget -= need
+            return [dev_of[id(a)] if isinstance(a, np.ndarray) else a for a in arrays]
+        up = upload([x, y, sample_weight])
+        if up is not None:
+            x, y, sample_weight = up
+        if validation_data is not None:
+            up = upload(list(validation_data))
+            if up is not None:
+                validation_data = tuple(up)
         take = lambda a, b: a.index_select(0, torch.as_tensor(b, dtype=torch.long, device=a.device)) \
             if isinstance(a, torch.Tensor) else a[b]
         n = x.shape[0]
@@ -1173,6 +1348,9 @@ class UnfoldedSNMFModel(object):
                 cb.model = self
             if hasattr(cb, 'on_train_begin'):
                 cb.on_train_begin({})
+        # a callback that looks at every batch's loss needs the number: the step then waits for it, as
+        # Keras does; without one the losses of an epoch are read when the epoch ends
+        per_batch_cbs = [cb for cb in callbacks if hasattr(cb, 'on_batch_end')]
         # every train_on_batch is a collective: all ranks must take the same number of steps even
         # when their shards differ in size (dp.shard hands the remainder to the first ranks)
         steps = dp.max_over_ranks(epoch_steps(n, batch_size))
@@ -1186,7 +1364,7 @@ class UnfoldedSNMFModel(object):
                 if hasattr(cb, 'on_epoch_begin'):
                     cb.on_epoch_begin(ep, {})
             idx = rng.permutation(n) if shuffle else np.arange(n)
-            tot, cnt = 0.0, 0
+            ep_losses, cnt = [], 0
             for b, live in epoch_batches(idx, batch_size, steps):
                 sw = None if sample_weight is None else take(sample_weight, b)
                 if not live:
@@ -1194,16 +1372,14 @@ class UnfoldedSNMFModel(object):
                     # (zero gradient, zero count) on a batch it has already used
                     sw = np.zeros((len(b), x.shape[1]), np.float32)
                 loss = self.train_on_batch(take(x, b), take(y, b), sw, _live=live)
-                tot += loss
-                for cb in callbacks:
-                    if hasattr(cb, 'on_batch_end'):
-                        cb.on_batch_end(cnt, {'batch': cnt, 'size': len(b), 'loss': loss})
+                ep_losses.append(loss)
+                for cb in per_batch_cbs:
+                    cb.on_batch_end(cnt, {'batch': cnt, 'size': len(b), 'loss': float(loss)})
                 cnt += 1
-            logs = {'loss': tot / max(cnt, 1)}
+            logs = {'loss': sum(float(l) for l in ep_losses) / max(cnt, 1)}
             hist['loss'].append(logs['loss'])
             if validation_data is not None:
-                xv, yv, wv = validation_data
-                logs['val_loss'] = self.test_on_batch(xv, yv, wv)
+                logs['val_loss'] = self._validate(validation_data, batch_size, take)
                 hist['val_loss'].append(logs['val_loss'])
             if verbose and dp.rank() == 0:
                 print('epoch %d loss %.6f%s' % (ep + 1, logs['loss'],
@@ -1217,6 +1393,42 @@ class UnfoldedSNMFModel(object):
             if hasattr(cb, 'on_train_end'):
                 cb.on_train_end({})
         return hist
+
+    def _validation_sums(self, x, y, w):
+        """[sum w*loss, #frames with w != 0] of one validation batch as a device tensor of 2 floats."""
+        return ops.loss_forward(y, w, x_raw=x, mask=self.forward(x))
+
+    def _validate(self, validation_data, batch_size, take):
+        """Validation loss of fit(), evaluated in mini-batches of `batch_size` sequences as Keras'
+        test loop does (enhance.py:1152-1157: model.fit(..., validation_data=...)); the reference's
+        2 460-utterance CHiME2 validation set at N = 2000 would otherwise need a ~40 GB hidden tensor.
+        The sums [sum w*loss, count, frames, fault] are accumulated on the device over the batches and
+        all-reduced ONCE (every rank holds its shard), so the value is the loss of the whole set."""
+        from . import dp
+        dev = self.cell.device
+        tt = lambda a: a if isinstance(a, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        xv, yv = validation_data[0], validation_data[1]
+        wv = validation_data[2] if len(validation_data) > 2 else None
+        nv = xv.shape[0]
+        s4 = torch.zeros(4, dtype=torch.float32, device=dev)
+        for lo in range(0, nv, int(batch_size)):
+            b = np.arange(lo, min(nv, lo + int(batch_size)))
+            xb, yb = tt(take(xv, b)), tt(take(yv, b))
+            wb = tt(take(wv, b)) if wv is not None else \
+                torch.ones(xb.shape[:2], dtype=torch.float32, device=dev)
+            s4[:2].add_(self._validation_sums(xb, yb, wb))
+            s4[2] += float(xb.shape[0] * xb.shape[1])
+        ops.status_take(s4[3:])
+        dp.allreduce_sum_(s4)
+        sse, cnt, rows, fault = s4.tolist()
+        if fault != 0.0:
+            raise _capi.DrnmfError('fit(): a persistent small-shape chain timed out during validation on '
+                                   'at least one rank (DRNMF_ERR_TIMEOUT); rerun, or set DRNMF_PERSIST=0')
+        scale = 1.0 / max(cnt, 1.0)
+        if getattr(self, 'loss_norm', 'masked_mean') == 'keras204':
+            scale *= rows / max(cnt, 1.0)
+        return sse * scale + (self._regularization_loss() if hasattr(self, '_train_items') else 0.0)
 
 
 def epoch_steps(n_local, batch_size):
@@ -1324,11 +1536,20 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
         y = x if y is None else tt(self._first(y))
         sw = self._first(sample_weight)
         w = tt(sw) if sw is not None else torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
+        s3 = torch.zeros(3, dtype=torch.float32, device=dev)
+        s3[:2].copy_(self._validation_sums(x, y, w))
+        ops.status_take(s3[2:])
+        dp.allreduce_sum_(s3)
+        sse, cnt, fault = s3.tolist()
+        if fault != 0.0:
+            raise _capi.DrnmfError('test_on_batch: a persistent small-shape chain timed out on at least '
+                                   'one rank (DRNMF_ERR_TIMEOUT); rerun, or set DRNMF_PERSIST=0')
+        return sse / max(cnt, 1.0)
+
+    def _validation_sums(self, x, y, w):
         h = self.cell.call(x, mask_value=self.mask_value)
         _, A, Bn = ops.head_forward(h, self.clean.kernel, self.noise.kernel, want_ab=True)
-        s = ops.loss_forward(y, w, A=A, Bn=Bn, hidden=h, l1_weight=self.loss_weights[1])
-        dp.allreduce_sum_(s)
-        return float(s[0]) / max(float(s[1]), 1.0)
+        return ops.loss_forward(y, w, A=A, Bn=Bn, hidden=h, l1_weight=self.loss_weights[1])
 
     def fit(self, x, y=None, sample_weight=None, validation_data=None, **kw):
         y = x if y is None else self._first(y)

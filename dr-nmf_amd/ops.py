@@ -489,6 +489,96 @@ def sumsq(g):
     return float(out.cpu().numpy().astype(np.float64).sum())     # 256 partials, summed on the host
 
 
+def sumsq_partials(g, out=None):
+    """256 partial sums of g^2 left ON THE DEVICE (the global-norm clip of adam_step_flat reads them)."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(g))
+    if out is None:
+        out = torch.empty(256, dtype=torch.float32, device=g.device)
+    rc = L.drnmf_sumsq(h, g.numel(), _capi.ptr(_f32c(g, "g")), _capi.ptr(out), _stream())
+    _capi.check(rc, h, "drnmf_sumsq")
+    return out
+
+
+ADAM_BLOCK = 1024          # elements per drnmf_adam_block_t entry
+
+
+def adam_block_table(items, device):
+    """Device table of drnmf_adam_block_t {float* param; int64 flat_off; int32 count; int32 reserved}
+    for drnmf_adam_step_flat: `items` = [(name, tensor)] in flat-buffer order; the tensors must stay
+    where they are (same storage) for as long as the table is used.  Returns (table, n_blocks)."""
+    rows = []
+    off = 0
+    for _, t in items:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("adam_block_table needs contiguous float32 tensors")
+        n, base = int(t.numel()), int(t.data_ptr())
+        for e in range(0, n, ADAM_BLOCK):
+            rows.append((base + 4 * e, off + e, min(ADAM_BLOCK, n - e), 0))
+        off += n
+    arr = np.zeros(len(rows), dtype=np.dtype([('param', '<u8'), ('flat_off', '<i8'),
+                                              ('count', '<i4'), ('reserved', '<i4')]))
+    for i, r in enumerate(rows):
+        arr[i] = r
+    table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+    return table, len(rows)
+
+
+def adam_step_flat(table, n_blocks, flat_grad, flat_m, flat_v, scalars4, lr_t, beta1=0.9, beta2=0.999,
+                   eps=1e-8, clipnorm=0.0, keras204=False, reg_loss=0.0, sumsq256=None, report=None):
+    """ONE launch for the whole optimiser step; scale, clip and the fault guard are evaluated on the
+    device from `scalars4` = [sum w*mse, count, frames, fault] (see include/drnmf.h).  `report`: 4 floats
+    of device-accessible memory (e.g. a pinned host tensor) that receive [loss, fault, scale, count]."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(flat_grad))
+    rc = L.drnmf_adam_step_flat(h, int(n_blocks), _capi.ptr(table), _capi.ptr(flat_grad),
+                                _capi.ptr(flat_m), _capi.ptr(flat_v), _capi.ptr(scalars4),
+                                _capi.ptr(sumsq256), float(lr_t), float(beta1), float(beta2),
+                                float(eps), float(clipnorm), 1 if keras204 else 0, float(reg_loss),
+                                report if isinstance(report, int) else _capi.ptr(report), _stream())
+    _capi.check(rc, h, "drnmf_adam_step_flat")
+
+
+_report_rings = {}
+
+
+def host_report_ring(device):
+    """(numpy view [slots, 4] of the handle's host-mapped report ring, its base address) -- a slot's
+    address is a valid `report` argument of adam_step_flat."""
+    dev = device if isinstance(device, int) else _dev_index(device)
+    if dev not in _report_rings:
+        L = _capi.lib()
+        h = _capi.handle(dev)
+        p = C.POINTER(C.c_float)()
+        n = C.c_int32(0)
+        _capi.check(L.drnmf_host_report_ring(h, C.byref(p), C.byref(n)), h, "drnmf_host_report_ring")
+        arr = np.ctypeslib.as_array(p, shape=(int(n.value), 4))
+        _report_rings[dev] = (arr, C.addressof(p.contents))
+    return _report_rings[dev]
+
+
+def check_status(device):
+    """Raise if an EARLIER, already synchronised call on this device's handle suffered an asynchronous
+    fault (a persistent chain that timed out: its output is invalid).  Reads and clears the flag."""
+    L = _capi.lib()
+    dev = device if isinstance(device, int) else _dev_index(device)
+    h = _capi.handle(dev)
+    _capi.check(L.drnmf_check_status(h), h, "drnmf_check_status")
+
+
+def status_take(dst):
+    """Stream-ordered: adds 1.0 to the one-element device tensor `dst` if the handle's fault word is
+    raised, and clears it (no synchronisation)."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(dst))
+    _capi.check(L.drnmf_status_take_device(h, _capi.ptr(dst), _stream()), h, "drnmf_status_take_device")
+
+
+def reload_env():
+    """libdrnmf reads its DRNMF_* tuning variables once per process; call this after changing one."""
+    _capi.lib().drnmf_reload_env()
+
+
 def divide_a_by_aplusb(A, B):
     """exp(log(1e-7+A) - log(1e-7+A+B)) (custom_layers.py:41-45), elementwise."""
     L = _capi.lib()

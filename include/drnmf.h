@@ -38,7 +38,9 @@ enum {
     DRNMF_ERR_RCCL = -5,
     DRNMF_ERR_TIMEOUT = -6  /* a persistent small-shape launch of an EARLIER call on this handle gave up
                              * waiting for its own workgroups (they were not resident together); that
-                             * call's output is invalid.  Reported by the next cell call on the handle. */
+                             * call's output is invalid.  Reported by drnmf_check_status (after the
+                             * caller has synchronised), by drnmf_status_take_device (stream-ordered,
+                             * no synchronisation) or, failing both, by the next cell call on the handle. */
 };
 
 /* divergence selector for the frame-parallel ISTA / MU kernels */
@@ -74,6 +76,28 @@ int32_t drnmf_version(void);
 int32_t drnmf_create(drnmf_handle_t* out, int32_t device);
 int32_t drnmf_destroy(drnmf_handle_t h);
 const char* drnmf_last_error(drnmf_handle_t h); /* h may be NULL: last create() error */
+
+/* Asynchronous faults.  Every call only ENQUEUES work, so a fault that happens on the device (today: a
+ * persistent small-shape chain that gave up waiting for its own workgroups, DRNMF_ERR_TIMEOUT) cannot
+ * be the return value of the call that suffered it.  The handle keeps one fault word:
+ *   drnmf_check_status        host side: reads AND clears it; DRNMF_ERR_TIMEOUT if it was raised.  Call
+ *                             it after synchronising the stream (e.g. right after copying a result to
+ *                             the host) -- the reference's counterpart is the Python exception Theano
+ *                             raises out of predict_on_batch / train_on_batch (enhance.py:1152, 1189).
+ *   drnmf_status_take_device  stream-ordered: a one-thread kernel reads and clears the word and adds
+ *                             1.0f to *dst_device if it was raised.  The training step puts dst inside
+ *                             the flat buffer it all-reduces, so that EVERY rank skips the update
+ *                             (drnmf_adam_step_flat) and learns of the fault at the same step. */
+int32_t drnmf_check_status(drnmf_handle_t h);
+int32_t drnmf_status_take_device(drnmf_handle_t h, float* dst_device, void* stream);
+/* A ring of `*slots` 4-float slots in host-mapped, coherent memory owned by the handle: a valid
+ * DEVICE pointer for the `report4` argument of drnmf_adam_step_flat and readable by the host once an
+ * event recorded behind that launch has completed (no copy, no stream synchronisation). */
+int32_t drnmf_host_report_ring(drnmf_handle_t h, float** ring_host, int32_t* slots);
+
+/* Tuning / measurement variables (DRNMF_*) are read from the environment once
+ * per process; drnmf_reload_env retakes the snapshot (tests that flip a variable between calls). */
+int32_t drnmf_reload_env(void);
 
 /* ---- parameter maps: replaces build_alt's maps_from_alt lambdas (enhance.py:161-204) and their
  * evaluation in SimpleDeepRNN.build (custom_layers.py:234-287).
@@ -318,6 +342,33 @@ int32_t drnmf_adam_step(drnmf_handle_t h, int64_t n, float* param, const float* 
                         float* v, float lr_t, float beta1, float beta2, float eps, float grad_scale,
                         void* stream);
 int32_t drnmf_sumsq(drnmf_handle_t h, int64_t n, const float* g, float* out256, void* stream);
+
+/* The same update as ONE launch over the flat gradient buffer of a training step, with every
+ * data-dependent factor read from device memory (no host round trip between the gradient all-reduce and
+ * the update; replaces the host-side `sse, cnt, rows = flat[-3:].tolist()` + one drnmf_adam_step per
+ * tensor).  Reference: keras.optimizers.Adam.get_updates under model.train_on_batch
+ * (enhance.py:1052-1057, 1152) [K2.0.4-memory].
+ *   blocks    device array of n_blocks entries (caller-built, caller-owned): entry b covers
+ *             count <= 1024 consecutive elements of the flat buffers from flat_off on; their
+ *             parameters are param[0 .. count)
+ *   scalars4  device: [sum w*mse, #frames with w != 0, #frames, fault] -- the all-reduced tail of the
+ *             flat buffer; fault != 0 (drnmf_status_take_device on some rank) skips the update
+ *   sumsq256  drnmf_sumsq partials of flat_grad (required when clipnorm > 0, else may be NULL)
+ *   loss_norm 0: scale = 1/max(count,1); 1 ('keras204'): * frames/max(count,1)
+ *   reg_loss  host-computed penalty added to the reported loss (0 for build_alt's configuration)
+ *   report4   device-accessible (may be mapped host memory) or NULL: [normalised loss, fault (0/1),
+ *             applied gradient scale, max(count, 1)] */
+typedef struct drnmf_adam_block {
+    float* param;
+    int64_t flat_off;
+    int32_t count;
+    int32_t reserved;
+} drnmf_adam_block_t;
+int32_t drnmf_adam_step_flat(drnmf_handle_t h, int64_t n_blocks, const drnmf_adam_block_t* blocks,
+                             const float* flat_grad, float* flat_m, float* flat_v,
+                             const float* scalars4, const float* sumsq256, float lr_t, float beta1,
+                             float beta2, float eps, float clipnorm, int32_t loss_norm,
+                             float reg_loss, float* report4, void* stream);
 
 /* ---- data-parallel training: ONE all-reduce(sum) per optimiser step over the flat fp32 buffer
  * [gradients..., sum w*mse, count, rows] and one broadcast that makes the replicas' weights

@@ -12,6 +12,42 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _reload_drnmf_env():
+    """libdrnmf reads its DRNMF_* tuning variables ONCE per process (drnmf_reload_env retakes the
+    snapshot): a test that flips one must tell the library -- only if it is loaded already."""
+    try:
+        from drnmf_amd import _capi
+    except Exception:
+        return
+    if _capi._lib is not None:
+        _capi._lib.drnmf_reload_env()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, with setenv / delenv of a DRNMF_* variable followed by drnmf_reload_env."""
+    orig_set, orig_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        orig_set(name, value, *a, **k)
+        if name.startswith("DRNMF_"):
+            _reload_drnmf_env()
+
+    def delenv(name, *a, **k):
+        orig_del(name, *a, **k)
+        if name.startswith("DRNMF_"):
+            _reload_drnmf_env()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield monkeypatch
+
+
+@pytest.fixture(autouse=True)
+def _drnmf_env_snapshot():
+    """Set up first / torn down last: whatever a test's monkeypatch changed has been undone by then."""
+    yield
+    _reload_drnmf_env()
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
@@ -22,7 +58,7 @@ def golden():
 def cell_form(request, monkeypatch):
     """The recurrent cell has two forms (csrc/cell_gram.h): the factored pair of contractions and,
     for small dictionaries, the Gram form.  'auto' leaves the library's rule in charge; 'factored'
-    forces the factored kernels (DRNMF_GRAM=0, read by libdrnmf at every call) so that the small
+    forces the factored kernels (DRNMF_GRAM=0; the monkeypatch fixture above makes libdrnmf re-read it) so that the small
     parity shapes keep exercising them too."""
     if request.param == "factored":
         monkeypatch.setenv("DRNMF_GRAM", "0")

@@ -63,12 +63,12 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_normalised_reads_the_models_three_scalar_tail():
-    # the model's flat buffer ends in [sum w*mse, count, rows] (layers.UnfoldedSNMFModel.N_SCALARS = 3):
-    # the default must index the tail from its START (rows is not the count)
+def test_normalised_reads_the_models_scalar_tail():
+    # the model's flat buffer ends in [sum w*mse, count, rows, fault] (layers.UnfoldedSNMFModel.N_SCALARS
+    # = 4): the default must index the tail from its START (rows is not the count)
     from drnmf_amd import dp, layers
-    assert dp.N_SCALARS == layers.UnfoldedSNMFModel.N_SCALARS == 3
-    flat = torch.tensor([2.0, 4.0, 6.0, 10.0, 4.0, 64.0], dtype=torch.float64)
+    assert dp.N_SCALARS == layers.UnfoldedSNMFModel.N_SCALARS == 4
+    flat = torch.tensor([2.0, 4.0, 6.0, 10.0, 4.0, 64.0, 0.0], dtype=torch.float64)
     g, loss = dp.normalised(flat)
     np.testing.assert_allclose(g.numpy(), [0.5, 1.0, 1.5])
     assert loss == 2.5

@@ -186,8 +186,9 @@ def test_gram_and_factored_forms_agree(dev, monkeypatch):
     f1, h1, m1 = res["1"]
     assert np.max(np.abs(h0 - h1)) <= 2e-5 * np.max(np.abs(h0))
     assert np.mean((m0 - m1) ** 2) <= 1e-12
-    assert f0[-2] == f1[-2] and abs(f0[-3] - f1[-3]) <= 1e-5 * abs(f0[-3])
-    g0, g1 = f0[:-3], f1[:-3]
+    assert f0[-1] == f1[-1] == 0.0                                  # fault word
+    assert f0[-3] == f1[-3] and f0[-2] == f1[-2] and abs(f0[-4] - f1[-4]) <= 1e-5 * abs(f0[-4])
+    g0, g1 = f0[:-4], f1[:-4]
     assert np.max(np.abs(g0 - g1)) <= 2e-4 * np.max(np.abs(g0))
 
 
@@ -265,7 +266,7 @@ def test_persistent_gram_bptt_is_bit_identical(dev, monkeypatch, cfg):
         model = layers.build_unfolded_snmf(p, device=dev)
         model.compile(lr=1e-3)
         res[mode] = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(w)).cpu().numpy().copy()
-    assert np.isfinite(res["1"]).all() and np.abs(res["1"][:-3]).max() > 0
+    assert np.isfinite(res["1"]).all() and np.abs(res["1"][:-4]).max() > 0
     assert np.array_equal(res["0"], res["1"])
 
 

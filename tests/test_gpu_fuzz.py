@@ -70,7 +70,7 @@ def test_fuzz_gradients(dev):
         model.compile(lr=1e-3)
         flat = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(wmask)).clone()
         ref_loss, ref, cnt = TT._autograd(model, P, wmask, K, cfg["square"])
-        assert abs(float(flat[-3]) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-9, cfg
+        assert abs(float(flat[-4]) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-9, cfg
         nm = {"kernel_clean": "kc", "kernel_noise": "kn"}
         for name, _ in model._train_items:
             g, r_ = model._gview[name].cpu().numpy(), ref[nm.get(name, name)]

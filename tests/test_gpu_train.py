@@ -93,8 +93,8 @@ def test_gradients_match_autograd(dev, cfg):
     torch.cuda.synchronize()
     ref_loss, ref, cnt = _autograd(model, P, wmask, K, square)
     big = cfg["B"] * cfg["r"] >= 100000
-    assert abs(float(flat[-3]) - ref_loss) <= (5e-5 if big else 1e-5) * abs(ref_loss) + 1e-9
-    assert float(flat[-2]) == cnt
+    assert abs(float(flat[-4]) - ref_loss) <= (5e-5 if big else 1e-5) * abs(ref_loss) + 1e-9
+    assert float(flat[-3]) == cnt
     name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
     checked = 0
     for n, _ in model._train_items:
@@ -141,8 +141,8 @@ def test_long_sequence_gradients_match_autograd(dev, cfg):
     flat = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(wmask)).clone()
     torch.cuda.synchronize()
     ref_loss, ref, cnt = _autograd(model, P, wmask, K, False)
-    assert abs(float(flat[-3]) - ref_loss) <= 2e-5 * abs(ref_loss) + 1e-9
-    assert float(flat[-2]) == cnt
+    assert abs(float(flat[-4]) - ref_loss) <= 2e-5 * abs(ref_loss) + 1e-9
+    assert float(flat[-3]) == cnt
     name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
     checked = 0
     for n, _ in model._train_items:
@@ -182,8 +182,8 @@ def test_kl_beta_cell_gradients_match_autograd(dev, cfg):
     torch.cuda.synchronize()
     ref_loss, ref, cnt = _autograd(model, P, wmask, K, False, divergence=div, beta=beta)
     assert np.isfinite(ref_loss)
-    assert abs(float(flat[-3]) - ref_loss) <= 2e-5 * abs(ref_loss) + 1e-9
-    assert float(flat[-2]) == cnt
+    assert abs(float(flat[-4]) - ref_loss) <= 2e-5 * abs(ref_loss) + 1e-9
+    assert float(flat[-3]) == cnt
     name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
     checked = 0
     for n, _ in model._train_items:
@@ -246,8 +246,8 @@ def test_snmf_cost_pretraining_gradients_and_fit(dev, cfg):
     flat = pre.loss_and_grads(t(P["X"]), t(P["X"]), t(wmask)).clone()
     torch.cuda.synchronize()
     ref_loss, ref, cnt = _autograd(model, P, wmask, K, False, snmf_cost_l1_weight=lam1 * N / F)
-    assert abs(float(flat[-3]) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-9
-    assert float(flat[-2]) == cnt
+    assert abs(float(flat[-4]) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-9
+    assert float(flat[-3]) == cnt
     name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
     for n, _ in pre._train_items:
         g = pre._gview[n].cpu().numpy()
@@ -327,7 +327,7 @@ def test_full_size_training_step_properties(dev):
     f1 = model.loss_and_grads(x, y, w).clone()
     f2 = model.loss_and_grads(x, y, w).clone()
     assert torch.equal(f1, f2)
-    assert bool(torch.isfinite(f1).all()) and float(f1[-2]) == float(w.sum())
+    assert bool(torch.isfinite(f1).all()) and float(f1[-3]) == float(w.sum())
 
     # linearity of the BPTT in d_out
     cell = model.cell
@@ -350,7 +350,7 @@ def test_full_size_training_step_properties(dev):
     model.loss_and_grads(x, y, w)
     gD = {n: model._gview[n].clone() for n in names}
     gnorm = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in gD.values())))
-    L0 = float(f1[-3])
+    L0 = float(f1[-4])
     # (measured at this shape: steps of 5e-3 / 1.2e-3 / 3e-4 / 8e-5 of the loss give 0.4601 /
     # 0.4822 / 0.4836 / 0.4838 against |g|^2 = 0.4837 -- third-order terms, not the gradient)
     eps = 3e-4 * L0 / gnorm ** 2
@@ -394,8 +394,8 @@ def test_mixed_precision_training_fp16_forward_fp32_bptt(dev):
     f32 = model32.loss_and_grads(x, y, w).clone()
     f16 = model16.loss_and_grads(x, y, w).clone()
     torch.cuda.synchronize()
-    assert float(f16[-2]) == float(f32[-2])
-    assert abs(float(f16[-3]) - float(f32[-3])) <= 5e-3 * abs(float(f32[-3]))
+    assert float(f16[-3]) == float(f32[-3])
+    assert abs(float(f16[-4]) - float(f32[-4])) <= 5e-3 * abs(float(f32[-4]))
     ref_loss, ref, cnt = _autograd(model32, P, wmask, cfg["K"], False)
     name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
     for n, _ in model16._train_items:
