@@ -1015,7 +1015,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                                  float u0_diag, float u0_off, float uk_off, float* h_out,
                                  void* workspace, size_t workspace_bytes, void* stream_,
                                  int profile_frames, float* out_us,
-                                 const float* initial_state = nullptr) {
+                                 const float* initial_state = nullptr, float* final_state = nullptr,
+                                 bool allow_split = true) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = persist_check_flag(h);
     if (rc) return rc;
@@ -1026,19 +1027,60 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                    "cell_forward is the reference's (Euclidean) cell; KL / beta: drnmf_cell_forward_ista");
     if (!x || !params || !log_h0 || !h_out || !workspace)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_forward: NULL pointer argument");
-    const Workspace W = workspace_layout(d);
+    const Workspace W = workspace_layout(d, allow_split);
     if (workspace_bytes < W.total)
         DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "cell_forward: workspace %zu < required %zu",
                    workspace_bytes, W.total);
     if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 255))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "workspace/params must be 256-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
+    auto store_final = [&](const Workspace& Wl) -> int32_t {
+        if (!final_state) return DRNMF_OK;
+        const size_t tot = (size_t)d->B * d->N;
+        hipLaunchKernelGGL(store_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                           (const float*)((char*)workspace + Wl.off_state), final_state, d->B, d->N, Wl.Np);
+        DRNMF_HIP(h, hipGetLastError());
+        return DRNMF_OK;
+    };
     if (W.gram) {
         if (profile_frames > 0)
             DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
                        "cell_profile brackets the factored launches; this call takes the Gram form");
-        return cell_forward_gram(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off,
-                                 h_out, workspace, stream, initial_state);
+        rc = cell_forward_gram(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off,
+                               h_out, workspace, stream, initial_state);
+        return rc ? rc : store_final(W);
+    }
+    if (W.split > 1 && profile_frames <= 0) {
+        // ---- independent sub-batches on the caller's stream + side streams (Workspace::split) ----
+        for (int i = 0; i + 1 < W.split; ++i) {
+            if (!h->side_stream[i]) DRNMF_HIP(h, hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
+            if (!h->join_ev[i]) DRNMF_HIP(h, hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming));
+        }
+        if (!h->fork_ev) DRNMF_HIP(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+        DRNMF_HIP(h, hipEventRecord(h->fork_ev, stream));
+        const size_t width = (size_t)d->N * (d->return_all_hidden ? d->K : 1);
+        int32_t first_err = DRNMF_OK;
+        for (int sidx = 0; sidx < W.split; ++sidx) {
+            const int b0 = sidx * W.split_rows;
+            if (b0 >= d->B) break;
+            drnmf_cell_desc_t ds = *d;
+            ds.B = (d->B - b0 < W.split_rows) ? d->B - b0 : W.split_rows;
+            hipStream_t st = sidx == 0 ? stream : h->side_stream[sidx - 1];
+            if (sidx > 0) DRNMF_HIP(h, hipStreamWaitEvent(st, h->fork_ev, 0));
+            const int32_t src = cell_forward_impl(
+                h, &ds, x + (size_t)b0 * d->T * d->F, mask_value, params, log_h0, u0_diag, u0_off, uk_off,
+                h_out + (size_t)b0 * d->T * width, (char*)workspace + (size_t)sidx * W.split_bytes,
+                W.split_bytes, (void*)st, 0, nullptr,
+                initial_state ? initial_state + (size_t)b0 * d->N : nullptr,
+                final_state ? final_state + (size_t)b0 * d->N : nullptr, false);
+            if (src && !first_err) first_err = src;
+            // (join also after a failed sub-call: the caller's stream must not run ahead of side work)
+            if (sidx > 0) {
+                DRNMF_HIP(h, hipEventRecord(h->join_ev[sidx - 1], st));
+                DRNMF_HIP(h, hipStreamWaitEvent(stream, h->join_ev[sidx - 1], 0));
+            }
+        }
+        return first_err;
     }
     const ParamsLayout L = params_layout(d);
     char* ws = (char*)workspace;
@@ -1243,7 +1285,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             }
             for (auto e : ev) (void)hipEventDestroy(e);
         }
-        return DRNMF_OK;
+        return store_final(W);
     }
 
     auto get_graph = [&](int fpg, hipGraphExec_t* out) -> int32_t {
@@ -1311,7 +1353,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         if (grc) return grc;
         for (; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(exec_1, stream));
     }
-    return DRNMF_OK;
+    return store_final(W);
 }
 
 extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
@@ -1328,16 +1370,8 @@ extern "C" int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cel
                                                float uk_off, const float* initial_state,
                                                float* final_state, float* h_out, void* workspace,
                                                size_t workspace_bytes, void* stream_) {
-    int rc = cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
-                               workspace, workspace_bytes, stream_, 0, nullptr, initial_state);
-    if (rc || !final_state) return rc;
-    const Workspace W = workspace_layout(d);
-    const size_t tot = (size_t)d->B * d->N;
-    hipLaunchKernelGGL(store_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream_, (const float*)((char*)workspace + W.off_state),
-                       final_state, d->B, d->N, W.Np);
-    DRNMF_HIP(h, hipGetLastError());
-    return DRNMF_OK;
+    return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
+                             workspace, workspace_bytes, stream_, 0, nullptr, initial_state, final_state);
 }
 
 extern "C" int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,

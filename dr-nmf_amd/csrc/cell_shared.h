@@ -389,9 +389,17 @@ struct Workspace {
                            // BPTT's weight gradients; 0 = absent
     size_t off_xhat;       // KL / beta cell, training forward: x^_k = h_in Dn_k^T of every (frame, layer),
                            // tile-packed [T][K][Bp][Fp] (the BPTT needs dg/dx^ there); 0 = absent
+    // Large inference batches (the reference predicts in slabs of 250 utterances, enhance.py:1189-1193):
+    // batch rows never interact, so the batch runs as `split` independent sub-batches of `split_rows`
+    // rows (the last one takes the rest) on the caller's stream + side streams of the handle -- the
+    // launch boundaries, prologues and epilogues of one sub-batch's chain fill with the other's MFMA
+    // loops (tools/two_stream_probe.py: B = 256 +13 % with two, B = 512 +15 % with four).  Sub-batch s
+    // owns the workspace bytes [s * split_bytes, (s + 1) * split_bytes).
+    int split, split_rows;
+    size_t split_bytes;
 };
 
-Workspace workspace_layout(const drnmf_cell_desc_t* d) {
+Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) {
     Workspace W;
     W.gram = gram_wanted(d);
     W.half = d->operand_f16 != 0;
@@ -493,6 +501,27 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d) {
     }
     W.off_t = take(256 + 65536);     // frame counters (256 B) + the persistent chains' sync lines (cell_gram_persist.h)
     W.total = o;
+    W.split = 1;
+    W.split_rows = d->B;
+    W.split_bytes = 0;
+    if (allow_split && !W.gram && !d->return_all_hidden && d->divergence == DRNMF_DIV_ED) {
+        // measured (profiles/r04_*): nothing below ~192 rows (a launch of a 64-row sub-batch costs what
+        // one of 128 rows does); two sub-batches from 192 rows, four from 512
+        int S = d->B >= 512 ? 4 : (d->B >= 192 ? 2 : 1);
+        if (const char* e = tune_env("DRNMF_SPLIT")) {      // tuning aid: force the number of sub-batches
+            const int v = atoi(e);
+            if (v >= 1 && v <= 4) S = v;
+        }
+        while (S > 1 && d->B < 32 * S) --S;
+        if (S > 1) {
+            W.split = S;
+            W.split_rows = round_up((d->B + S - 1) / S, 32);
+            drnmf_cell_desc_t ds = *d;
+            ds.B = W.split_rows;
+            W.split_bytes = round_up_sz(workspace_layout(&ds, false).total, 256);
+            if (W.split_bytes * S > W.total) W.total = W.split_bytes * S;
+        }
+    }
     return W;
 }
 

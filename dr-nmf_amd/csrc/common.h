@@ -147,6 +147,10 @@ struct drnmf_handle_s {
     // occupancy of the two persistent kernels and the CU count of THIS handle's device / partition,
     // queried at drnmf_create (params.hip); 0 = the persistent chains are never taken
     int persist_per_cu = 0, persist_n_cu = 0;
+    // side streams + fork / join events of the sub-batch split of large inference batches
+    // (cell_shared.h Workspace::split), created at first use, destroyed with the handle
+    hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
 };
 
 // Tuning / measurement aids are read from the environment ONCE per process (at

@@ -168,6 +168,11 @@ extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
     }
     for (auto& e : h->fft_event)
         if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < 3; ++i) {
+        if (h->side_stream[i]) { (void)hipStreamSynchronize(h->side_stream[i]); (void)hipStreamDestroy(h->side_stream[i]); }
+        if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
+    }
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     if (h->persist_done) (void)hipEventDestroy(h->persist_done);
     if (h->persist_flag) (void)hipHostFree(h->persist_flag);
     delete h;

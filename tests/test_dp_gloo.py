@@ -1,4 +1,4 @@
-"""World-size-2 data parallelism on CPU (gloo): shard utterances, all-reduce the UNNORMALISED flat
+"""World-size-2 and -8 data parallelism on CPU (gloo): shard utterances, all-reduce the UNNORMALISED flat
 gradient + (sum, count), normalise after the reduce -- must equal the unsharded gradient even when
 the ranks hold different numbers of valid frames.  Compute on each rank is
 the torch oracle (test infrastructure); the code under test is drnmf_amd/dp.py, the same helper
@@ -23,8 +23,8 @@ def _free_port():
     return p
 
 
-def _problem():
-    B, T, F, r, K = 6, 7, 21, 5, 2
+def _problem(B=6):
+    T, F, r, K = 7, 21, 5, 2
     P = O.synth_problem(B, T, F, r, seed=9, ragged=True, density=0.2)
     N = 2 * r
     params = dict(W=P["W"], U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
@@ -54,7 +54,8 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     from drnmf_amd import dp
-    P, alt, labels, K, kc, kn, w = _problem()
+    torch.set_num_threads(1)
+    P, alt, labels, K, kc, kn, w = _problem(_SEQS[world])
     lo, hi = dp.shard(P["X"].shape[0])
     flat = _flat_grads(P, alt, labels, K, kc, kn, w, lo, hi)
     dp.allreduce_sum_(flat)
@@ -86,17 +87,26 @@ def test_shard_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
 
 
-def test_two_rank_allreduce_equals_unsharded(tmp_path):
+# sequences per world size: 6 over 2 ranks (3 + 3); 10 over 8 ranks (2, 2, 1, 1, 1, 1, 1, 1 -- uneven, six
+# ranks with a single sequence: BASELINE configs[3] is 8 ranks)
+_SEQS = {2: 6, 8: 10}
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_allreduce_equals_unsharded(tmp_path, world):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    g0 = np.load(tmp_path / "g0.npy")
-    g1 = np.load(tmp_path / "g1.npy")
-    np.testing.assert_array_equal(g0, g1)                  # every rank applies the same step
-    P, alt, labels, K, kc, kn, w = _problem()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g = [np.load(tmp_path / ("g%d.npy" % r)) for r in range(world)]
+    g0 = g[0]
+    for gr in g[1:]:
+        np.testing.assert_array_equal(g0, gr)              # every rank applies the same step
+    P, alt, labels, K, kc, kn, w = _problem(_SEQS[world])
     full = _flat_grads(P, alt, labels, K, kc, kn, w, 0, P["X"].shape[0])
     cnt = float(full[-1])
     ref = np.concatenate([(full[:-2] / cnt).numpy(), [float(full[-2]) / cnt]])
     np.testing.assert_allclose(g0, ref, rtol=1e-12, atol=1e-15)
+    if world != 2:
+        return
     # and it differs from the naive average of per-rank normalised gradients (ragged lengths)
     lo, hi = 0, 3
     a = _flat_grads(P, alt, labels, K, kc, kn, w, 0, 3)
@@ -110,10 +120,11 @@ def _plan_worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     from drnmf_amd import dp, layers
-    lo, hi = dp.shard(17)                       # 9 / 8 sequences: 2 / 1 mini-batches of 8
-    n = hi - lo
-    steps = dp.max_over_ranks(layers.epoch_steps(n, 8))
-    plan = [(b.tolist(), live) for b, live in layers.epoch_batches(np.arange(n), 8, steps)]
+    bs = 8 if world == 2 else 2
+    lo, hi = dp.shard(17)        # 2 ranks: 9 / 8 sequences = 2 / 1 mini-batches of 8;
+    n = hi - lo                  # 8 ranks: 3, 2, 2, ... sequences = 2 / 1 / 1 ... mini-batches of 2
+    steps = dp.max_over_ranks(layers.epoch_steps(n, bs))
+    plan = [(b.tolist(), live) for b, live in layers.epoch_batches(np.arange(n), bs, steps)]
     # every step is a collective in fit(): stand in for it with the flat-buffer all-reduce
     tot = []
     for b, live in plan:
@@ -128,17 +139,22 @@ def _plan_worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_uneven_shards_take_the_same_number_of_steps(tmp_path):
-    """fit() under data parallelism: 17 utterances over 2 ranks with batch_size 8 give 2 and 1
-    local mini-batches; both ranks must run 2 collective steps (the short rank joins the second
-    with zero weights), and broadcast_ makes the replicas equal."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_uneven_shards_take_the_same_number_of_steps(tmp_path, world):
+    """fit() under data parallelism: 17 utterances over 2 ranks with batch_size 8 give 2 and 1 local
+    mini-batches (over 8 ranks with batch_size 2: 2 on rank 0, 1 on the seven others); every rank must
+    run 2 collective steps (the short ranks join the second with zero weights), and broadcast_ makes
+    the replicas equal."""
     port = _free_port()
-    mp.spawn(_plan_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    p0, p1 = np.load(tmp_path / "plan0.npy"), np.load(tmp_path / "plan1.npy")
-    assert p0[0] == p1[0] == 2 and p0[1] == p1[1] == 2
-    # step 0: 8 + 8 live sequences, step 1: 1 + 0; both ranks took part in both reductions
-    np.testing.assert_array_equal(p0[2:6], [16.0, 2.0, 1.0, 2.0])
-    np.testing.assert_array_equal(p0, p1)
+    mp.spawn(_plan_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    plans = [np.load(tmp_path / ("plan%d.npy" % r)) for r in range(world)]
+    p0 = plans[0]
+    assert p0[0] == 2 and p0[1] == 2
+    # step 0: every rank's first mini-batch is live (16 sequences either way), step 1: one live
+    # sequence on rank 0, none elsewhere; all ranks took part in both reductions
+    np.testing.assert_array_equal(p0[2:6], [16.0, float(world), 1.0, float(world)])
+    for pr in plans[1:]:
+        np.testing.assert_array_equal(p0, pr)
     np.testing.assert_array_equal(p0[6:], np.ones(5))
 
 

@@ -1,0 +1,119 @@
+"""Full-size parity at the BASELINE configurations that earlier rounds compared only at reduced length
+("What's weak" 1.ii):
+
+  configs[0]  CPU-reference shape: one utterance, F=513, N=200, K=10, T=1000 -- every hidden state of
+              the whole utterance against the fp64 oracle, in every form the library can take
+              (persistent chains, launch-per-layer-step Gram graphs, factored kernels);
+  configs[2]  the shipped r=100 training configuration at its REAL size (B=32, T=500, F=257, K=5,
+              ragged; data_setup_downsample1 + params_unfolded_snmf_ea1e7d48*.yaml, enhance.py:1152):
+              loss and every gradient tensor against torch-CPU fp64 autograd of the oracle
+              restatement, persistent BPTT on and off and in the factored form.
+
+Tolerances as in test_gpu_parity.py / test_gpu_train.py (written there): hidden state
+max|dh|/max|h| <= 1e-4; gradients max|dg|/max|g| <= 2e-3, loss 2e-5 relative."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import drnmf_oracle as O
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = [pytest.mark.gpu]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from drnmf_amd import _capi
+    _capi.handle(0)
+    return torch.device("cuda:0")
+
+
+FORMS = [("auto", None, None), ("gram graphs", "1", "0"), ("factored", "0", None)]
+
+
+@pytest.fixture(scope="module")
+def config1_case():
+    import test_gpu_parity as TP
+    K = 10
+    P, alt, labels, N = TP._problem(1, 1000, 513, 100, K, untied=(), seed=11, density=0.05)
+    ref = TP._oracle_cell(P, alt, labels, K)
+    return P, alt, labels, N, K, ref
+
+
+@pytest.mark.parametrize("form", FORMS, ids=[f[0] for f in FORMS])
+def test_config1_whole_utterance_matches_oracle(dev, monkeypatch, config1_case, form):
+    """BASELINE configs[0] at its full length (T = 1000 frames x K = 10 layers = 10 000 dependent
+    layer-steps from one initial state) against O.cell_forward_factored in fp64."""
+    import test_gpu_parity as TP
+    P, alt, labels, N, K, ref = config1_case
+    _, gram, persist = form
+    for name, val in (("DRNMF_GRAM", gram), ("DRNMF_PERSIST", persist)):
+        if val is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, val)
+    h, _, desc = TP._run_cell(dev, P, alt, labels, N, K)
+    from drnmf_amd import ops
+    assert ops.cell_launches_per_frame(desc) == (2 * K - 1 if gram == "0" else K - 1)
+    scale = np.max(np.abs(ref))
+    err_t = np.max(np.abs(h - ref), axis=(0, 2)) / scale
+    assert np.all(np.isfinite(h))
+    assert err_t.max() <= TP.H_TOL, "max|dh|/max|h| = %.3e at frame %d" % (err_t.max(), err_t.argmax())
+    assert err_t[-100:].max() <= 4 * max(err_t[:100].max(), 1e-7)      # no growth along the utterance
+
+
+@pytest.fixture(scope="module")
+def config3_case():
+    """Model, data and the fp64 autograd reference of the shipped r = 100 training step (computed
+    once: T*K = 2500 sequential steps of torch-CPU autograd in float64)."""
+    import test_gpu_train as TT
+    cfg = dict(B=32, T=500, F=257, r=100, K=5, untied=("log_D", "log_alph"))
+    model, P, wmask = TT._setup(**cfg)
+    weights = model.get_weights()
+    ref_loss, ref, cnt = TT._autograd(model, P, wmask, cfg["K"], False)
+    return cfg, P, wmask, weights, ref_loss, ref, cnt
+
+
+@pytest.mark.parametrize("form", FORMS, ids=[f[0] for f in FORMS])
+def test_config3_r100_real_size_gradients_match_autograd(dev, monkeypatch, config3_case, form):
+    import test_gpu_train as TT
+    from drnmf_amd import layers
+    cfg, P, wmask, weights, ref_loss, ref, cnt = config3_case
+    _, gram, persist = form
+    for name, val in (("DRNMF_GRAM", gram), ("DRNMF_PERSIST", persist)):
+        if val is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, val)
+    B, T, F, r, K = (cfg[k] for k in ("B", "T", "F", "r", "K"))
+    N = 2 * r
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=list(cfg["untied"]),
+             params_trainable=["log_D", "log_alph"], untie_alph=False)
+    np.random.seed(5)
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.set_weights(weights)
+    model.compile(lr=1e-3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    flat = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(wmask)).clone()
+    torch.cuda.synchronize()
+    assert float(flat[-1]) == 0.0                                      # no fault
+    assert abs(float(flat[-4]) - ref_loss) <= 2e-5 * abs(ref_loss) + 1e-9
+    assert float(flat[-3]) == cnt
+    name_map = {"kernel_clean": "kc", "kernel_noise": "kn"}
+    checked = 0
+    for n, _ in model._train_items:
+        g = model._gview[n].cpu().numpy()
+        r_ = ref[name_map.get(n, n)]
+        assert r_ is not None, n
+        scale = max(np.max(np.abs(r_)), 1e-12)
+        err = np.max(np.abs(g - r_)) / scale
+        assert err <= TT.G_TOL, "%s: rel err %.3e (max ref %.3e)" % (n, err, scale)
+        checked += 1
+    assert checked == 2 * K + 3        # log_h0, K x (log_D_k, log_alph_k), two recon kernels
