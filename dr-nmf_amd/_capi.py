@@ -36,6 +36,7 @@ SIGNATURES = {
     "drnmf_version": (_i32, []),
     "drnmf_create": (_i32, [C.POINTER(_vp), _i32]),
     "drnmf_destroy": (_i32, [_vp]),
+    "drnmf_create_unbound": (_i32, [C.POINTER(_vp)]),
     "drnmf_last_error": (C.c_char_p, [_vp]),
     "drnmf_params_bytes": (_sz, [_DP]),
     "drnmf_prepare_params": (_i32, [_vp, _DP, _vp, _vp, _vp, _vp, _vp]),

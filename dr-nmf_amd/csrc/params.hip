@@ -122,6 +122,18 @@ extern "C" int32_t drnmf_status_take_device(drnmf_handle_t h, float* dst_device,
     return DRNMF_OK;
 }
 
+// A handle bound to NO device: size queries, descriptor validation and argument checks behave as on a
+// real handle; whatever would touch the GPU fails with DRNMF_ERR_HIP.  For hosts without a GPU (the
+// CPU-side sanitizer run of the ABI's host half, tests/test_sanitize.py); no product path creates one.
+extern "C" int32_t drnmf_create_unbound(drnmf_handle_t* out) {
+    if (!out) return DRNMF_ERR_INVALID_ARG;
+    drnmf_handle_t h = new (std::nothrow) drnmf_handle_s();
+    if (!h) return DRNMF_ERR_HIP;
+    h->device = -1;
+    *out = h;
+    return DRNMF_OK;
+}
+
 int32_t persist_check_flag(drnmf_handle_t h) {
     if (!h->persist_flag || *(volatile unsigned*)h->persist_flag == 0u) return DRNMF_OK;
     *(volatile unsigned*)h->persist_flag = 0u;

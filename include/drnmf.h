@@ -75,6 +75,10 @@ typedef struct drnmf_cell_desc {
 int32_t drnmf_version(void);
 int32_t drnmf_create(drnmf_handle_t* out, int32_t device);
 int32_t drnmf_destroy(drnmf_handle_t h);
+/* A handle bound to no device (hosts without a GPU: the sanitizer run of the host half of the library,
+ * tests/test_sanitize.py): size queries, descriptor validation and argument checks work, anything that
+ * would touch the GPU returns DRNMF_ERR_HIP.  Not used by any product path. */
+int32_t drnmf_create_unbound(drnmf_handle_t* out);
 const char* drnmf_last_error(drnmf_handle_t h); /* h may be NULL: last create() error */
 
 /* Asynchronous faults.  Every call only ENQUEUES work, so a fault that happens on the device (today: a
