@@ -1,12 +1,12 @@
 /* CPU-side sanitizer run of the HOST half of libdrnmf.
  *
  * Linked against dr-nmf_amd/build_asan/libdrnmf_asan.so -- every translation unit's host code built with
- * -fsanitize=address,undefined (dr-nmf_amd/build.py: build_sanitized) -- and run on a host WITHOUT a
+ * the address + undefined-behaviour sanitizers (tools/sanitize/build_sanitized.py) -- and run on a host WITHOUT a
  * GPU: every size query, descriptor validator, layout rule (under the tuning variables that switch
  * their branches) and argument-check / error path of the C ABI, through a handle bound to no device
  * (drnmf_create_unbound).  Nothing here reaches a kernel launch: every compute entry point is called
  * with arguments its own checks must refuse.  Exit code 0 = every expectation held and no sanitizer
- * report was printed (a report aborts the process: -fno-sanitize-recover, ASAN halt_on_error). */
+ * report was printed (a report aborts the process: no-recover build, halt_on_error). */
 #define _POSIX_C_SOURCE 200112L
 #include <stdio.h>
 #include <stdlib.h>
