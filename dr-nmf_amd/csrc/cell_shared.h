@@ -505,9 +505,10 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     W.split_rows = d->B;
     W.split_bytes = 0;
     if (allow_split && !W.gram && !d->return_all_hidden && d->divergence == DRNMF_DIV_ED) {
-        // measured (profiles/r04_*): nothing below ~192 rows (a launch of a 64-row sub-batch costs what
-        // one of 128 rows does); two sub-batches from 192 rows, four from 512
-        int S = d->B >= 512 ? 4 : (d->B >= 192 ? 2 : 1);
+        // measured (profiles/r04b_split_sweep.txt; cell + head, T = 200, k frames/s with 1 / 2 / 3 / 4
+        // sub-batches): B = 128 426 / 491 / 490 / 362, 192 469 / 546 / 569 / 574, 250 580 / 656 / 598 / 600,
+        // 384 622 / 740 / 743 / 715, 512 727 / 765 / 786 / 779, 1024 657 / 928 / 929 / 937
+        int S = d->B >= 896 ? 4 : (d->B >= 448 ? 3 : (d->B >= 128 ? 2 : 1));
         if (const char* e = tune_env("DRNMF_SPLIT")) {      // tuning aid: force the number of sub-batches
             const int v = atoi(e);
             if (v >= 1 && v <= 4) S = v;

@@ -141,17 +141,23 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
     //   chunk 1, 2: fragments of the next chunk in the first half, 8 bare MFMAs for them to land
     //   chunk 3: the 8 LDS writes of the next k-tile (global loads issued ~3000 cycles earlier)
     // STAGE = false (last k-tile): reads and MFMAs only.
-    auto ktile = [&](int buf, auto stage_tag, int k_next) {
+    // NB (0, 1 or 2) = 32-column halves of this wave's 64 output columns that lie inside N: the last
+    // column tile of a 2^k+1-wide output (F = 513: column 512 alone) keeps 3 of its 4 waves' MFMAs off the
+    // matrix pipes instead of running a full 128-column tile for one column (the staging loads, LDS writes
+    // and barriers are still shared by all four waves).  NB < 2 leaves the scheduling to the compiler.
+    auto ktile = [&](int buf, auto stage_tag, int k_next, auto nb_tag) {
         constexpr bool STAGE = decltype(stage_tag)::value;
+        constexpr int NB = decltype(nb_tag)::value;
         const float* As = lds + buf * 2 * BM * LDS_LD + (wm * 64 + li) * LDS_LD + 4 * kk;
         const float* Bs = lds + buf * 2 * BM * LDS_LD + BM * LDS_LD + (wn * 64 + li) * LDS_LD +
                           4 * kk;
         f32x4 fa0[2], fa1[2], fb0[2], fb1[2];
         auto fetch = [&](int c) {
+            if (NB == 0) return;
             fa0[c & 1] = *(const f32x4*)(As + 8 * c);
             fb0[c & 1] = *(const f32x4*)(Bs + 8 * c);
             fa1[c & 1] = *(const f32x4*)(As + 32 * LDS_LD + 8 * c);
-            fb1[c & 1] = *(const f32x4*)(Bs + 32 * LDS_LD + 8 * c);
+            if (NB == 2) fb1[c & 1] = *(const f32x4*)(Bs + 32 * LDS_LD + 8 * c);
         };
         fetch(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -159,16 +165,26 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c < 3) fetch(c + 1);
-            const f32x4 a0 = fa0[c & 1], a1 = fa1[c & 1], b0 = fb0[c & 1], b1 = fb1[c & 1];
+            if (NB == 2) {
+                const f32x4 a0 = fa0[c & 1], a1 = fa1[c & 1], b0 = fb0[c & 1], b1 = fb1[c & 1];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+                }
+            } else if (NB == 1) {
+                const f32x4 a0 = fa0[c & 1], a1 = fa1[c & 1], b0 = fb0[c & 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                }
             }
         }
         if (STAGE) swrite(buf ^ 1, k_next);
+        if (NB < 2) return;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
 #pragma unroll
@@ -199,12 +215,26 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
     };
 
     const int nkt = (g.K + BK - 1) / BK;
+    // (wave-uniform: tn, wn and N are)
+    const int nb = n0 + wn * 64 + 32 < g.N ? 2 : (n0 + wn * 64 < g.N ? 1 : 0);
     gload(0);
     swrite(0, 0);
     __syncthreads();
-    for (int kt = 0; kt + 1 < nkt; ++kt) {
-        ktile(kt & 1, std::true_type{}, (kt + 1) * BK);
-        __syncthreads();
+    if (nb == 2) {
+        for (int kt = 0; kt + 1 < nkt; ++kt) {
+            ktile(kt & 1, std::true_type{}, (kt + 1) * BK, std::integral_constant<int, 2>{});
+            __syncthreads();
+        }
+    } else if (nb == 1) {
+        for (int kt = 0; kt + 1 < nkt; ++kt) {
+            ktile(kt & 1, std::true_type{}, (kt + 1) * BK, std::integral_constant<int, 1>{});
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt + 1 < nkt; ++kt) {
+            ktile(kt & 1, std::true_type{}, (kt + 1) * BK, std::integral_constant<int, 0>{});
+            __syncthreads();
+        }
     }
 
     // Last k-tile and epilogue.  Register v of lane l holds row (v&3) + 8*(v>>2) + 4*(l>>5),
@@ -244,8 +274,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        ktile((nkt - 1) & 1, std::false_type{}, 0);
-        if (g.ktail) {
+        if (nb == 2) ktile((nkt - 1) & 1, std::false_type{}, 0, std::integral_constant<int, 2>{});
+        else if (nb == 1) ktile((nkt - 1) & 1, std::false_type{}, 0, std::integral_constant<int, 1>{});
+        if (g.ktail && nb > 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (!(tk && m0 + wm * 64 + i * 32 + li < g.M)) ta[i] = 0.f;

@@ -127,14 +127,20 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
     // measurements behind this): the fragments of step s+1 (two ds_read2_b32) behind the 1st and
     // 3rd MFMA of step s; the 8 global loads of the NEXT k-tile in steps 0..3; its 8 LDS writes in
     // steps 12..15.  STAGE = false: the last k-tile of the split.
-    auto ktile = [&](int buf, auto stage_tag, int64_t kt_next) {
+    // NA (0, 1 or 2) = 32-row halves of this wave's 64 output rows that lie inside M: the last tile row
+    // of an output with 4 j + few rows (dictionary training: F = 513 padded to 516 = four tile rows + 4)
+    // keeps the matrix pipes of the waves that own nothing but padding idle (gemm_nt.h has the column
+    // counterpart).  NA < 2 leaves the scheduling to the compiler.
+    auto ktile = [&](int buf, auto stage_tag, int64_t kt_next, auto na_tag) {
         constexpr bool STAGE = decltype(stage_tag)::value;
+        constexpr int NA = decltype(na_tag)::value;
         const float* As = lds + buf * 2 * BK * BM + kk * BM + wm * 64 + li;
         const float* Bs = lds + buf * 2 * BK * BM + BK * BM + kk * BN + wn * 64 + li;
         float fa0[2], fa1[2], fb0[2], fb1[2];
         auto fetch = [&](int s) {
+            if (NA == 0) return;
             fa0[s & 1] = As[2 * s * BM];
-            fa1[s & 1] = As[2 * s * BM + 32];
+            if (NA == 2) fa1[s & 1] = As[2 * s * BM + 32];
             fb0[s & 1] = Bs[2 * s * BN];
             fb1[s & 1] = Bs[2 * s * BN + 32];
         };
@@ -144,13 +150,20 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             if (s < 15) fetch(s + 1);
-            const float a0 = fa0[s & 1], a1 = fa1[s & 1], b0 = fb0[s & 1], b1 = fb1[s & 1];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (NA == 2) {
+                const float a0 = fa0[s & 1], a1 = fa1[s & 1], b0 = fb0[s & 1], b1 = fb1[s & 1];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            } else if (NA == 1) {
+                const float a0 = fa0[s & 1], b0 = fb0[s & 1], b1 = fb1[s & 1];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            }
         }
         if (STAGE) swrite(buf ^ 1, kt_next);
+        if (NA < 2) return;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
 #pragma unroll
@@ -164,15 +177,29 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const Operands g, const Ep
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    const int na = m0 + wm * 64 + 32 < g.M ? 2 : (m0 + wm * 64 < g.M ? 1 : 0);   // (wave-uniform)
     if (kt0 < kt1) {
         gload(kt0);
         swrite(0, kt0);
         __syncthreads();
-        for (int64_t kt = kt0; kt + 1 < kt1; ++kt) {
-            ktile((int)((kt - kt0) & 1), std::true_type{}, kt + 1);
-            __syncthreads();
+        if (na == 2) {
+            for (int64_t kt = kt0; kt + 1 < kt1; ++kt) {
+                ktile((int)((kt - kt0) & 1), std::true_type{}, kt + 1, std::integral_constant<int, 2>{});
+                __syncthreads();
+            }
+            ktile((int)((kt1 - 1 - kt0) & 1), std::false_type{}, 0, std::integral_constant<int, 2>{});
+        } else if (na == 1) {
+            for (int64_t kt = kt0; kt + 1 < kt1; ++kt) {
+                ktile((int)((kt - kt0) & 1), std::true_type{}, kt + 1, std::integral_constant<int, 1>{});
+                __syncthreads();
+            }
+            ktile((int)((kt1 - 1 - kt0) & 1), std::false_type{}, 0, std::integral_constant<int, 1>{});
+        } else {
+            for (int64_t kt = kt0; kt + 1 < kt1; ++kt) {
+                ktile((int)((kt - kt0) & 1), std::true_type{}, kt + 1, std::integral_constant<int, 0>{});
+                __syncthreads();
+            }
         }
-        ktile((int)((kt1 - 1 - kt0) & 1), std::false_type{}, 0);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)

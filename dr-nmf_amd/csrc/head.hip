@@ -8,8 +8,69 @@
 // accumulators kept in registers and the mask computed in the epilogue: A and Bn never touch
 // HBM unless the caller asks for them.
 #include "common.h"
+#include "gemm_nt.h"
 
 namespace {
+
+// ---- large row counts: the head as TWO frame-parallel GEMMs on the gemm_nt template (128 x 128 tiles
+// staged through LDS, 32x32x2 MFMA: 70 % of the fp32-MFMA peak against the 38 % of head_kernel, which
+// feeds every wave straight from global memory with 4-byte dictionary loads):
+//     pass 1: A  = h[:, :r] exp(Kc)   -> written to the mask buffer itself (and A_out)
+//     pass 2: Bn = h[:, r:] exp(Kn);  the epilogue reads A back from the mask buffer (the same thread
+//             that overwrites it), forms the ratio mask and stores it (and Bn_out)
+// No scratch beyond ecat: the round trip of A through the output costs 8 bytes per element against
+// 4 r flops.  ecatT[seg][f][k] = exp(K_seg[k][f]) (K contiguous: the "Bt" of gemm_nt), rows f >= F zero.
+__global__ void __launch_bounds__(256)
+head_exp_t_kernel(const float* __restrict__ kc, const float* __restrict__ kn,
+                  float* __restrict__ ecatT, int r, int rp, int F, int Fp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t tot = (size_t)2 * rp * Fp;
+    if (i >= tot) return;
+    const int k = (int)(i % rp);
+    const int f = (int)((i / rp) % Fp);
+    const int seg = (int)(i / ((size_t)Fp * rp));
+    float v = 0.f;
+    if (k < r && f < F) v = expf((seg ? kn : kc)[(size_t)k * F + f]);
+    ecatT[i] = v;
+}
+__global__ void __launch_bounds__(256)
+head_w_t_kernel(const float* __restrict__ Wn, float* __restrict__ ecatT, int r, int rp, int F, int Fp,
+                int N) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t tot = (size_t)2 * rp * Fp;
+    if (i >= tot) return;
+    const int k = (int)(i % rp);
+    const int f = (int)((i / rp) % Fp);
+    const int seg = (int)(i / ((size_t)Fp * rp));
+    ecatT[i] = (k < r && f < F) ? Wn[(size_t)f * N + seg * r + k] : 0.f;
+}
+struct EpiHeadA {
+    float* mask;
+    float* A_out;
+    int F, square;
+    static constexpr bool EARLY = false;
+    __device__ f32x2 pre(int, int) const { return f32x2{0.f, 0.f}; }
+    __device__ void operator()(int row, int col, float acc, f32x2) const {
+        const float A = square ? acc * acc : acc;
+        const size_t o = (size_t)row * F + col;
+        mask[o] = A;
+        if (A_out) A_out[o] = A;
+    }
+};
+struct EpiHeadB {
+    float* mask;
+    float* Bn_out;
+    int F, square, mode;
+    __device__ f32x2 pre(int row, int col) const { return f32x2{mask[(size_t)row * F + col], 0.f}; }
+    __device__ void operator()(int row, int col, float acc, f32x2 p) const {
+        const float A = p[0];
+        const float Bn = square ? acc * acc : acc;
+        const size_t o = (size_t)row * F + col;
+        mask[o] = mode == 0 ? expf(logf(1e-7f + A) - logf(1e-7f + A + Bn)) : A / (1e-9f + A + Bn);
+        if (Bn_out) Bn_out[o] = Bn;
+    }
+};
+constexpr int64_t HEAD_GEMM_MIN_ROWS = 2048;   // below: head_kernel (one launch, no round trip of A)
 
 // exp of the log-domain kernels into one zero-padded block: ecat[seg][k][f], seg 0 = clean,
 // seg 1 = noise, k < rp = round_up(r,16), f < Fp.
@@ -188,6 +249,16 @@ void launch_head(const HeadArgs& a, hipStream_t stream) {   // (rows < 2^31 * 16
 #undef LAUNCH_HEAD
 }
 
+// the two-GEMM form (see the top of the file); ecatT already holds the transposed dictionaries
+hipError_t launch_head_gemm(const HeadArgs& a, hipStream_t stream) {
+    const float* h0 = a.hidden + a.h_off;
+    gemm::Operands g1{h0, a.ecat, a.rows, a.F, a.r, a.ld_h, a.rp};
+    hipError_t e = gemm::launch(g1, EpiHeadA{a.mask, a.A_out, a.F, a.square}, stream);
+    if (e != hipSuccess) return e;
+    gemm::Operands g2{h0 + a.r, a.ecat + (size_t)a.Fp * a.rp, a.rows, a.F, a.r, a.ld_h, a.rp};
+    return gemm::launch(g2, EpiHeadB{a.mask, a.Bn_out, a.F, a.square, a.mode}, stream);
+}
+
 }  // namespace
 
 extern "C" int32_t drnmf_padded_f(int32_t F) { return F > 0 ? pad_f(F) : 0; }
@@ -205,16 +276,22 @@ extern "C" int32_t drnmf_head_forward(drnmf_handle_t h, int64_t rows, int32_t F,
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "head_forward: NULL pointer argument");
     hipStream_t stream = (hipStream_t)stream_;
     const int Fp = pad_f(F), rp = round_up(r, 16);
+    const bool as_gemm = rows >= HEAD_GEMM_MIN_ROWS;
     {
         const size_t tot = (size_t)2 * rp * Fp;
-        hipLaunchKernelGGL(head_exp_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                           stream, kernel_clean, kernel_noise, ecat, r, rp, F, Fp);
+        if (as_gemm)
+            hipLaunchKernelGGL(head_exp_t_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                               stream, kernel_clean, kernel_noise, ecat, r, rp, F, Fp);
+        else
+            hipLaunchKernelGGL(head_exp_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                               stream, kernel_clean, kernel_noise, ecat, r, rp, F, Fp);
     }
     HeadArgs a;
     a.hidden = hidden; a.ecat = ecat; a.mask = mask; a.A_out = A_out; a.Bn_out = Bn_out;
     a.rows = rows; a.ld_h = ld_h; a.h_off = h_off; a.F = F; a.Fp = Fp; a.r = r; a.rp = rp;
     a.square = square; a.mode = 0;
-    launch_head(a, stream);
+    if (as_gemm) DRNMF_HIP(h, launch_head_gemm(a, stream));
+    else launch_head(a, stream);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }
@@ -224,13 +301,19 @@ int head_irm_forward(drnmf_handle_t h, int64_t rows, int F, int r, const float* 
                      const float* Wn, float* irm, float* ecat, hipStream_t stream) {
     const int Fp = pad_f(F), rp = round_up(r, 16);
     const size_t tot = (size_t)2 * rp * Fp;
-    hipLaunchKernelGGL(head_w_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, Wn,
-                       ecat, r, rp, F, Fp, 2 * r);
+    const bool as_gemm = rows >= HEAD_GEMM_MIN_ROWS;
+    if (as_gemm)
+        hipLaunchKernelGGL(head_w_t_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, Wn,
+                           ecat, r, rp, F, Fp, 2 * r);
+    else
+        hipLaunchKernelGGL(head_w_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, Wn,
+                           ecat, r, rp, F, Fp, 2 * r);
     HeadArgs a;
     a.hidden = H; a.ecat = ecat; a.mask = irm; a.A_out = nullptr; a.Bn_out = nullptr;
     a.rows = rows; a.ld_h = ld_h; a.h_off = 0; a.F = F; a.Fp = Fp; a.r = r; a.rp = rp;
     a.square = 0; a.mode = 1;
-    launch_head(a, stream);
+    if (as_gemm) DRNMF_HIP(h, launch_head_gemm(a, stream));
+    else launch_head(a, stream);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }

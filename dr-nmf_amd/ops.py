@@ -22,6 +22,18 @@ def _dev_index(t):
     return t.device.index if t.device.index is not None else torch.cuda.current_device()
 
 
+def _dev_of(d):
+    """Device index of an int, a torch.device / device string, or a CUDA tensor."""
+    if isinstance(d, int):
+        return d
+    if isinstance(d, torch.Tensor):
+        return _dev_index(d)
+    d = torch.device(d)
+    if d.type != 'cuda':
+        raise ValueError("drnmf_amd ops need a CUDA(HIP) device; got %s. There is no CPU fallback." % d)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
 def _f32c(t, name):
     if t.dtype != torch.float32:
         raise ValueError("%s must be float32 (got %s)" % (name, t.dtype))
@@ -545,7 +557,7 @@ _report_rings = {}
 def host_report_ring(device):
     """(numpy view [slots, 4] of the handle's host-mapped report ring, its base address) -- a slot's
     address is a valid `report` argument of adam_step_flat."""
-    dev = device if isinstance(device, int) else _dev_index(device)
+    dev = _dev_of(device)
     if dev not in _report_rings:
         L = _capi.lib()
         h = _capi.handle(dev)
@@ -561,8 +573,7 @@ def check_status(device):
     """Raise if an EARLIER, already synchronised call on this device's handle suffered an asynchronous
     fault (a persistent chain that timed out: its output is invalid).  Reads and clears the flag."""
     L = _capi.lib()
-    dev = device if isinstance(device, int) else _dev_index(device)
-    h = _capi.handle(dev)
+    h = _capi.handle(_dev_of(device))
     _capi.check(L.drnmf_check_status(h), h, "drnmf_check_status")
 
 

@@ -182,8 +182,12 @@ def test_cell_reference_dense_form_agrees(dev):
 def test_head_matches_oracle(dev):
     from drnmf_amd import ops
     rng = np.random.default_rng(0)
+    # (>= 2048 rows take the two-GEMM form of csrc/head.hip: A through the mask buffer, ratio in the
+    # second epilogue; r = 7 there = contraction not a multiple of 4, the scalar staging path)
     for rows_shape, r, F, square in [((3, 7), 6, 21, False), ((130,), 100, 257, False),
-                                     ((2, 5), 7, 33, True), ((257,), 16, 513, False)]:
+                                     ((2, 5), 7, 33, True), ((257,), 16, 513, False),
+                                     ((2100,), 100, 257, False), ((16, 140), 24, 513, True),
+                                     ((2050,), 7, 33, False), ((5, 500), 1000, 513, False)]:
         h = np.abs(rng.standard_normal(rows_shape + (2 * r,))).astype(np.float32) * \
             (rng.random(rows_shape + (2 * r,)) < 0.3)
         kc = (rng.standard_normal((r, F)) - 2).astype(np.float32)
