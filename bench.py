@@ -962,6 +962,16 @@ def main():
         extra["config1_single_utterance"] = safe(config1_bench, torch, dev)
         if not a.no_slab:
             extra["inference_slab_250"] = safe(slab_bench, torch, dev, F, r, K, T)
+            # the same forward (cell + mask head) over batch sizes: from 128 rows on the batch runs as
+            # independent sub-batches on side streams (csrc/cell_shared.h Workspace::split)
+            sweep = []
+            for b_sw in (64, 128, 250, 512, 1024):
+                res = safe(slab_bench, torch, dev, F, r, K, min(T, 400), slab=b_sw)
+                sweep.append({"B": b_sw, "frames": min(T, 400),
+                              **({"error": res["error"]} if "error" in res else
+                                 {"frames_per_s": res["frames_per_s"],
+                                  "frac_of_f32_mfma_peak": res["frac_of_f32_mfma_peak"]})})
+            extra["inference_batch_sweep"] = sweep
             # the same slab for the shipped small model (params_unfolded_snmf_*.yaml: N_fft = 512, r = 100,
             # K = 5): 16 persistent row-tile chains, two per XCD (csrc/cell_gram_persist.h)
             extra["inference_slab_250_shipped_r100"] = safe(slab_bench, torch, dev, 257, 100, 5, 500)

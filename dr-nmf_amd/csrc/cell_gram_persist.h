@@ -632,7 +632,9 @@ static inline bool persist_shape_ok(drnmf_handle_t h, int numM, int numO, int K)
     // device); on a smaller partition (fewer CUs than 8 x 32) every participant of every chain must
     // still fit the device at once.  Occupancy and CU count belong to the handle's device
     // (drnmf_create -> persist_query_occupancy): handles on different devices / partitions differ.
-    return h->persist_per_cu >= 1 && numM * numO <= h->persist_n_cu * h->persist_per_cu;
+    // (persist_lock_fd: this handle owns the device's cross-process admission, common.h)
+    return h->persist_lock_fd >= 0 && h->persist_per_cu >= 1 &&
+           numM * numO <= h->persist_n_cu * h->persist_per_cu;
 }
 // (defined once, in cell_forward.hip)
 static inline void persist_query_occupancy_impl(int device, int* per_cu, int* n_cu) {

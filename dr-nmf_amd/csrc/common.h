@@ -147,6 +147,14 @@ struct drnmf_handle_s {
     // occupancy of the two persistent kernels and the CU count of THIS handle's device / partition,
     // queried at drnmf_create (params.hip); 0 = the persistent chains are never taken
     int persist_per_cu = 0, persist_n_cu = 0;
+    // Cross-PROCESS admission of the persistent chains: two processes on one GPU (several ranks of a
+    // test job, a second tenant) are not coordinated by the per-handle stream admission below -- their
+    // chains could each hold CUs the other's workgroups need.  The first handle on a device that
+    // acquires an exclusive, non-blocking flock on /tmp/drnmf_persist_<pci bus id>.lock keeps it for its
+    // lifetime and may take the chains; every other handle (other processes, a second handle of this
+    // process) runs the launch-per-layer-step graphs, which compute the same bits.  The kernel drops the
+    // lock when its owner dies.  -1: not the owner.
+    int persist_lock_fd = -1;
     // side streams + fork / join events of the sub-batch split of large inference batches
     // (cell_shared.h Workspace::split), created at first use, destroyed with the handle
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};

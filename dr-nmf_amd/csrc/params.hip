@@ -4,6 +4,10 @@
 #include "common.h"
 #include "gemm_tn.h"
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <map>
 #include <mutex>
 #include <string>
@@ -84,6 +88,21 @@ extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
     }
     // occupancy of the persistent chain kernels on THIS device / partition (cell_forward.hip)
     persist_query_occupancy(device, &h->persist_per_cu, &h->persist_n_cu);
+    {   // cross-process admission of the persistent chains (common.h)
+        char bus[64] = {0}, path[128];
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device) != hipSuccess) {
+            (void)hipGetLastError();
+            snprintf(bus, sizeof(bus), "dev%d", device);
+        }
+        for (char* c = bus; *c; ++c)
+            if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
+        snprintf(path, sizeof(path), "/tmp/drnmf_persist_%s.lock", bus);
+        const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (fd >= 0) {
+            if (flock(fd, LOCK_EX | LOCK_NB) == 0) h->persist_lock_fd = fd;
+            else close(fd);
+        }
+    }
     *out = h;
     return DRNMF_OK;
 }
@@ -94,6 +113,13 @@ extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
 extern "C" int32_t drnmf_check_status(drnmf_handle_t h) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     return persist_check_flag(h);
+}
+
+// 1: this handle may run the persistent small-shape chains (it owns the device's cross-process lock and
+// has a fault word); 0: it always takes the launch-per-layer-step graphs (same results).
+extern "C" int32_t drnmf_persist_admitted(drnmf_handle_t h) {
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    return (h->persist_lock_fd >= 0 && h->persist_flag != nullptr && h->persist_per_cu >= 1) ? 1 : 0;
 }
 
 // A small ring of 4-float slots in host-mapped, coherent memory that kernels may write (the report of
@@ -187,6 +213,7 @@ extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     if (h->persist_done) (void)hipEventDestroy(h->persist_done);
     if (h->persist_flag) (void)hipHostFree(h->persist_flag);
+    if (h->persist_lock_fd >= 0) close(h->persist_lock_fd);      // (releases the flock)
     delete h;
     return DRNMF_OK;
 }

@@ -438,6 +438,12 @@ class SimpleDeepRNN(_Layer):
         self._dense_now = not (np.all(d == d[0]) and np.all(off == off[0]) and
                                np.all(Uk == Uk.flat[0]))
         self._u = (float(d[0]), float(off[0]) if N > 1 else 0.0, float(Uk.flat[0]))
+        if self.divergence != 'ed':
+            # The KL / beta variant is ista_kl / ista_beta run recurrently: it has NO U term at all
+            # (DESIGN.md section 7), so whatever log_U1 / log_Uk hold is ignored -- the dense-matrix
+            # kernels implement the Euclidean step only and must never be chosen for this cell
+            # (a set_weights() that broke U's structure silently switched models).
+            self._dense_now = False
 
     # -- general dense-matrix path -------------------------------------------------------------
     def dense_matrices(self):

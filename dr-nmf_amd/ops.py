@@ -577,6 +577,13 @@ def check_status(device):
     _capi.check(L.drnmf_check_status(h), h, "drnmf_check_status")
 
 
+def persist_admitted(device):
+    """True if this process's handle on `device` may run the persistent small-shape chains (it holds the
+    device's cross-process lock; see include/drnmf.h)."""
+    L = _capi.lib()
+    return int(L.drnmf_persist_admitted(_capi.handle(_dev_of(device)))) == 1
+
+
 def status_take(dst):
     """Stream-ordered: adds 1.0 to the one-element device tensor `dst` if the handle's fault word is
     raised, and clears it (no synchronisation)."""

@@ -94,6 +94,11 @@ const char* drnmf_last_error(drnmf_handle_t h); /* h may be NULL: last create() 
  *                             (drnmf_adam_step_flat) and learns of the fault at the same step. */
 int32_t drnmf_check_status(drnmf_handle_t h);
 int32_t drnmf_status_take_device(drnmf_handle_t h, float* dst_device, void* stream);
+/* 1 if this handle may run the persistent small-shape chains, 0 if it always takes the
+ * launch-per-layer-step form (same results).  Chains of two PROCESSES on one GPU are not coordinated on
+ * the device; the first handle that takes an exclusive flock on /tmp/drnmf_persist_<pci bus id>.lock
+ * (at drnmf_create, held until drnmf_destroy / process exit) is the one admitted. */
+int32_t drnmf_persist_admitted(drnmf_handle_t h);
 /* A ring of `*slots` 4-float slots in host-mapped, coherent memory owned by the handle: a valid
  * DEVICE pointer for the `report4` argument of drnmf_adam_step_flat and readable by the host once an
  * event recorded behind that launch has completed (no copy, no stream synchronisation). */

@@ -191,6 +191,7 @@ static void refused_calls(drnmf_handle_t h) {
     CHECK(drnmf_comm_destroy(h) == DRNMF_OK);
     /* fault word / report ring on a handle without host-mapped memory */
     CHECK(drnmf_check_status(h) == DRNMF_OK);
+    CHECK(drnmf_persist_admitted(h) == 0 && drnmf_persist_admitted(NULL) < 0);
     CHECK(drnmf_status_take_device(h, &f, NULL) == DRNMF_OK);    /* no fault word: nothing is launched */
     REFUSED(h, drnmf_status_take_device(h, NULL, NULL));
     float* ring = NULL;

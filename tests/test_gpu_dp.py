@@ -414,3 +414,54 @@ def test_persistent_timeout_is_reported_not_swallowed(dev, monkeypatch):
         TP._run_cell(dev, P, alt, labels, N, K)
     again = TP._run_cell(dev, P, alt, labels, N, K)[0]     # the flag is reported once
     assert np.array_equal(again, good)
+
+
+def _tenant_worker(rank, world, out_dir):
+    """One of several PROCESSES sharing the GPU, each running a chain-eligible forward over and over."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as TP
+    from drnmf_amd import ops
+    torch.cuda.set_device(0)
+    os.environ["DRNMF_GRAM"] = "1"
+    os.environ["DRNMF_PERSIST"] = "1"
+    ops.reload_env()
+    dev = torch.device("cuda:0")
+    B, T, F, r, K = 16, 192, 33, 100, 4
+    P, alt, labels, N = TP._problem(B, T, F, r, K, untied=("log_D", "log_alph"), ragged=True, seed=40)
+    admitted = ops.persist_admitted(dev)
+    outs = []
+    for _ in range(12):
+        h, _, _ = TP._run_cell(dev, P, alt, labels, N, K)
+        outs.append(h)
+    ops.check_status(dev)                       # raises on a chain that timed out
+    for h in outs[1:]:
+        assert np.array_equal(h, outs[0])
+    np.savez(os.path.join(out_dir, "tenant%d.npz" % rank), h=outs[0], admitted=np.array([int(admitted)]))
+
+
+def test_processes_sharing_one_gpu_admit_one_owner_of_the_persistent_chains(dev, monkeypatch, tmp_path):
+    """persistent chains of two PROCESSES on one GPU are not coordinated on
+    the device (each could hold CUs the other's workgroups need).  Policy: the first handle on a device
+    holds an exclusive flock for its lifetime and is the only one admitted to the chains
+    (drnmf_persist_admitted); every other process runs the launch-per-layer-step graphs -- the same bits.
+    Here this pytest process is the owner; three concurrent tenant processes must not be admitted, must
+    finish without a timeout and must reproduce the owner's output bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as TP
+    from drnmf_amd import ops
+    monkeypatch.setenv("DRNMF_GRAM", "1")
+    monkeypatch.setenv("DRNMF_PERSIST", "1")
+    assert ops.persist_admitted(dev), "the test process created the first handle on this GPU"
+    B, T, F, r, K = 16, 192, 33, 100, 4
+    P, alt, labels, N = TP._problem(B, T, F, r, K, untied=("log_D", "log_alph"), ragged=True, seed=40)
+    mine, _, _ = TP._run_cell(dev, P, alt, labels, N, K)
+    ops.check_status(dev)
+    mp.spawn(_tenant_worker, args=(3, str(tmp_path)), nprocs=3, join=True)
+    for rank in range(3):
+        z = np.load(tmp_path / ("tenant%d.npz" % rank))
+        assert int(z["admitted"][0]) == 0
+        assert np.array_equal(z["h"], mine)
+    ref = TP._oracle_cell(P, alt, labels, K)
+    assert np.max(np.abs(mine - ref)) <= TP.H_TOL * np.max(np.abs(ref))

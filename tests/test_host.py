@@ -243,6 +243,19 @@ def test_dense_matrices_of_generic_layer_configurations():
     w[i] = np.asarray(alt["log_Uk"], np.float32)
     cell.set_weights(w)
     assert not cell._dense_now
+    # ... but never the KL / beta variant: that cell has no U term, and the dense-matrix kernels are
+    # the Euclidean step
+    alt_kl, maps_kl = layers.build_alt(N, K, params, ["log_D"])
+    kl = layers.SimpleDeepRNN(N, activation="relu", K_layers=K, alt_params=alt_kl,
+                              maps_from_alt=maps_kl, flag_connect_input_to_layers=True,
+                              flag_nonnegative=True, return_sequences=True, device="cpu",
+                              divergence="kl")
+    kl.build((None, 3, F))
+    wk = kl.get_weights()
+    j = kl.weight_names.index(kl.name + "_log_Uk")
+    wk[j] = wk[j] + np.float32(0.1) * np.arange(N * N, dtype=np.float32).reshape(N, N) / (N * N)
+    kl.set_weights(wk)
+    assert not kl._dense_now
 
     np.random.seed(4)
     A = np.random.standard_normal((F, N)).astype(np.float32)
