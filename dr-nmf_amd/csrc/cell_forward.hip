@@ -1010,13 +1010,20 @@ static int32_t cell_forward_gram(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     return DRNMF_OK;
 }
 
+// What one sub-batch of a split call still has to replay once its prologue is enqueued: the caller
+// interleaves the graph launches of all sub-batches (see the split branch of cell_forward_impl).
+struct FwdPlan {
+    hipGraphExec_t exec_n = nullptr, exec_1 = nullptr;
+    int fpg = 1, n_full = 0, n_rem = 0;
+};
+
 static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
                                  float mask_value, const void* params, const float* log_h0,
                                  float u0_diag, float u0_off, float uk_off, float* h_out,
                                  void* workspace, size_t workspace_bytes, void* stream_,
                                  int profile_frames, float* out_us,
                                  const float* initial_state = nullptr, float* final_state = nullptr,
-                                 bool allow_split = true) {
+                                 bool allow_split = true, FwdPlan* plan = nullptr) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = persist_check_flag(h);
     if (rc) return rc;
@@ -1059,21 +1066,62 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         if (!h->fork_ev) DRNMF_HIP(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
         DRNMF_HIP(h, hipEventRecord(h->fork_ev, stream));
         const size_t width = (size_t)d->N * (d->return_all_hidden ? d->K : 1);
+        // every sub-batch may add two graphs to the cache: make the room once, up front, so that no
+        // insertion below retires an executable another sub-batch's plan still holds
+        {
+            const int32_t erc = graph_cache_make_room(h, stream, 24 - 2 * (size_t)W.split);
+            if (erc) return erc;
+        }
         int32_t first_err = DRNMF_OK;
+        FwdPlan plans[MAX_SPLIT];
+        hipStream_t sts[MAX_SPLIT];
+        int nsub = 0;
         for (int sidx = 0; sidx < W.split; ++sidx) {
             const int b0 = sidx * W.split_rows;
             if (b0 >= d->B) break;
             drnmf_cell_desc_t ds = *d;
             ds.B = (d->B - b0 < W.split_rows) ? d->B - b0 : W.split_rows;
             hipStream_t st = sidx == 0 ? stream : h->side_stream[sidx - 1];
+            sts[sidx] = st;
             if (sidx > 0) DRNMF_HIP(h, hipStreamWaitEvent(st, h->fork_ev, 0));
+            // prologue (input packing, initial state) enqueued; the frame graphs come back as a plan
             const int32_t src = cell_forward_impl(
                 h, &ds, x + (size_t)b0 * d->T * d->F, mask_value, params, log_h0, u0_diag, u0_off, uk_off,
                 h_out + (size_t)b0 * d->T * width, (char*)workspace + (size_t)sidx * W.split_bytes,
                 W.split_bytes, (void*)st, 0, nullptr,
-                initial_state ? initial_state + (size_t)b0 * d->N : nullptr,
-                final_state ? final_state + (size_t)b0 * d->N : nullptr, false);
+                initial_state ? initial_state + (size_t)b0 * d->N : nullptr, nullptr, false, &plans[sidx]);
             if (src && !first_err) first_err = src;
+            if (src) plans[sidx] = FwdPlan{};
+            nsub = sidx + 1;
+        }
+        // Round-robin over the sub-batches, one graph launch (a block of frames) each: a host that
+        // enqueued one sub-batch's whole sequence first would fill the hardware queue with it (T = 2000:
+        // ~100 k packets) and the side streams would only start when the first was nearly done --
+        // measured: the 250 x 2000 slab at 445 k frames/s, against 656 k with 200-frame sequences.
+        {
+            int most = 0;
+            for (int i = 0; i < nsub; ++i) most = plans[i].n_full > most ? plans[i].n_full : most;
+            for (int c = 0; c < most && !first_err; ++c)
+                for (int i = 0; i < nsub; ++i)
+                    if (c < plans[i].n_full) DRNMF_HIP(h, hipGraphLaunch(plans[i].exec_n, sts[i]));
+            most = 0;
+            for (int i = 0; i < nsub; ++i) most = plans[i].n_rem > most ? plans[i].n_rem : most;
+            for (int c = 0; c < most && !first_err; ++c)
+                for (int i = 0; i < nsub; ++i)
+                    if (c < plans[i].n_rem) DRNMF_HIP(h, hipGraphLaunch(plans[i].exec_1, sts[i]));
+        }
+        for (int sidx = 0; sidx < nsub; ++sidx) {
+            const int b0 = sidx * W.split_rows;
+            hipStream_t st = sts[sidx];
+            if (final_state && !first_err) {
+                drnmf_cell_desc_t ds = *d;
+                ds.B = (d->B - b0 < W.split_rows) ? d->B - b0 : W.split_rows;
+                const Workspace Ws = workspace_layout(&ds, false);
+                const size_t tot = (size_t)ds.B * d->N;
+                hipLaunchKernelGGL(store_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)((char*)workspace + (size_t)sidx * W.split_bytes + Ws.off_state),
+                                   final_state + (size_t)b0 * d->N, ds.B, d->N, Ws.Np);
+            }
             // (join also after a failed sub-call: the caller's stream must not run ahead of side work)
             if (sidx > 0) {
                 DRNMF_HIP(h, hipEventRecord(h->join_ev[sidx - 1], st));
@@ -1295,8 +1343,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     for (auto& g : h->graphs)
         if (g.key == gkey) { entry = &g; break; }
     if (!entry) {
-        {   // bounded cache: the oldest entry is retired without synchronising (common.h)
-            const int32_t erc = graph_cache_make_room(h, stream, 24);
+        if (!plan) {   // bounded cache: the oldest entry is retired without synchronising (common.h)
+            const int32_t erc = graph_cache_make_room(h, stream, 24);   // (plan mode: the caller made room)
             if (erc) return erc;
         }
         GraphEntry ge;
@@ -1346,6 +1394,18 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     hipGraphExec_t exec_n = nullptr, exec_1 = nullptr;
     int32_t grc = get_graph(fpg_max, &exec_n);
     if (grc) return grc;
+    if (plan) {
+        plan->exec_n = exec_n;
+        plan->fpg = fpg_max;
+        plan->n_full = d->T / fpg_max;
+        plan->n_rem = d->T % fpg_max;
+        if (plan->n_rem) {
+            grc = get_graph(1, &exec_1);
+            if (grc) return grc;
+            plan->exec_1 = exec_1;
+        }
+        return DRNMF_OK;
+    }
     int t = 0;
     for (; t + fpg_max <= d->T; t += fpg_max) DRNMF_HIP(h, hipGraphLaunch(exec_n, stream));
     if (t < d->T) {

@@ -24,6 +24,7 @@ namespace {
 constexpr int ROWS = 16;    // batch rows per workgroup (one MFMA M tile)
 constexpr int ATOMS = 32;   // atoms per cell_a workgroup
 constexpr int MAX_KS = 8;
+constexpr int MAX_SPLIT = 8;   // sub-batches of a large inference batch (Workspace::split)
 constexpr int NW_B = 8;    // waves per cell_b workgroup (more requests in flight per CU)
 constexpr int NW_A = 4;    // waves per cell_a workgroup (8 measured slower, twice: 224k vs 232k, later 259k vs 277k frames/s)
 
@@ -508,10 +509,13 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
         // measured (profiles/r04b_split_sweep.txt; cell + head, T = 200, k frames/s with 1 / 2 / 3 / 4
         // sub-batches): B = 128 426 / 491 / 490 / 362, 192 469 / 546 / 569 / 574, 250 580 / 656 / 598 / 600,
         // 384 622 / 740 / 743 / 715, 512 727 / 765 / 786 / 779, 1024 657 / 928 / 929 / 937
-        int S = d->B >= 896 ? 4 : (d->B >= 448 ? 3 : (d->B >= 128 ? 2 : 1));
+        // -- sub-batches of ~256 rows from 896 rows on (beyond that one sub-batch's h no longer fits the
+        // 4 MB L2 of an XCD next to its dictionary slices: B = 1024 unsplit runs at 36 % L2 hit rate in cell_b)
+        int S = d->B >= 896 ? (d->B + 128) / 256 : (d->B >= 448 ? 3 : (d->B >= 128 ? 2 : 1));
+        if (S > MAX_SPLIT) S = MAX_SPLIT;
         if (const char* e = tune_env("DRNMF_SPLIT")) {      // tuning aid: force the number of sub-batches
             const int v = atoi(e);
-            if (v >= 1 && v <= 4) S = v;
+            if (v >= 1 && v <= MAX_SPLIT) S = v;
         }
         while (S > 1 && d->B < 32 * S) --S;
         if (S > 1) {

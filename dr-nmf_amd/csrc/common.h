@@ -157,8 +157,8 @@ struct drnmf_handle_s {
     int persist_lock_fd = -1;
     // side streams + fork / join events of the sub-batch split of large inference batches
     // (cell_shared.h Workspace::split), created at first use, destroyed with the handle
-    hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t side_stream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 // Tuning / measurement aids are read from the environment ONCE per process (at

@@ -206,7 +206,7 @@ extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
     }
     for (auto& e : h->fft_event)
         if (e) (void)hipEventDestroy(e);
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 7; ++i) {
         if (h->side_stream[i]) { (void)hipStreamSynchronize(h->side_stream[i]); (void)hipStreamDestroy(h->side_stream[i]); }
         if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
     }

@@ -461,7 +461,10 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
 // =====================================================================================================
 namespace {
 
-constexpr int TR_SPLITS = 8;
+// split-K count of the W-update statistics' TN products (contraction over the n frames): chosen per shape
+// so that tiles x splits fills the chip in whole rounds (gemm_tn::pick_splits; 513 x 1000 on 32k frames: 12)
+constexpr int TR_MAX_SPLITS = 64;
+static inline int tr_splits(int64_t n, int Fp4, int N) { return gemm_tn::pick_splits(Fp4, N, n, TR_MAX_SPLITS); }
 
 struct EpiPartTN {
     float* P;
@@ -483,57 +486,96 @@ colsum_rows_kernel(const float* __restrict__ H, float* __restrict__ part, int64_
     const int64_t r0 = blockIdx.y * per;
     int64_t r1 = r0 + per;
     if (r1 > n) r1 = n;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += H[r * N + col];
-    part[(size_t)blockIdx.y * N + col] = s;
+    // eight rows in flight per thread (one dependent load per row ran the 131-MB H of a 32k-frame KL
+    // iteration at 0.84 TB/s); the eight chains are added in a fixed order
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = H[(r + u) * N + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += v[u];
+    }
+    for (; r < r1; ++r) s8[0] += H[r * N + col];
+    part[(size_t)blockIdx.y * N + col] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
 }
 
-// W update of one column (sparse_nmf_gpu.m:232-262) + L2 renormalisation of every column:
+// W update (sparse_nmf_gpu.m:232-262) + L2 renormalisation of every column:
 //   dpw = DEN + W * sum_f(NUM * W);  dmw = NUM + W * sum_f(DEN * W);  W <- W * dmw / max(dpw, flr)
-// NUM/DEN are sums of TR_SPLITS partial [Fp4][N] buffers; for beta == 1, DEN[f][n] = hs[n].
+// NUM/DEN are sums of the split-K partial [Fp4][N] buffers; for beta == 1, DEN[f][n] = hs[n].
+// Three passes over (atom, group of W_FB bins) -- fold + the two per-atom sums; apply + sum of squares;
+// scale -- each on (N/256) x (F/W_FB) workgroups with per-group partials summed in a fixed order.  (One
+// thread per atom walking all F bins and 2 x 8 partial buffers, twice, ran a 513 x 1000
+// dictionary on FOUR workgroups: 0.80 ms of a 3.4-ms iteration, profiles/r04c_snmf_train_kernel_stats.csv.)
+constexpr int W_FB = 8;
 __global__ void __launch_bounds__(256)
-w_update_kernel(float* __restrict__ W, const float* __restrict__ PN, const float* __restrict__ PD,
-                const float* __restrict__ hs_part, const unsigned char* __restrict__ upd, int F,
-                int N, size_t stride, int hs_splits, int beta_is_one, float flr) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+w_fold_kernel(const float* __restrict__ W, float* __restrict__ PN, float* __restrict__ PD,
+              const float* __restrict__ hs_part, float* __restrict__ wpart, int F, int N, size_t stride,
+              int hs_splits, int beta_is_one, int nsplit) {
+    const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (n >= N) return;
+    float hs = 0.f;
+    if (beta_is_one)
+        for (int s = 0; s < hs_splits; ++s) hs += hs_part[(size_t)s * N + n];
+    float sn = 0.f, sd = 0.f;
+    const int f1 = (g + 1) * W_FB < F ? (g + 1) * W_FB : F;
+    for (int f = g * W_FB; f < f1; ++f) {
+        const size_t o = (size_t)f * N + n;
+        float num = 0.f, den = hs;
+        for (int s = 0; s < nsplit; ++s) num += PN[s * stride + o];
+        PN[o] = num;                                   // (folded in place: slot 0)
+        if (!beta_is_one) {
+            den = 0.f;
+            for (int s = 0; s < nsplit; ++s) den += PD[s * stride + o];
+            PD[o] = den;
+        }
+        const float w = W[o];
+        sn = fmaf(num, w, sn);
+        sd = fmaf(den, w, sd);
+    }
+    wpart[((size_t)g * 3 + 0) * N + n] = sn;
+    wpart[((size_t)g * 3 + 1) * N + n] = sd;
+    if (g == 0 && beta_is_one) wpart[((size_t)gridDim.y * 3) * N + n] = hs;     // DEN of every bin
+}
+__global__ void __launch_bounds__(256)
+w_apply_kernel(float* __restrict__ W, const float* __restrict__ PN, const float* __restrict__ PD,
+               float* __restrict__ wpart, const unsigned char* __restrict__ upd, int F, int N,
+               int beta_is_one, float flr) {
+    const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, ng = gridDim.y;
     if (n >= N) return;
     const bool do_upd = upd ? upd[n] != 0 : true;
-    if (do_upd) {
-        float hs = 0.f;
-        if (beta_is_one)
-            for (int s = 0; s < hs_splits; ++s) hs += hs_part[(size_t)s * N + n];
-        float sn = 0.f, sd = 0.f;
-        for (int f = 0; f < F; ++f) {
-            float num = 0.f, den = hs;
-            for (int s = 0; s < TR_SPLITS; ++s) num += PN[s * stride + (size_t)f * N + n];
-            if (!beta_is_one) {
-                den = 0.f;
-                for (int s = 0; s < TR_SPLITS; ++s) den += PD[s * stride + (size_t)f * N + n];
-            }
-            const float w = W[(size_t)f * N + n];
-            sn = fmaf(num, w, sn);
-            sd = fmaf(den, w, sd);
-        }
-        for (int f = 0; f < F; ++f) {
-            float num = 0.f, den = hs;
-            for (int s = 0; s < TR_SPLITS; ++s) num += PN[s * stride + (size_t)f * N + n];
-            if (!beta_is_one) {
-                den = 0.f;
-                for (int s = 0; s < TR_SPLITS; ++s) den += PD[s * stride + (size_t)f * N + n];
-            }
-            const float w = W[(size_t)f * N + n];
+    float sn = 0.f, sd = 0.f;
+    for (int q = 0; q < ng; ++q) {
+        sn += wpart[((size_t)q * 3 + 0) * N + n];
+        sd += wpart[((size_t)q * 3 + 1) * N + n];
+    }
+    const float hs = beta_is_one ? wpart[((size_t)ng * 3) * N + n] : 0.f;
+    float s2 = 0.f;
+    const int f1 = (g + 1) * W_FB < F ? (g + 1) * W_FB : F;
+    for (int f = g * W_FB; f < f1; ++f) {
+        const size_t o = (size_t)f * N + n;
+        float w = W[o];
+        if (do_upd) {
+            const float num = PN[o], den = beta_is_one ? hs : PD[o];
             const float dpw = fmaxf(den + w * sn, flr);
             const float dmw = num + w * sd;
-            W[(size_t)f * N + n] = w * dmw / dpw;
+            w = w * dmw / dpw;
+            W[o] = w;
         }
-    }
-    float s2 = 0.f;
-    for (int f = 0; f < F; ++f) {
-        const float w = W[(size_t)f * N + n];
         s2 = fmaf(w, w, s2);
     }
+    wpart[((size_t)g * 3 + 2) * N + n] = s2;
+}
+__global__ void __launch_bounds__(256)
+w_norm_kernel(float* __restrict__ W, const float* __restrict__ wpart, int F, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, ng = gridDim.y;
+    if (n >= N) return;
+    float s2 = 0.f;
+    for (int q = 0; q < ng; ++q) s2 += wpart[((size_t)q * 3 + 2) * N + n];
     const float inv = 1.f / sqrtf(s2);
-    for (int f = 0; f < F; ++f) W[(size_t)f * N + n] *= inv;
+    const int f1 = (g + 1) * W_FB < F ? (g + 1) * W_FB : F;
+    for (int f = g * W_FB; f < f1; ++f) W[(size_t)f * N + n] *= inv;
 }
 
 // objective partials: div (beta-divergence between V and lambda) and sum(H)
@@ -601,7 +643,7 @@ constexpr int OBJ_BLOCKS = 1024, HS_SPLITS = 64;
 
 struct TrWs {
     size_t off_P1, off_P2, off_LAM, off_Vp, off_Wt, off_DMH, off_norm, off_colsum, off_PN, off_PD,
-        off_hs, off_obj, off_min, total;
+        off_hs, off_obj, off_min, off_wpart, total;
     int Fp4;
 };
 TrWs tr_ws(int64_t n, int F, int N) {
@@ -615,11 +657,13 @@ TrWs tr_ws(int64_t n, int F, int N) {
     w.off_DMH = take((size_t)n * N * 4);
     w.off_norm = take((size_t)N * 4);
     w.off_colsum = take((size_t)N * 4);
-    w.off_PN = take((size_t)TR_SPLITS * w.Fp4 * N * 4);
-    w.off_PD = take((size_t)TR_SPLITS * w.Fp4 * N * 4);
+    const int nsplit = tr_splits(n, w.Fp4, N);
+    w.off_PN = take((size_t)nsplit * w.Fp4 * N * 4);
+    w.off_PD = take((size_t)nsplit * w.Fp4 * N * 4);
     w.off_hs = take((size_t)HS_SPLITS * N * 4);
     w.off_obj = take((size_t)OBJ_BLOCKS * 2 * 4);
     w.off_min = take(256);
+    w.off_wpart = take(((size_t)((F + W_FB - 1) / W_FB) * 3 + 1) * N * 4);
     w.total = o;
     return w;
 }
@@ -729,18 +773,27 @@ extern "C" int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F,
     // ---- W update (:232-264) -------------------------------------------------------------------
     if (update_w) {
         const size_t pstr = (size_t)Fp4 * N;
+        const int nsplit = tr_splits(n, Fp4, N);
         const float* num_src = beta == 2.f ? Vp : (beta == 1.f ? P1 : P2);
         gemm_tn::Operands tn{num_src, H, n, Fp4, N, Fp4, N};
-        DRNMF_HIP(h, gemm_tn::launch(tn, EpiPartTN{PN, N, pstr}, TR_SPLITS, stream));
+        DRNMF_HIP(h, gemm_tn::launch(tn, EpiPartTN{PN, N, pstr}, nsplit, stream));
         if (beta == 1.f) {
             hipLaunchKernelGGL(colsum_rows_kernel, dim3((N + 255) / 256, HS_SPLITS), dim3(256), 0,
                                stream, H, hs, n, N, HS_SPLITS);
         } else {
             gemm_tn::Operands td{P1, H, n, Fp4, N, Fp4, N};
-            DRNMF_HIP(h, gemm_tn::launch(td, EpiPartTN{PD, N, pstr}, TR_SPLITS, stream));
+            DRNMF_HIP(h, gemm_tn::launch(td, EpiPartTN{PD, N, pstr}, nsplit, stream));
         }
-        hipLaunchKernelGGL(w_update_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, W, PN, PD, hs,
-                           w_update_mask, F, N, pstr, HS_SPLITS, beta == 1.f ? 1 : 0, flr);
+        {
+            float* wpart = (float*)(ws + L.off_wpart);
+            const dim3 wgrid((N + 255) / 256, (F + W_FB - 1) / W_FB);
+            const int b1 = beta == 1.f ? 1 : 0;
+            hipLaunchKernelGGL(w_fold_kernel, wgrid, dim3(256), 0, stream, W, PN, PD, hs, wpart, F, N, pstr,
+                               HS_SPLITS, b1, nsplit);
+            hipLaunchKernelGGL(w_apply_kernel, wgrid, dim3(256), 0, stream, W, PN, PD, wpart, w_update_mask,
+                               F, N, b1, flr);
+            hipLaunchKernelGGL(w_norm_kernel, wgrid, dim3(256), 0, stream, W, wpart, F, N);
+        }
         hipLaunchKernelGGL(transpose_pad_kernel, dim3((Fp4 + 31) / 32, (N + 31) / 32), dim3(256), 0,
                            stream, W, Wt, F, N, Fp4);
         DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream));   // (:263)

@@ -4,7 +4,8 @@ no stream synchronisation and no device-to-host copy inside train_on_batch.
 Runs 3 warm-up steps, synchronises, then `steps` steps WITHOUT reading a loss, and prints the number of
 synchronising HIP calls the host made in between (counted by wrapping torch.cuda.synchronize /
 Tensor.tolist / Tensor.item / Tensor.cpu at the Python level; the rocprofv3 trace of the same command
-is the authoritative count: profiles/r04_step_hip_api_stats.csv)."""
+is the authoritative count: run it with steps = 0 and steps = 20 and subtract the per-API call counts --
+tools/hip_api_delta.py, profiles/r04_step_hip_api_delta.txt)."""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -44,6 +45,6 @@ print("MARK steady-state steps enqueued", flush=True)
 for n in orig:
     setattr(torch.Tensor, n, orig[n])
 torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / steps
+ms = e0.elapsed_time(e1) / max(steps, 1)
 print("shape", sys.argv[1:6], "%d steps: %.3f ms per step; host-side synchronising tensor reads inside the steps: %s;"
-      " losses %.6g -> %.6g" % (steps, ms, counts, float(losses[0]), float(losses[-1])))
+      " losses %s" % (steps, ms, counts, ("%.6g -> %.6g" % (float(losses[0]), float(losses[-1]))) if losses else "-"))
