@@ -67,6 +67,14 @@ __device__ __forceinline__ f32x4 load4(const float* base, int64_t row, int64_t n
 // outside the k-tiles -- one extra MFMA step per output tile whose two k slots are those columns,
 // fragments fetched straight from global memory with the early loads.  This is how the odd bins of
 // a 2^k+1 STFT (K = 513 = 16 tiles + 1) ride along without a 17th, almost empty k-tile.
+// `static constexpr bool REDUCE = true` in the functor: its operator() RETURNS a float per output element;
+// the kernel sums them per thread (fixed order), per workgroup (LDS tree, fixed order) and stores ONE
+// partial per workgroup at epi.red_out[blockIdx.x] -- a grid-wide sum (the objective of the dictionary
+// training) rides on a GEMM's epilogue instead of costing its own pass over the outputs; deterministic.
+template <class E, class = void> struct epi_reduce : std::false_type {};
+template <class E> struct epi_reduce<E, std::void_t<decltype(E::REDUCE)>>
+    : std::integral_constant<bool, E::REDUCE> {};
+
 template <class E, class = void> struct epi_early : std::true_type {};
 template <class E> struct epi_early<E, std::void_t<decltype(E::EARLY)>>
     : std::integral_constant<bool, E::EARLY> {};
@@ -241,6 +249,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
     // column l&31.  Row indices are formed in 32 bits (launch() refuses M >= 2^31): the functors'
     // row * ld then is one 32 x 32 -> 64-bit multiply-add instead of a 64 x 32-bit product.
     constexpr bool EARLY = epi_early<Epi>::value;
+    constexpr bool RED = epi_reduce<Epi>::value;
+    float red = 0.f;
     const int M32 = (int)g.M, m032 = (int)m0;
     auto rowof = [&](int a, int v) { return m032 + wm * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk; };
     auto colof = [&](int b) { return n0 + wn * 64 + b * 32 + li; };
@@ -307,12 +317,25 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
                     // opaque copy: the store addresses are formed again here instead of 64 64-bit
                     // load addresses staying live across the MFMAs (that cost the second wave per SIMD)
                     if (EARLY) asm volatile("" : "+v"(row));
-                    if (FULL || row < M32) epi(row, col, acc[a][b][v], pv[EARLY ? a : 0][EARLY ? b : 0][v]);
+                    if (FULL || row < M32) {
+                        if constexpr (RED) red += epi(row, col, acc[a][b][v], pv[EARLY ? a : 0][EARLY ? b : 0][v]);
+                        else epi(row, col, acc[a][b][v], pv[EARLY ? a : 0][EARLY ? b : 0][v]);
+                    }
                 }
             }
     };
     if (m032 + BM <= M32) finish(std::true_type{});
     else finish(std::false_type{});
+    if constexpr (RED) {
+        __syncthreads();                       // every wave is done with the staged tiles
+        lds[tid] = red;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) lds[tid] += lds[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) epi.red_out[blockIdx.x] = lds[0];
+    }
 }
 
 template <class Epi>

@@ -148,6 +148,37 @@ struct EpiLambda {   // lambda = max(W H, flr) and its beta-dependent derivative
     }
 };
 
+// The same with the objective's divergence term D(V | lambda) summed on the way (gemm_nt.h REDUCE): the
+// lambda of sparse_nmf_gpu.m:263 is the one its objective (:267-281) is evaluated on, so the training
+// iteration needs no separate pass over V and lambda.  beta == 2: lambda is written once (P1).
+template <int BC>
+struct EpiLambdaObj {
+    const float* V;
+    float* P1;
+    float* P2;
+    float* red_out;      // one partial per workgroup
+    int F, ld;
+    float beta, flr;
+    static constexpr bool REDUCE = true;
+    __device__ f32x2 pre(int64_t row, int col) const { return f32x2{V[row * F + col], 0.f}; }
+    __device__ float operator()(int64_t row, int col, float acc, f32x2 pv) const {
+        const float lam = fmaxf(acc, flr), v = pv[0];
+        const size_t o = row * ld + col;
+        if (BC == 2) {
+            P1[o] = lam;
+            return (v - lam) * (v - lam);
+        } else if (BC == 1) {
+            P1[o] = v / lam;
+            return v * logf(v / lam) - v + lam;
+        }
+        P1[o] = powf(lam, beta - 1.f);
+        P2[o] = v * powf(lam, beta - 2.f);
+        if (beta == 0.f) return v / lam - logf(v / lam) - 1.f;
+        return (powf(v, beta) + (beta - 1.f) * powf(lam, beta) - beta * v * powf(lam, beta - 1.f)) /
+               (beta * (beta - 1.f));
+    }
+};
+
 template <int BC>
 struct EpiMuUpdate {   // H <- H * dmh / max(dph + sparsity, flr): sparse_nmf_gpu.m:217-227
     float* H;
@@ -162,6 +193,28 @@ struct EpiMuUpdate {   // H <- H * dmh / max(dph + sparsity, flr): sparse_nmf_gp
     __device__ void operator()(int64_t row, int col, float acc, f32x2 pv) const {
         if (BC == 1) H[row * N + col] = pv[0] * acc / fmaxf(pv[1] + sparsity, flr);
         else H[row * N + col] = pv[0] * pv[1] / fmaxf(acc + sparsity, flr);
+    }
+};
+
+// H update with sum(H) -- the sparsity term of the objective -- summed on the way (gemm_nt.h REDUCE)
+template <int BC>
+struct EpiMuUpdateSum {
+    float* H;
+    const float* DMH;
+    const float* colsum;
+    float* red_out;
+    int N;
+    float sparsity, flr;
+    static constexpr bool EARLY = BC == 1;
+    static constexpr bool REDUCE = true;
+    __device__ f32x2 pre(int64_t row, int col) const {
+        return f32x2{H[row * N + col], BC == 1 ? colsum[col] : DMH[row * N + col]};
+    }
+    __device__ float operator()(int64_t row, int col, float acc, f32x2 pv) const {
+        const float hn = BC == 1 ? pv[0] * acc / fmaxf(pv[1] + sparsity, flr)
+                                 : pv[0] * pv[1] / fmaxf(acc + sparsity, flr);
+        H[row * N + col] = hn;
+        return hn;
     }
 };
 
@@ -476,6 +529,50 @@ struct EpiPartTN {
     }
 };
 
+// Odd rows of the W-update statistics.  F = 2^k + 1 bins put ONE row (4 with the padding to Fp4) into a
+// fifth 128-row tile of the two TN products NUM = V'^T H, DEN = P1^T H -- a fifth of their time for
+// 1/128 of a tile.  The TN products cover the first Mg = F - F % 128 rows; the 1..TN_TAIL_MAX rows
+// behind them are dot products of H's columns with single columns of V' / P1, one streaming pass over H
+// shared by both statistics: tailp[split][src][j][n], TT_SPLITS row ranges, summed by w_fold_kernel.
+constexpr int TN_TAIL_MAX = 4, TT_SPLITS = 64;
+static inline int tn_tail_rows(int F) { return (F > 128 && F % 128 >= 1 && F % 128 <= TN_TAIL_MAX) ? F % 128 : 0; }
+__global__ void __launch_bounds__(256)
+tn_tail_kernel(const float* __restrict__ A0, const float* __restrict__ A1, const float* __restrict__ H,
+               float* __restrict__ tailp, int64_t n, int N, int lda, int Mg, int ntail) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    const int64_t per = (n + TT_SPLITS - 1) / TT_SPLITS;
+    const int64_t r0 = blockIdx.y * per;
+    int64_t r1 = r0 + per;
+    if (r1 > n) r1 = n;
+    float a0[TN_TAIL_MAX] = {0.f, 0.f, 0.f, 0.f}, a1[TN_TAIL_MAX] = {0.f, 0.f, 0.f, 0.f};
+    int64_t t = r0;
+    for (; t + 4 <= r1; t += 4) {
+        float hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hv[u] = H[(t + u) * N + col];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < TN_TAIL_MAX; ++j) {
+                if (j >= ntail) break;
+                a0[j] = fmaf(A0[(t + u) * lda + Mg + j], hv[u], a0[j]);      // (wave-uniform address)
+                if (A1) a1[j] = fmaf(A1[(t + u) * lda + Mg + j], hv[u], a1[j]);
+            }
+    }
+    for (; t < r1; ++t) {
+        const float h = H[t * N + col];
+        for (int j = 0; j < ntail; ++j) {
+            a0[j] = fmaf(A0[t * lda + Mg + j], h, a0[j]);
+            if (A1) a1[j] = fmaf(A1[t * lda + Mg + j], h, a1[j]);
+        }
+    }
+    for (int j = 0; j < ntail; ++j) {
+        tailp[(((size_t)blockIdx.y * 2 + 0) * TN_TAIL_MAX + j) * N + col] = a0[j];
+        tailp[(((size_t)blockIdx.y * 2 + 1) * TN_TAIL_MAX + j) * N + col] = a1[j];
+    }
+}
+
 // column sums over frames of H: hs[n] (beta == 1 W update)
 __global__ void __launch_bounds__(256)
 colsum_rows_kernel(const float* __restrict__ H, float* __restrict__ part, int64_t n, int N,
@@ -512,7 +609,7 @@ constexpr int W_FB = 8;
 __global__ void __launch_bounds__(256)
 w_fold_kernel(const float* __restrict__ W, float* __restrict__ PN, float* __restrict__ PD,
               const float* __restrict__ hs_part, float* __restrict__ wpart, int F, int N, size_t stride,
-              int hs_splits, int beta_is_one, int nsplit) {
+              int hs_splits, int beta_is_one, int nsplit, const float* __restrict__ tailp, int Mg) {
     const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (n >= N) return;
     float hs = 0.f;
@@ -523,11 +620,19 @@ w_fold_kernel(const float* __restrict__ W, float* __restrict__ PN, float* __rest
     for (int f = g * W_FB; f < f1; ++f) {
         const size_t o = (size_t)f * N + n;
         float num = 0.f, den = hs;
-        for (int s = 0; s < nsplit; ++s) num += PN[s * stride + o];
+        if (f >= Mg) {                                 // odd rows: tn_tail_kernel's partials
+            for (int s = 0; s < TT_SPLITS; ++s) num += tailp[(((size_t)s * 2 + 0) * TN_TAIL_MAX + (f - Mg)) * N + n];
+        } else {
+            for (int s = 0; s < nsplit; ++s) num += PN[s * stride + o];
+        }
         PN[o] = num;                                   // (folded in place: slot 0)
         if (!beta_is_one) {
             den = 0.f;
-            for (int s = 0; s < nsplit; ++s) den += PD[s * stride + o];
+            if (f >= Mg) {
+                for (int s = 0; s < TT_SPLITS; ++s) den += tailp[(((size_t)s * 2 + 1) * TN_TAIL_MAX + (f - Mg)) * N + n];
+            } else {
+                for (int s = 0; s < nsplit; ++s) den += PD[s * stride + o];
+            }
             PD[o] = den;
         }
         const float w = W[o];
@@ -578,51 +683,14 @@ w_norm_kernel(float* __restrict__ W, const float* __restrict__ wpart, int F, int
     for (int f = g * W_FB; f < f1; ++f) W[(size_t)f * N + n] *= inv;
 }
 
-// objective partials: div (beta-divergence between V and lambda) and sum(H)
+// objective from the per-workgroup partials of the two fused reductions (EpiLambdaObj, EpiMuUpdateSum)
 __global__ void __launch_bounds__(256)
-objective_kernel(const float* __restrict__ Vp, const float* __restrict__ LAM,
-                 const float* __restrict__ H, int64_t n, int F, int Fp4, int N, float beta,
-                 float* __restrict__ part) {
-    __shared__ double sd[256], sh[256];
-    double d = 0.0, hsum = 0.0;
-    const int64_t totV = n * (int64_t)Fp4, totH = n * (int64_t)N;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < totV; i += (int64_t)gridDim.x * 256) {
-        if ((int)(i % Fp4) >= F) continue;
-        const float v = Vp[i], l = LAM[i];
-        float e;
-        if (beta == 2.f) e = (v - l) * (v - l);
-        else if (beta == 1.f) e = v * logf(v / l) - v + l;
-        else if (beta == 0.f) e = v / l - logf(v / l) - 1.f;
-        else e = (powf(v, beta) + (beta - 1.f) * powf(l, beta) - beta * v * powf(l, beta - 1.f)) /
-                 (beta * (beta - 1.f));
-        d += (double)e;
-    }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < totH; i += (int64_t)gridDim.x * 256)
-        hsum += (double)H[i];
-    sd[threadIdx.x] = d;
-    sh[threadIdx.x] = hsum;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            sd[threadIdx.x] += sd[threadIdx.x + o];
-            sh[threadIdx.x] += sh[threadIdx.x + o];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = (float)sd[0];
-        part[2 * blockIdx.x + 1] = (float)sh[0];
-    }
-}
-__global__ void __launch_bounds__(256)
-objective_final_kernel(const float* __restrict__ part, int nblocks, float sparsity,
-                       float* __restrict__ obj) {
+objective_final2_kernel(const float* __restrict__ dpart, int nd, const float* __restrict__ hpart, int nh,
+                        float sparsity, float* __restrict__ obj) {
     __shared__ double sd[256], sh[256];
     double d = 0.0, hs = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) {
-        d += (double)part[2 * i];
-        hs += (double)part[2 * i + 1];
-    }
+    for (int i = threadIdx.x; i < nd; i += 256) d += (double)dpart[i];
+    for (int i = threadIdx.x; i < nh; i += 256) hs += (double)hpart[i];
     sd[threadIdx.x] = d;
     sh[threadIdx.x] = hs;
     __syncthreads();
@@ -639,11 +707,11 @@ objective_final_kernel(const float* __restrict__ part, int nblocks, float sparsi
     }
 }
 
-constexpr int OBJ_BLOCKS = 1024, HS_SPLITS = 64;
+constexpr int HS_SPLITS = 64;
 
 struct TrWs {
-    size_t off_P1, off_P2, off_LAM, off_Vp, off_Wt, off_DMH, off_norm, off_colsum, off_PN, off_PD,
-        off_hs, off_obj, off_min, off_wpart, total;
+    size_t off_P1, off_P2, off_Vp, off_Wt, off_DMH, off_norm, off_colsum, off_PN, off_PD,
+        off_hs, off_obj, off_min, off_wpart, off_tailp, total;
     int Fp4;
 };
 TrWs tr_ws(int64_t n, int F, int N) {
@@ -652,18 +720,19 @@ TrWs tr_ws(int64_t n, int F, int N) {
     size_t o = 0;
     auto take = [&](size_t b) { size_t at = o; o += round_up_sz(b, 256); return at; };
     const size_t nf = (size_t)n * w.Fp4 * 4;
-    w.off_P1 = take(nf); w.off_P2 = take(nf); w.off_LAM = take(nf); w.off_Vp = take(nf);
+    w.off_P1 = take(nf); w.off_P2 = take(nf); w.off_Vp = take(nf);
     w.off_Wt = take((size_t)N * w.Fp4 * 4);
     w.off_DMH = take((size_t)n * N * 4);
     w.off_norm = take((size_t)N * 4);
     w.off_colsum = take((size_t)N * 4);
-    const int nsplit = tr_splits(n, w.Fp4, N);
+    const int nsplit = tr_splits(n, tn_tail_rows(F) ? F - tn_tail_rows(F) : w.Fp4, N);
     w.off_PN = take((size_t)nsplit * w.Fp4 * N * 4);
     w.off_PD = take((size_t)nsplit * w.Fp4 * N * 4);
     w.off_hs = take((size_t)HS_SPLITS * N * 4);
-    w.off_obj = take((size_t)OBJ_BLOCKS * 2 * 4);
+    w.off_obj = take((size_t)((n + 127) / 128) * (((F + 127) / 128) + ((N + 127) / 128)) * 4);
     w.off_min = take(256);
     w.off_wpart = take(((size_t)((F + W_FB - 1) / W_FB) * 3 + 1) * N * 4);
+    w.off_tailp = take((size_t)TT_SPLITS * 2 * TN_TAIL_MAX * N * 4);
     w.total = o;
     return w;
 }
@@ -679,6 +748,18 @@ hipError_t lambda_train(const gemm::Operands& gl, const float* Vp, float* P1, fl
     if (beta == 2.f) return launch_lambda_train<2>(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream);
     if (beta == 1.f) return launch_lambda_train<1>(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream);
     return launch_lambda_train<0>(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream);
+}
+
+template <int BC>
+hipError_t launch_lambda_obj(const gemm::Operands& gl, const float* Vp, float* P1, float* P2, float* dpart,
+                             int Fp4, float beta, float flr, hipStream_t stream) {
+    return gemm::launch(gl, EpiLambdaObj<BC>{Vp, P1, P2, dpart, Fp4, Fp4, beta, flr}, stream);
+}
+hipError_t lambda_train_obj(const gemm::Operands& gl, const float* Vp, float* P1, float* P2, float* dpart,
+                            int Fp4, float beta, float flr, hipStream_t stream) {
+    if (beta == 2.f) return launch_lambda_obj<2>(gl, Vp, P1, P2, dpart, Fp4, beta, flr, stream);
+    if (beta == 1.f) return launch_lambda_obj<1>(gl, Vp, P1, P2, dpart, Fp4, beta, flr, stream);
+    return launch_lambda_obj<0>(gl, Vp, P1, P2, dpart, Fp4, beta, flr, stream);
 }
 
 }  // namespace
@@ -701,14 +782,14 @@ extern "C" int32_t drnmf_snmf_train_init(drnmf_handle_t h, int64_t n, int32_t F,
     hipStream_t stream = (hipStream_t)stream_;
     char* ws = (char*)workspace;
     float* P1 = (float*)(ws + L.off_P1); float* P2 = (float*)(ws + L.off_P2);
-    float* LAM = (float*)(ws + L.off_LAM); float* Vp = (float*)(ws + L.off_Vp);
+    float* Vp = (float*)(ws + L.off_Vp);
     float* Wt = (float*)(ws + L.off_Wt);
     float* norm = (float*)(ws + L.off_norm); float* colsum = (float*)(ws + L.off_colsum);
     unsigned* minb = (unsigned*)(ws + L.off_min);
     const int Fp4 = L.Fp4;
     const float flr = 1e-9f;
     const int64_t nH = n * (int64_t)N, nV = n * (int64_t)F;
-    DRNMF_HIP(h, hipMemsetAsync(ws, 0, L.off_Wt, stream));   // P1, P2, LAM, Vp (zero padding)
+    DRNMF_HIP(h, hipMemsetAsync(ws, 0, L.off_Wt, stream));   // P1, P2, Vp (zero padding)
     const float* Vsrc = V;
     if (beta != 2.f) {   // zeros of V are raised to its smallest positive entry (:201-205)
         DRNMF_HIP(h, hipMemsetAsync(minb, 0x7f, 4, stream));
@@ -728,7 +809,7 @@ extern "C" int32_t drnmf_snmf_train_init(drnmf_handle_t h, int64_t n, int32_t F,
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((Fp4 + 31) / 32, (N + 31) / 32), dim3(256), 0,
                        stream, W, Wt, F, N, Fp4);
     gemm::Operands gl{H, W, n, F, N, N, N};
-    DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream));   // (:173)
+    DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, nullptr, Fp4, beta, flr, stream));   // (:173)
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }
@@ -748,11 +829,14 @@ extern "C" int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F,
     hipStream_t stream = (hipStream_t)stream_;
     char* ws = (char*)workspace;
     float* P1 = (float*)(ws + L.off_P1); float* P2 = (float*)(ws + L.off_P2);
-    float* LAM = (float*)(ws + L.off_LAM); float* Vp = (float*)(ws + L.off_Vp);
+    float* Vp = (float*)(ws + L.off_Vp);
     float* Wt = (float*)(ws + L.off_Wt); float* DMH = (float*)(ws + L.off_DMH);
     float* colsum = (float*)(ws + L.off_colsum);
     float* PN = (float*)(ws + L.off_PN); float* PD = (float*)(ws + L.off_PD);
-    float* hs = (float*)(ws + L.off_hs); float* objp = (float*)(ws + L.off_obj);
+    float* hs = (float*)(ws + L.off_hs);
+    const int nd = (int)((n + 127) / 128) * ((F + 127) / 128), nh = (int)((n + 127) / 128) * ((N + 127) / 128);
+    float* dpart = (float*)(ws + L.off_obj);
+    float* hpart = dpart + nd;
     const int Fp4 = L.Fp4;
     const float flr = 1e-9f;
     gemm::Operands gl{H, W, n, F, N, N, N};
@@ -762,26 +846,34 @@ extern "C" int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F,
         hipLaunchKernelGGL(colsum_rows_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, stream, W,
                            colsum, (int64_t)F, N, 1);
         gemm::Operands gu{P1, Wt, n, N, Fp4, Fp4, Fp4};
-        DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<1>{H, DMH, colsum, N, sparsity, flr}, stream));
+        DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdateSum<1>{H, DMH, colsum, hpart, N, sparsity, flr}, stream));
     } else {
         gemm::Operands gd{beta == 2.f ? Vp : P2, Wt, n, N, Fp4, Fp4, Fp4};
         DRNMF_HIP(h, gemm::launch(gd, EpiStore{DMH, N}, stream));
         gemm::Operands gu{P1, Wt, n, N, Fp4, Fp4, Fp4};
-        DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdate<2>{H, DMH, colsum, N, sparsity, flr}, stream));
+        DRNMF_HIP(h, gemm::launch(gu, EpiMuUpdateSum<2>{H, DMH, colsum, hpart, N, sparsity, flr}, stream));
     }
-    DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream));   // (:228)
+    // (:228) -- the iteration's LAST lambda is the one the objective is evaluated on (:263, :267-281)
+    if (update_w) DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, nullptr, Fp4, beta, flr, stream));
+    else DRNMF_HIP(h, lambda_train_obj(gl, Vp, P1, P2, dpart, Fp4, beta, flr, stream));
     // ---- W update (:232-264) -------------------------------------------------------------------
     if (update_w) {
         const size_t pstr = (size_t)Fp4 * N;
-        const int nsplit = tr_splits(n, Fp4, N);
+        const int ntail = tn_tail_rows(F), Mg = ntail ? F - ntail : Fp4;
+        const int nsplit = tr_splits(n, Mg, N);
+        float* tailp = (float*)(ws + L.off_tailp);
         const float* num_src = beta == 2.f ? Vp : (beta == 1.f ? P1 : P2);
-        gemm_tn::Operands tn{num_src, H, n, Fp4, N, Fp4, N};
+        if (ntail)
+            hipLaunchKernelGGL(tn_tail_kernel, dim3((N + 255) / 256, TT_SPLITS), dim3(256), 0, stream, num_src,
+                               beta == 1.f ? (const float*)nullptr : (const float*)P1, H, tailp, n, N, Fp4, Mg,
+                               ntail);
+        gemm_tn::Operands tn{num_src, H, n, Mg, N, Fp4, N};
         DRNMF_HIP(h, gemm_tn::launch(tn, EpiPartTN{PN, N, pstr}, nsplit, stream));
         if (beta == 1.f) {
             hipLaunchKernelGGL(colsum_rows_kernel, dim3((N + 255) / 256, HS_SPLITS), dim3(256), 0,
                                stream, H, hs, n, N, HS_SPLITS);
         } else {
-            gemm_tn::Operands td{P1, H, n, Fp4, N, Fp4, N};
+            gemm_tn::Operands td{P1, H, n, Mg, N, Fp4, N};
             DRNMF_HIP(h, gemm_tn::launch(td, EpiPartTN{PD, N, pstr}, nsplit, stream));
         }
         {
@@ -789,19 +881,17 @@ extern "C" int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F,
             const dim3 wgrid((N + 255) / 256, (F + W_FB - 1) / W_FB);
             const int b1 = beta == 1.f ? 1 : 0;
             hipLaunchKernelGGL(w_fold_kernel, wgrid, dim3(256), 0, stream, W, PN, PD, hs, wpart, F, N, pstr,
-                               HS_SPLITS, b1, nsplit);
+                               HS_SPLITS, b1, nsplit, tailp, ntail ? Mg : F);
             hipLaunchKernelGGL(w_apply_kernel, wgrid, dim3(256), 0, stream, W, PN, PD, wpart, w_update_mask,
                                F, N, b1, flr);
             hipLaunchKernelGGL(w_norm_kernel, wgrid, dim3(256), 0, stream, W, wpart, F, N);
         }
         hipLaunchKernelGGL(transpose_pad_kernel, dim3((Fp4 + 31) / 32, (N + 31) / 32), dim3(256), 0,
                            stream, W, Wt, F, N, Fp4);
-        DRNMF_HIP(h, lambda_train(gl, Vp, P1, P2, LAM, Fp4, beta, flr, stream));   // (:263)
+        DRNMF_HIP(h, lambda_train_obj(gl, Vp, P1, P2, dpart, Fp4, beta, flr, stream));   // (:263)
     }
-    // ---- objective (:267-281) ------------------------------------------------------------------
-    hipLaunchKernelGGL(objective_kernel, dim3(OBJ_BLOCKS), dim3(256), 0, stream, Vp, LAM, H, n, F,
-                       Fp4, N, beta, objp);
-    hipLaunchKernelGGL(objective_final_kernel, dim3(1), dim3(256), 0, stream, objp, OBJ_BLOCKS,
+    // ---- objective (:267-281): D(V | lambda) and sum(H) were summed in the epilogues above ------
+    hipLaunchKernelGGL(objective_final2_kernel, dim3(1), dim3(256), 0, stream, dpart, nd, hpart, nh,
                        sparsity, obj);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;

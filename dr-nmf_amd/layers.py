@@ -790,7 +790,8 @@ class DeviceLoss(object):
 
     def _get(self):
         if self._value is None:
-            self._event.synchronize()
+            if not self._event.query():
+                self._event.synchronize()
             loss, fault = float(self._slot[0]), float(self._slot[1])
             if fault != 0.0:
                 raise _capi.DrnmfError(
@@ -1136,7 +1137,10 @@ class UnfoldedSNMFModel(object):
         # loss_norm='keras204', which must be the GLOBAL batch's, not inflated by the replay)
         ns = self.N_SCALARS
         self._flat[-ns:-ns + 2].copy_(sums)
-        self._flat[-2] = float(x.shape[0] * x.shape[1]) if live else 0.0
+        # (fill_, a kernel: `tensor[i] = python_float` is a BLOCKING host-to-device copy of a CPU scalar --
+        # one hidden hipMemcpyWithStream per step in rounds 1-3, profiles/r04d_step_hip_api_delta.txt)
+        self._flat[-2:-1].fill_(float(x.shape[0] * x.shape[1]) if live else 0.0)
+        self._flat[-1:].fill_(0.0)
         # fault word: 1.0 if a persistent chain of THIS step's forward / BPTT gave up (stream-ordered
         # read-and-clear of the handle's flag; all-reduced with the gradients, so that every rank skips
         # the update and reports the step -- ADVICE r3)
@@ -1273,8 +1277,8 @@ class UnfoldedSNMFModel(object):
             torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
         s3 = torch.empty(4, dtype=torch.float32, device=dev)
         s3[:2].copy_(ops.loss_forward(y, w, x_raw=x, mask=self.forward(x)))
-        s3[2] = float(x.shape[0] * x.shape[1])
-        s3[3] = 0.0
+        s3[2:3].fill_(float(x.shape[0] * x.shape[1]))      # (fill_: no blocking scalar copy)
+        s3[3:].fill_(0.0)
         ops.status_take(s3[3:])                 # fault word of this forward, all-reduced with the sums
         dp.allreduce_sum_(s3)
         sse, cnt, rows, fault = s3.tolist()

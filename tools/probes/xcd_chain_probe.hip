@@ -14,7 +14,8 @@
 //     F        512 | 256   MFMA bins (the odd STFT bin is outside the tiles)
 //     KS, CB   atom ranges and 16-bin column blocks of a B-type workgroup: (F/16/CB) * KS must be 32
 //     K        untied layers whose dictionaries (2 packings) are walked: K * 2 * F * 2048 * 4 bytes
-//     features bit 0 exchange (checked), bit 1 MFMAs, bit 2 dictionary stream
+//     features bit 0 exchange (checked), bit 1 MFMAs, bit 2 dictionary stream, bit 3 no LDS epilogue,
+//              bit 4 in-kernel timeline of chain 0 / workgroup 0
 //
 //   A-type phase (cell_a): workgroup i owns 64 atoms; 8 waves split the F/16 bin chunks; per chunk and
 //       wave: RB*KS exchanged 1-KB loads (residual partials), 4 dictionary loads, 16*RB MFMAs; publishes
@@ -55,6 +56,7 @@ struct Args {
     const float* D;      // [K][2][WPC][F*64]
     unsigned* sync;      // [8][LINE]
     unsigned* errors;    // [0] wrong words, [1] timeouts
+    unsigned long long* tl;   // [2][8] s_memtime segment sums (features bit 4): compute wave 0 / sync wave of chain 0, workgroup 0
     int chains, F, K, features, phases;
 };
 
@@ -82,22 +84,34 @@ __global__ void __launch_bounds__(64 * (NWV + 1)) chain_kernel(const Args a) {
     const int nchB = NAC / KS;                                 // 16-atom chunks of the range
     const int perB = (nchB + NWV - 1) / NWV, perA = (nft + NWV - 1) / NWV;
 
+    const bool stamp = (a.features & 16) && chain == 0 && i == 0;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1;
+#define STAMP(k) do { if (stamp) { t1 = __builtin_amdgcn_s_memtime(); seg[k] += t1 - t0; t0 = t1; } } while (0)
     if (w == NWV) {
         // ---------------- synchronising wave ----------------
+        if (stamp) t0 = __builtin_amdgcn_s_memtime();
         for (int p = 0; p < a.phases; ++p) {
             __syncthreads();                                   // (1) partials in LDS
             __syncthreads();                                   // (2) this workgroup's tile is acknowledged
+            STAMP(0);                                          // waiting for the compute waves
             if (l == 0) {
-                __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, SYNC_SCOPE);
+                const unsigned old = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, SYNC_SCOPE);
+                if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); seg[7] += old & 0u; }
+                STAMP(1);                                      // arrival atomic returned
                 const unsigned want = (unsigned)(p + 1) * WPC;
                 unsigned spins = 0;
                 while (__hip_atomic_load(line, __ATOMIC_RELAXED, SYNC_SCOPE) < want) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 21)) { a.errors[1] = 1; break; }
                 }
+                if (stamp) seg[6] += spins;
+                STAMP(2);                                      // poll loop
             }
             __syncthreads();                                   // (3) release the compute waves
+            STAMP(3);
         }
+        if (stamp && l == 0)
+            for (int k = 0; k < 8; ++k) a.tl[8 + k] = seg[k];
         return;
     }
 
@@ -119,6 +133,9 @@ __global__ void __launch_bounds__(64 * (NWV + 1)) chain_kernel(const Args a) {
             if (g < nd) dpre[g] = *(const f32x4*)(src + ((size_t)(w * nd + g) * 256 + l * 4));
     };
     prefetch(0);
+    const bool cst = stamp && w == 0;
+#define CSTAMP(k) do { if (cst) { t1 = __builtin_amdgcn_s_memtime(); seg[k] += t1 - t0; t0 = t1; } } while (0)
+    if (cst) t0 = __builtin_amdgcn_s_memtime();
     for (int p = 0; p < a.phases; ++p) {
         const int type = p & 1;
         const float* dsrc = dict_ptr(p);
@@ -254,7 +271,9 @@ __global__ void __launch_bounds__(64 * (NWV + 1)) chain_kernel(const Args a) {
                     for (int v = 0; v < 4; ++v)
                         lds[((w * RB + rb) * 16 + 4 * q + v) * 65 + 16 * cb + j] = acc[rb][cb][0][v] + acc[rb][cb][1][v];
         }
+        CSTAMP(0);                                             // loads + MFMAs + LDS write
         __syncthreads();                                       // (1)
+        CSTAMP(1);
         // ---- cross-wave reduction + publish (first 256 threads) ----
         if (tid < 256 && !(a.features & 8)) {
             const int er = tid >> 4, ec = tid & 15;
@@ -277,10 +296,16 @@ __global__ void __launch_bounds__(64 * (NWV + 1)) chain_kernel(const Args a) {
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CSTAMP(2);                                             // reduce + stores acknowledged
         __syncthreads();                                       // (2)
+        CSTAMP(3);
         prefetch(p + 1);
+        CSTAMP(4);
         __syncthreads();                                       // (3)
+        CSTAMP(5);                                             // waiting for the chain's barrier
     }
+    if (cst && l == 0)
+        for (int k = 0; k < 8; ++k) a.tl[k] = seg[k];
     if (bad) atomicAdd(&a.errors[0], bad);
 }
 
@@ -326,6 +351,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a.sync, 8 * LINE * 4));
     CK(hipMalloc(&a.errors, 64));
     CK(hipMemset(a.errors, 0, 64));
+    CK(hipMalloc(&a.tl, 16 * 8));
+    CK(hipMemset(a.tl, 0, 16 * 8));
     hipStream_t st; CK(hipStreamCreate(&st));
     float ms = -1.f;
 #define CASE(rb, ks, cb) if (RB == rb && KS == ks && CB == cb) ms = run<rb, ks, cb>(a, st)
@@ -341,5 +368,14 @@ int main(int argc, char** argv) {
            a.chains, WPC, RB * 16, a.chains * RB * 16, a.F, KS, CB, a.K, dbytes / 1e6, a.features,
            (a.features & 1) ? " exch" : "", (a.features & 2) ? " mfma" : "", (a.features & 4) ? " dict" : "",
            us, 2 * us, flop / us / 1e6, flop / us / 1e6 / 157.3 * 100, err[0], err[1]);
+    if (a.features & 16) {
+        unsigned long long tl[16];
+        CK(hipMemcpy(tl, a.tl, sizeof(tl), hipMemcpyDeviceToHost));
+        const double ph = (double)a.phases * 2400.0;          // s_memtime ticks ~ shader clocks ~ 2.4 GHz
+        printf("  timeline (us per phase, chain 0 workgroup 0): compute wave 0: work %.2f, barrier(1) %.2f, reduce+ack %.2f,"
+               " barrier(2) %.2f, prefetch %.2f, barrier(3) %.2f | sync wave: wait for compute %.2f, arrival atomic %.2f,"
+               " poll %.2f (%.1f polls), barrier(3) %.2f\n", tl[0] / ph, tl[1] / ph, tl[2] / ph, tl[3] / ph, tl[4] / ph,
+               tl[5] / ph, tl[8] / ph, tl[9] / ph, tl[10] / ph, (double)tl[14] / a.phases, tl[11] / ph);
+    }
     return (err[0] || err[1]) ? 2 : 0;
 }
