@@ -31,6 +31,22 @@ stats fwd "$B" --forward-only --steps 1 --warmup 1 --no-cpu-baseline --no-extras
 stats ista "$ROOT/tools/ista_profile.py" 32768 513 2000 25
 stats c5 "$ROOT/tools/c5_profile.py" 16
 stats train_c3 "$ROOT/tools/train_profile.py" 32 500 257 1000 5 3
+# dictionary training (sparse_nmf_gpu.m:210-298), 20 iterations each of KL and ED on 32768 x 513 x 1000
+stats snmf_train "$ROOT/tools/snmf_profile.py" 32768 513 1000 20
+python3 "$ROOT/tools/snmf_profile.py" 32768 513 1000 20 > "$OUT/snmf_train_unprofiled.txt" 2>&1
+# the reference's inference slab (250 utterances) and B = 1024: forward only, sub-batches on side streams
+stats fwd_b250 "$B" --forward-only --batch 250 --frames 200 --steps 1 --warmup 1 --no-cpu-baseline --no-extras
+stats fwd_b1024 "$B" --forward-only --batch 1024 --frames 100 --steps 1 --warmup 1 --no-cpu-baseline --no-extras
+python3 "$ROOT/tools/batch_sweep.py" 400 64 128 250 512 1024 2048 > "$OUT/batch_sweep.txt" 2> "$OUT/batch_sweep.err"
+python3 "$ROOT/tools/batch_sweep.py" 2000 250 >> "$OUT/batch_sweep.txt" 2>> "$OUT/batch_sweep.err"
+# HIP API calls of 20 steady-state optimiser steps (with-steps minus zero-steps trace): no synchronising call
+for nst in 0 20; do
+  timeout 900 rocprofv3 --hip-trace --stats --output-format csv -d "$OUT/step_api_$nst" -o api -- python3 "$ROOT/tools/step_api_trace.py" 32 500 257 100 5 $nst \
+      > "$OUT/step_api_${nst}.txt" 2> "$OUT/step_api_$nst.err"
+  cp "$(find "$OUT/step_api_$nst" -name '*hip_api_stats.csv' | head -1)" "$OUT/step_hip_api_stats_$nst.csv" 2>/dev/null
+done
+python3 "$ROOT/tools/hip_api_delta.py" "$OUT/step_hip_api_stats_0.csv" "$OUT/step_hip_api_stats_20.csv" 20 > "$OUT/step_hip_api_delta.txt" 2>&1
+find "$OUT" -name '*hip_api_trace.csv' -delete
 # the other shipped dictionary size (r = 100): persistent Gram chains (cell_gram_persist.h), forward + BPTT
 stats train_r100 "$ROOT/tools/train_profile.py" 32 500 257 100 5 10
 # small-shape lines alone, unprofiled (C1 + the r = 100 / r = 1000 training steps), persistent chains on / off
@@ -41,6 +57,9 @@ DRNMF_PERSIST=0 python3 "$ROOT/tools/small_shapes.py" 20 > "$OUT/small_shapes_pe
 DRNMF_BENCH_BACKEND=gloo DRNMF_BENCH_DEVICE=0 DRNMF_DP_BACKEND=torch timeout 900 python3 -m torch.distributed.run \
     --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 "$B" --gpus 2 --frames 400 \
     --steps 2 --warmup 1 --no-extras --no-cpu-baseline > "$OUT/n2_gloo_one_gpu.json" 2> "$OUT/n2_gloo_one_gpu.err"
+# ... and EIGHT ranks on the one device through bench.py's own spawn_ranks (build lock, rendezvous, rank-0 JSON)
+( cd "$ROOT" && DRNMF_BENCH_BACKEND=gloo DRNMF_BENCH_DEVICE=0 DRNMF_DP_BACKEND=torch timeout 900 python3 bench.py --gpus 8 --batch 4 \
+    --frames 8 --steps 2 --warmup 1 --no-extras --no-cpu-baseline 2> "$OUT/n8_gloo_one_gpu.err" | tail -1 > "$OUT/n8_gloo_one_gpu.json" )
 # 5. PMC passes, 20 frames of the headline forward (cell + head only)
 SMALL="--forward-only --frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch" -o p -- python3 "$B" $SMALL \
@@ -51,6 +70,16 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o p -- python3 "$B" $SMALL \
     > /dev/null 2> "$OUT/pmc_sq.err"
 python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_summary.json" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq"
+# 5b. the same passes at the reference's inference slab (B = 250; two sub-batches on side streams)
+SLAB="--forward-only --batch 250 --frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch_b250" -o p -- python3 "$B" $SLAB \
+    > /dev/null 2> "$OUT/pmc_fetch_b250.err"
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d "$OUT/pmc_write_b250" -o p -- python3 "$B" $SLAB \
+    > /dev/null 2> "$OUT/pmc_write_b250.err"
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_sq_b250" -o p -- python3 "$B" $SLAB \
+    > /dev/null 2> "$OUT/pmc_sq_b250.err"
+python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_b250_summary.json" "$OUT/pmc_fetch_b250" "$OUT/pmc_write_b250" "$OUT/pmc_sq_b250"
 # 6. the persistent chains of the shipped r = 100 training step: wave-cycle split and matrix-pipe time
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_r100" -o p -- python3 "$ROOT/tools/train_profile.py" 32 500 257 100 5 3 \
