@@ -419,7 +419,11 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     W.RB = 1;
     {
         const int groups = round_up(d->B, ROWS * 2) / (ROWS * 2);
-        if (groups * W.numA >= 500 && groups * W.nft_main * 2 >= 500) W.RB = 2;
+        // (a SUB-BATCH of a split call -- allow_split == false -- shares the chip with its siblings'
+        // launches: one such workgroup per CU is enough, and the halved operand traffic per MFMA is what
+        // counts; measured at B = 250 as 2 x 125 rows: 686-695 k frames/s with one row block, 723 k with two)
+        const int need = allow_split ? 500 : 250;
+        if (groups * W.numA >= need && groups * W.nft_main * 2 >= need) W.RB = 2;
     }
     if (const char* e = tune_env("DRNMF_RB")) {   // tuning aid: force the row blocking
         const int v = atoi(e);
@@ -506,21 +510,26 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     W.split_rows = d->B;
     W.split_bytes = 0;
     if (allow_split && !W.gram && !d->return_all_hidden && d->divergence == DRNMF_DIV_ED) {
-        // measured (profiles/r04b_split_sweep.txt; cell + head, T = 200, k frames/s with 1 / 2 / 3 / 4
-        // sub-batches): B = 128 426 / 491 / 490 / 362, 192 469 / 546 / 569 / 574, 250 580 / 656 / 598 / 600,
-        // 384 622 / 740 / 743 / 715, 512 727 / 765 / 786 / 779, 1024 657 / 928 / 929 / 937
-        // -- sub-batches of ~256 rows from 896 rows on (beyond that one sub-batch's h no longer fits the
-        // 4 MB L2 of an XCD next to its dictionary slices: B = 1024 unsplit runs at 36 % L2 hit rate in cell_b)
-        int S = d->B >= 896 ? (d->B + 128) / 256 : (d->B >= 448 ? 3 : (d->B >= 128 ? 2 : 1));
-        if (S > MAX_SPLIT) S = MAX_SPLIT;
+        // Sub-batches of 64, 128 or 256 rows (whole groups of two 16-row blocks; the last one takes the
+        // rest).  Measured, cell + head, T = 400, k frames/s by number of sub-batches
+        // (profiles/r04f_split_sweep.txt): B = 80: 286 unsplit / 343 with two (B = 64: 318 / 254 -- no split);
+        // 192: 573 (2) / 626 (3) / 623 (4); 250: 722 (2) / 647 (3); 320: 633 (2) / 718 (3) / 685 (4);
+        // 512: 789 (2) / 812 (3) / 844 (4); 768: 899 (2) / 935 (3) / 932 (4); 1024: 964 (3) / 973 (4) /
+        // 800 (5) / 774 (6) -- sub-batches that are not a multiple of 64 rows lose.  Beyond 256 rows one
+        // sub-batch's h no longer fits an XCD's 4 MB L2 next to its dictionary slices (B = 1024 unsplit:
+        // cell_b at 36 % L2 hit rate).
+        int R = d->B < 80 ? d->B : (d->B <= 224 ? 64 : (d->B <= 640 ? 128 : 256));
+        int S = (d->B + R - 1) / R;
+        if (S > MAX_SPLIT) { S = MAX_SPLIT; R = round_up((d->B + S - 1) / S, 64); }
         if (const char* e = tune_env("DRNMF_SPLIT")) {      // tuning aid: force the number of sub-batches
             const int v = atoi(e);
-            if (v >= 1 && v <= MAX_SPLIT) S = v;
+            if (v >= 1 && v <= MAX_SPLIT) { S = v; R = round_up((d->B + S - 1) / S, 32); }
         }
         while (S > 1 && d->B < 32 * S) --S;
+        if (S * R < d->B) R = round_up((d->B + S - 1) / S, 32);     // (the sub-batches must cover the batch)
         if (S > 1) {
             W.split = S;
-            W.split_rows = round_up((d->B + S - 1) / S, 32);
+            W.split_rows = R;
             drnmf_cell_desc_t ds = *d;
             ds.B = W.split_rows;
             W.split_bytes = round_up_sz(workspace_layout(&ds, false).total, 256);

@@ -770,6 +770,28 @@ def _require_h5py(path):
 
 
 # ------------------------------------------------------------------------------------------
+# Report-ring slots of a device are shared by every model of the process (the ring belongs to the library
+# handle): a slot is handed out again only after the DeviceLoss that last used it has been read.
+_ring_next = {}
+_ring_owner = {}
+
+
+def _claim_report_slot(dev_index, n_slots):
+    import weakref
+    i = _ring_next.get(dev_index, 0)
+    _ring_next[dev_index] = i + 1
+    slot = i % n_slots
+    prev = _ring_owner.get((dev_index, slot))
+    if prev is not None:
+        prev = prev()
+        if prev is not None and prev._value is None:
+            try:
+                prev._get()              # (waits for a step issued n_slots steps ago: long finished)
+            except Exception:            # noqa: BLE001 -- its fault is raised to whoever reads THAT loss
+                pass
+    return slot, (lambda loss: _ring_owner.__setitem__((dev_index, slot), weakref.ref(loss)))
+
+
 class DeviceLoss(object):
     """The loss of one optimiser step, still on its way from the device.
 
@@ -780,24 +802,29 @@ class DeviceLoss(object):
     that launch and reads the slot.  Behaves like a number wherever one is needed (float(), arithmetic,
     comparisons, formatting); a step whose persistent chain timed out raises here -- on every rank of a
     data-parallel group at the same step, because the fault word is part of the all-reduced buffer."""
-    __slots__ = ('_event', '_slot', '_value', '_device')
+    __slots__ = ('_event', '_slot', '_value', '_device', '_error', '__weakref__')
 
     def __init__(self, event, slot, device):
-        self._event, self._slot, self._value, self._device = event, slot, None, device
+        self._event, self._slot, self._value, self._device, self._error = event, slot, None, device, None
 
     def ready(self):
         return self._value is not None or self._event.query()
 
     def _get(self):
+        if self._error is not None:
+            raise self._error
         if self._value is None:
             if not self._event.query():
                 self._event.synchronize()
             loss, fault = float(self._slot[0]), float(self._slot[1])
+            self._slot = None                # (the ring slot may be reused from here on)
             if fault != 0.0:
-                raise _capi.DrnmfError(
+                self._value = float('nan')
+                self._error = _capi.DrnmfError(
                     'train_on_batch: a persistent small-shape chain of this step timed out on at least '
                     'one rank (DRNMF_ERR_TIMEOUT): the step was SKIPPED on every rank (weights and Adam '
                     'state unchanged) -- rerun it, or set DRNMF_PERSIST=0')
+                raise self._error
             self._value = loss
         return self._value
 
@@ -1221,7 +1248,7 @@ class UnfoldedSNMFModel(object):
         lr_t = lr * np.sqrt(1.0 - o['b2'] ** t) / (1.0 - o['b1'] ** t)
         table, nb = self._adam_blocks()
         ring, base = ops.host_report_ring(self.cell.device)
-        slot = self._step_no % ring.shape[0]
+        slot, register = _claim_report_slot(ops._dev_of(self.cell.device), ring.shape[0])
         self._step_no += 1
         ops.adam_step_flat(table, nb, flat, self._mflat, self._vflat, flat[-ns:], lr_t, o['b1'], o['b2'],
                            o['eps'], clipnorm=o['clipnorm'], keras204=keras204, reg_loss=reg_loss,
@@ -1230,6 +1257,7 @@ class UnfoldedSNMFModel(object):
         ev = torch.cuda.Event()
         ev.record()
         loss = DeviceLoss(ev, ring[slot], self.cell.device)
+        register(loss)
         o['iterations'] = t
         # the prepared parameter block is stale; the (u0_diag, u0_off, uk_off) scalars are derived
         # from log_U1 / log_Uk, which compile() refuses to train: re-deriving them here would cost

@@ -884,3 +884,43 @@ def test_plain_c_host_program_over_the_c_abi(dev, tmp_path):
     assert out.returncode == 0, out.stderr
     err, mx = (float(out.stdout.split(k)[1].split()[0]) for k in ("max_abs_err", "max_ref"))
     assert mx > 0 and err <= H_TOL * mx, out.stdout
+
+
+@pytest.mark.parametrize("B,split", [(100, None), (100, "1"), (130, "3"), (250, "2"), (97, "4"), (200, "8")])
+def test_large_batch_sub_batches_on_side_streams(dev, monkeypatch, B, split):
+    """Inference batches of 96 rows and more run as independent sub-batches on side streams of the handle
+    (csrc/cell_shared.h Workspace::split; batch rows never interact, custom_layers.py:337-338, 346-348).
+    Ragged lengths, a masked first frame in the LAST sub-batch, caller-supplied initial states and the
+    final states read back: every sub-batch count (also uneven ones: 97 rows as 32+32+32+1, 130 as
+    64+64+2) against the fp64 oracle, and the final state of every row against the oracle's."""
+    from drnmf_amd import ops
+    monkeypatch.setenv("DRNMF_GRAM", "0")            # (the split serves the factored form)
+    if split is None:
+        monkeypatch.delenv("DRNMF_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("DRNMF_SPLIT", split)
+    K, T, F, r = 3, 7, 33, 20
+    P, alt, labels, N = _problem(B, T, F, r, K, ragged=True, seed=B)
+    P["X"][B - 1, 0] = -1.0
+    rng = np.random.default_rng(B)
+    init = np.abs(rng.standard_normal((B, N))).astype(np.float32) * (rng.random((B, N)) < 0.3)
+    stack = lambda name: np.stack([alt[k] for k in dict.fromkeys(labels[name])], 0)
+    logD, logA, logL = stack("log_D"), stack("log_alph"), stack("log_lam1")
+    desc = ops.make_desc(B, T, F, N, K, n_D=logD.shape[0], n_alph=logA.shape[0],
+                         alph_len=int(np.asarray(logA[0]).size), n_lam=logL.shape[0])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    params = ops.prepare_params(desc, t(logD), t(logA.reshape(logA.shape[0], -1)), t(logL.reshape(-1)))
+    fin = torch.full((B, N), -7.0, dtype=torch.float32, device=dev)
+    u = O.u_scalars(alt, np.float32)
+    outs = []
+    for _ in range(2):                               # (second call: the cached graphs of every sub-batch)
+        h = ops.cell_forward(t(P["X"]), -1.0, params, desc, t(P["log_h0"]), u, initial_state=t(init),
+                             final_state=fin)
+        torch.cuda.synchronize()
+        outs.append(h.cpu().numpy())
+    ops.check_status(dev)
+    assert np.array_equal(outs[0], outs[1])
+    ref, st = O.cell_forward_factored(P["X"], O.maps_factored(alt, labels, K), O.u_scalars(alt), P["log_h0"],
+                                      mask_value=-1.0, initial_state=init.astype(np.float64), return_state=True)
+    _check_h(outs[0], ref)
+    np.testing.assert_allclose(fin.cpu().numpy(), st, atol=H_TOL * max(np.max(np.abs(st)), 1e-30))
