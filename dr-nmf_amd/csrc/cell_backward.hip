@@ -1129,9 +1129,11 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                                   float* d_log_alph, float* d_log_lam1, float* d_log_h0,
                                   void* stream_, float* prof_ms, float beta = 0.f) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
-    int rc = persist_check_flag(h);
-    if (rc) return rc;
-    rc = validate_cell_desc(h, d);
+    // (No implicit look at the handle's fault word here: a host-side read-and-clear at the entry of the
+    // NEXT call races with the stream-ordered drnmf_status_take_device of a training step -- the host
+    // could consume the word before the device-side guard of the fused Adam launch has seen it.  Faults
+    // are reported by drnmf_check_status / drnmf_status_take_device only.)
+    int rc = validate_cell_desc(h, d);
     if (rc) return rc;
     // operand_f16: the forward ran on fp16 matrix-core operands; its BPTT is computed in fp32 from
     // the stored hiddens and the fp32 dictionary packings kept in the same prepared block

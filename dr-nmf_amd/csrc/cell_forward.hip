@@ -1025,9 +1025,11 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                                  const float* initial_state = nullptr, float* final_state = nullptr,
                                  bool allow_split = true, FwdPlan* plan = nullptr) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
-    int rc = persist_check_flag(h);
-    if (rc) return rc;
-    rc = validate_cell_desc(h, d);
+    // (No implicit look at the handle's fault word here: a host-side read-and-clear at the entry of the
+    // NEXT call races with the stream-ordered drnmf_status_take_device of a training step -- the host
+    // could consume the word before the device-side guard of the fused Adam launch has seen it.  Faults
+    // are reported by drnmf_check_status / drnmf_status_take_device only.)
+    int rc = validate_cell_desc(h, d);
     if (rc) return rc;
     if (d->divergence != DRNMF_DIV_ED)
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,

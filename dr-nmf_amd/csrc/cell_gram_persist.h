@@ -24,8 +24,8 @@
 //     operand prefetch returns only after the prefetch, in order), the eight others request the next
 //     phase's PRIVATE operands (G tile, c_k[t], 1/alpha, validity, stored hiddens) meanwhile.
 //   * a chain whose poll exceeds PERSIST_SPIN_LIMIT raises its abort word: every workgroup of the
-//     chain leaves at its next barrier, the host-mapped flag of the handle is set, and the next ABI
-//     call on the handle returns DRNMF_ERR_TIMEOUT instead of handing out a wrong result silently.
+//     chain leaves at its next barrier and the host-mapped fault word of the handle is set: drnmf_check_status
+//     / drnmf_status_take_device report DRNMF_ERR_TIMEOUT instead of a wrong result going out silently.
 // Same arithmetic, in the same order, as gram_fwd_kernel / bwd_edge_kernel + gram_bwd_kernel: results
 // are bit-identical to the launch-per-layer-step form (tests/test_gpu_dp.py).
 #pragma once

@@ -515,10 +515,11 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
         // (profiles/r04f_split_sweep.txt): B = 80: 286 unsplit / 343 with two (B = 64: 318 / 254 -- no split);
         // 192: 573 (2) / 626 (3) / 623 (4); 250: 722 (2) / 647 (3); 320: 633 (2) / 718 (3) / 685 (4);
         // 512: 789 (2) / 812 (3) / 844 (4); 768: 899 (2) / 935 (3) / 932 (4); 1024: 964 (3) / 973 (4) /
-        // 800 (5) / 774 (6) -- sub-batches that are not a multiple of 64 rows lose.  Beyond 256 rows one
+        // 800 (5) / 774 (6); 640 as 5 x 128: 681, 224 as 4 x 64: 604 -- sub-batches that are not a multiple of
+        // 64 rows lose, and so do five or six of them.  Beyond 256 rows one
         // sub-batch's h no longer fits an XCD's 4 MB L2 next to its dictionary slices (B = 1024 unsplit:
         // cell_b at 36 % L2 hit rate).
-        int R = d->B < 80 ? d->B : (d->B <= 224 ? 64 : (d->B <= 640 ? 128 : 256));
+        int R = d->B < 80 ? d->B : (d->B <= 192 ? 64 : (d->B <= 512 ? 128 : 256));
         int S = (d->B + R - 1) / R;
         if (S > MAX_SPLIT) { S = MAX_SPLIT; R = round_up((d->B + S - 1) / S, 64); }
         if (const char* e = tune_env("DRNMF_SPLIT")) {      // tuning aid: force the number of sub-batches

@@ -1272,10 +1272,10 @@ class UnfoldedSNMFModel(object):
         # wait is for a step that finished long ago; it never drains the queue), and a ring slot is
         # never reused before it was read.
         self._pending.append(loss)
-        while len(self._pending) > self.PENDING_STEPS:
-            self._pending.pop(0)._get()
-        while self._pending and self._pending[0].ready():
-            self._pending.pop(0)._get()
+        while len(self._pending) > self.PENDING_STEPS or (self._pending and self._pending[0].ready()):
+            old = self._pending.pop(0)
+            if old._error is None:       # (a fault its reader has already been told about is not raised again)
+                old._get()
         return loss
 
     def train_on_batch(self, x, y, sample_weight=None, _live=True):

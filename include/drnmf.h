@@ -39,8 +39,8 @@ enum {
     DRNMF_ERR_TIMEOUT = -6  /* a persistent small-shape launch of an EARLIER call on this handle gave up
                              * waiting for its own workgroups (they were not resident together); that
                              * call's output is invalid.  Reported by drnmf_check_status (after the
-                             * caller has synchronised), by drnmf_status_take_device (stream-ordered,
-                             * no synchronisation) or, failing both, by the next cell call on the handle. */
+                             * caller has synchronised) or by drnmf_status_take_device (stream-ordered,
+                             * no synchronisation) -- never implicitly by a later call. */
 };
 
 /* divergence selector for the frame-parallel ISTA / MU kernels */

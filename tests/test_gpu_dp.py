@@ -384,15 +384,18 @@ def test_persistent_chains_next_to_a_busy_stream(dev, monkeypatch):
     torch.cuda.synchronize()
     for o in outs:
         assert np.array_equal(o.cpu().numpy(), ref)
-    again = TP._run_cell(dev, P, alt, labels, N, K)[0]      # no DRNMF_ERR_TIMEOUT pending
+    again = TP._run_cell(dev, P, alt, labels, N, K)[0]
+    from drnmf_amd import ops
+    ops.check_status(dev)                                   # no DRNMF_ERR_TIMEOUT pending
     assert np.array_equal(again, ref)
 
 
 def test_persistent_timeout_is_reported_not_swallowed(dev, monkeypatch):
     """a persistent launch whose barrier can never complete (fault injection: every barrier
-    waits for one arrival too many) must give up after its bounded spin, and the NEXT cell call on the
-    handle must fail with DRNMF_ERR_TIMEOUT instead of a wrong result going out silently; the call after
-    that works again."""
+    waits for one arrival too many) must give up after its bounded spin, and drnmf_check_status -- called
+    once the stream is synchronised -- must fail with DRNMF_ERR_TIMEOUT instead of a wrong result going out
+    silently (round 4: no longer reported implicitly by the next cell call, which raced with the training
+    step's device-side guard); the call after that works again."""
     import os
     import sys
     import time
@@ -410,9 +413,12 @@ def test_persistent_timeout_is_reported_not_swallowed(dev, monkeypatch):
     torch.cuda.synchronize()
     assert time.time() - t0 < 60.0                         # bounded, not a hang
     monkeypatch.delenv("DRNMF_PERSIST_FAULT")
+    from drnmf_amd import ops
     with pytest.raises(_capi.DrnmfError, match="timed out"):
-        TP._run_cell(dev, P, alt, labels, N, K)
-    again = TP._run_cell(dev, P, alt, labels, N, K)[0]     # the flag is reported once
+        ops.check_status(dev)                              # (after the synchronise above: read and clear)
+    ops.check_status(dev)                                  # the fault is reported once
+    again = TP._run_cell(dev, P, alt, labels, N, K)[0]
+    ops.check_status(dev)
     assert np.array_equal(again, good)
 
 
@@ -465,3 +471,51 @@ def test_processes_sharing_one_gpu_admit_one_owner_of_the_persistent_chains(dev,
         assert np.array_equal(z["h"], mine)
     ref = TP._oracle_cell(P, alt, labels, K)
     assert np.max(np.abs(mine - ref)) <= TP.H_TOL * np.max(np.abs(ref))
+
+
+def test_timed_out_training_step_is_skipped_and_reported(dev, monkeypatch):
+    """a persistent chain that times out inside a TRAINING step must not feed garbage
+    gradients into Adam.  Fault injection (DRNMF_PERSIST_FAULT=1: every chain barrier waits for an arrival
+    that never comes): the step's fault word -- taken from the handle stream-ordered, part of the
+    all-reduced flat buffer -- makes the fused Adam launch skip the update (weights and moments
+    bit-identical to before the step), float(loss) raises, check_status finds nothing left behind, and the
+    next step trains normally; predict_on_batch / test_on_batch report a timed-out forward themselves."""
+    from drnmf_amd import _capi, layers, ops
+    monkeypatch.setenv("DRNMF_GRAM", "1")
+    monkeypatch.setenv("DRNMF_PERSIST", "1")
+    B, T, F, r, K = 5, 6, 21, 6, 3
+    P = O.synth_problem(B, T, F, r, seed=31, ragged=True, density=0.15)
+    N = 2 * r
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=P["W"], alph=N / 4.0, lam1=0.3, params_untied=["log_D", "log_alph"],
+             params_trainable=["log_D", "log_alph"])
+    np.random.seed(3)
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.compile(lr=1e-2)
+    w = (P["X"] != -1.0).any(-1).astype(np.float32)
+    l0 = float(model.train_on_batch(P["X"], P["Y"], w))
+    assert np.isfinite(l0)
+    before = [a.copy() for a in model.get_weights()]
+    m_before = model._mflat.clone()
+    it_before = model.opt["iterations"]
+    monkeypatch.setenv("DRNMF_PERSIST_FAULT", "1")
+    bad = model.train_on_batch(P["X"], P["Y"], w)          # enqueues; the chains time out on the device
+    monkeypatch.delenv("DRNMF_PERSIST_FAULT")
+    with pytest.raises(_capi.DrnmfError, match="timed out"):
+        float(bad)
+    torch.cuda.synchronize()
+    for a, b in zip(before, model.get_weights()):
+        assert np.array_equal(a, b)                          # the update was skipped
+    assert torch.equal(m_before, model._mflat)
+    assert model.opt["iterations"] == it_before + 1          # (the host counted the step; Adam did not run)
+    ops.check_status(dev)                                    # the fault word was consumed by the step
+    l2 = float(model.train_on_batch(P["X"], P["Y"], w))
+    assert np.isfinite(l2) and any(not np.array_equal(a, b) for a, b in zip(before, model.get_weights()))
+    # inference: the copy to the host synchronises, then the status check raises
+    monkeypatch.setenv("DRNMF_PERSIST_FAULT", "1")
+    with pytest.raises(_capi.DrnmfError, match="timed out"):
+        model.predict_on_batch(P["X"])
+    with pytest.raises(_capi.DrnmfError, match="timed out"):
+        model.test_on_batch(P["X"], P["Y"], w)
+    monkeypatch.delenv("DRNMF_PERSIST_FAULT")
+    assert np.isfinite(model.predict_on_batch(P["X"])).all()
