@@ -1165,7 +1165,7 @@ class UnfoldedSNMFModel(object):
         ns = self.N_SCALARS
         self._flat[-ns:-ns + 2].copy_(sums)
         # (fill_, a kernel: `tensor[i] = python_float` is a BLOCKING host-to-device copy of a CPU scalar --
-        # one hidden hipMemcpyWithStream per step in rounds 1-3, profiles/r04d_step_hip_api_delta.txt)
+        # one hidden hipMemcpyWithStream per step in rounds 1-3, profiles/r04g_step_hip_api_delta.txt)
         self._flat[-2:-1].fill_(float(x.shape[0] * x.shape[1]) if live else 0.0)
         self._flat[-1:].fill_(0.0)
         # fault word: 1.0 if a persistent chain of THIS step's forward / BPTT gave up (stream-ordered

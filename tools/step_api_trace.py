@@ -5,7 +5,7 @@ Runs 3 warm-up steps, synchronises, then `steps` steps WITHOUT reading a loss, a
 synchronising HIP calls the host made in between (counted by wrapping torch.cuda.synchronize /
 Tensor.tolist / Tensor.item / Tensor.cpu at the Python level; the rocprofv3 trace of the same command
 is the authoritative count: run it with steps = 0 and steps = 20 and subtract the per-API call counts --
-tools/hip_api_delta.py, profiles/r04_step_hip_api_delta.txt)."""
+tools/hip_api_delta.py, profiles/r04g_step_hip_api_delta.txt)."""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
