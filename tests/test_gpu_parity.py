@@ -886,20 +886,27 @@ def test_plain_c_host_program_over_the_c_abi(dev, tmp_path):
     assert mx > 0 and err <= H_TOL * mx, out.stdout
 
 
-@pytest.mark.parametrize("B,split", [(100, None), (100, "1"), (130, "3"), (250, "2"), (97, "4"), (200, "8")])
-def test_large_batch_sub_batches_on_side_streams(dev, monkeypatch, B, split):
+@pytest.mark.parametrize("B,split,r,gram", [(100, None, 20, "0"), (100, "1", 20, "0"), (130, "3", 20, "0"),
+                                            (250, "2", 20, "0"), (97, "4", 20, "0"), (200, "8", 20, "0"),
+                                            (200, None, 250, None)])
+def test_large_batch_sub_batches_on_side_streams(dev, monkeypatch, B, split, r, gram):
     """Inference batches of 96 rows and more run as independent sub-batches on side streams of the handle
     (csrc/cell_shared.h Workspace::split; batch rows never interact, custom_layers.py:337-338, 346-348).
     Ragged lengths, a masked first frame in the LAST sub-batch, caller-supplied initial states and the
     final states read back: every sub-batch count (also uneven ones: 97 rows as 32+32+32+1, 130 as
-    64+64+2) against the fp64 oracle, and the final state of every row against the oracle's."""
+    64+64+2) against the fp64 oracle, and the final state of every row against the oracle's.  Last case:
+    N = 500 at B = 200 -- the whole batch is past the Gram form's size rule (factored, split), its 128- and
+    72-row sub-batches are inside it: each sub-batch takes its own form."""
     from drnmf_amd import ops
-    monkeypatch.setenv("DRNMF_GRAM", "0")            # (the split serves the factored form)
+    if gram is None:
+        monkeypatch.delenv("DRNMF_GRAM", raising=False)
+    else:
+        monkeypatch.setenv("DRNMF_GRAM", gram)       # (the split serves the factored form)
     if split is None:
         monkeypatch.delenv("DRNMF_SPLIT", raising=False)
     else:
         monkeypatch.setenv("DRNMF_SPLIT", split)
-    K, T, F, r = 3, 7, 33, 20
+    K, T, F = 3, 7, 33
     P, alt, labels, N = _problem(B, T, F, r, K, ragged=True, seed=B)
     P["X"][B - 1, 0] = -1.0
     rng = np.random.default_rng(B)

@@ -425,3 +425,70 @@ def test_training_steps_are_bitwise_reproducible(dev, cell_form, trainable):
     assert l1 == l2
     for a, b in zip(w1, w2):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("opts", [
+    dict(),                                         # plain Adam, masked-mean normalisation
+    dict(clipnorm="half"),                          # global-norm clip active: half of this batch's gradient norm
+    dict(loss_norm="keras204", decay=0.1),          # Keras' second division by mean(mask); lr decay
+    dict(clipnorm=1e6, loss_norm="keras204"),       # clip configured but not reached
+])
+def test_fused_adam_launch_matches_numpy_adam(dev, opts):
+    """drnmf_adam_step_flat (ONE launch over the flat gradient buffer; 1/count, the keras204 factor and the
+    global-norm clip evaluated on the device from the buffer's tail and the drnmf_sumsq partials) against
+    keras.optimizers.Adam restated in numpy [K2.0.4-memory], three consecutive steps on the SAME gradients
+    (the flat buffer is refilled from a copy, so only the optimiser differs)."""
+    K = 2
+    model, P, wmask = _setup(3, 5, 21, 6, K, ("log_D", "log_alph"))
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    opts = dict(opts)
+    half = opts.get("clipnorm") == "half"
+    if half:
+        opts["clipnorm"] = 1.0
+    model.compile(lr=lr, **opts)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    flat0 = model.loss_and_grads(t(P["X"]), t(P["Y"]), t(wmask)).clone()
+    f64 = flat0.cpu().numpy().astype(np.float64)
+    g, (sse, cnt, rows, fault) = f64[:-4], f64[-4:]
+    assert fault == 0.0
+    scale = 1.0 / max(cnt, 1.0)
+    if opts.get("loss_norm") == "keras204":
+        scale *= rows / max(cnt, 1.0)
+    want_loss = sse * scale
+    if half:
+        opts["clipnorm"] = model.opt["clipnorm"] = 0.5 * np.sqrt(np.sum(g * g)) * scale
+    clip = opts.get("clipnorm", 0.0)
+    if clip > 0:
+        norm = np.sqrt(np.sum(g * g)) * scale
+        if norm > clip:
+            scale *= clip / norm
+    p = np.concatenate([w_.detach().cpu().numpy().astype(np.float64).reshape(-1) for _, w_ in model._train_items])
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for it in range(3):
+        model._flat.copy_(flat0)
+        loss = model.apply_gradients(model._flat)
+        assert abs(float(loss) - want_loss) <= 1e-6 * abs(want_loss)
+        lr_i = lr / (1.0 + opts.get("decay", 0.0) * it)
+        lr_t = lr_i * np.sqrt(1.0 - b2 ** (it + 1)) / (1.0 - b1 ** (it + 1))
+        gs = g * scale
+        m = b1 * m + (1 - b1) * gs
+        v = b2 * v + (1 - b2) * gs * gs
+        p = p - lr_t * m / (np.sqrt(v) + eps)
+        got = np.concatenate([w_.detach().cpu().numpy().reshape(-1) for _, w_ in model._train_items])
+        # (fp32 parameters of magnitude <= ~20; a step of ~lr)
+        np.testing.assert_allclose(got, p, rtol=0, atol=5e-6 + 2e-3 * lr)
+    np.testing.assert_allclose(model._mflat.cpu().numpy(), m, rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(model._vflat.cpu().numpy(), v, rtol=4e-4, atol=1e-12)
+
+
+def test_fit_validates_in_mini_batches(dev):
+    """fit() evaluates validation_data in mini-batches of batch_size (Keras' test loop; enhance.py:1152-1157)
+    with the sums accumulated on the device: the value equals test_on_batch over the whole set."""
+    model, P, wmask = _setup(7, 6, 21, 6, 2, ("log_D", "log_alph"))
+    model.compile(lr=0.0)                       # (lr 0: the weights stay put, so the two values are comparable)
+    hist = model.fit(P["X"], P["Y"], sample_weight=wmask, batch_size=3, epochs=1, shuffle=False,
+                     validation_data=(P["X"], P["Y"], wmask))
+    whole = model.test_on_batch(P["X"], P["Y"], wmask)
+    assert abs(hist["val_loss"][0] - whole) <= 1e-6 * abs(whole)
+    assert np.isfinite(hist["loss"][0])

@@ -319,3 +319,34 @@ def test_early_stopping_min_delta_and_rank0_callbacks():
     assert mx.best == 0.5 and mx.model.stop_training
     assert callbacks.ModelCheckpoint.rank0_only and callbacks.LossHistory.rank0_only
     assert not getattr(callbacks.EarlyStopping, "rank0_only", False)
+
+
+def test_device_loss_behaves_like_a_number_and_reports_a_fault_once_per_reader():
+    """layers.DeviceLoss (what train_on_batch returns): arithmetic, comparisons, numpy and formatting go
+    through float(); a step whose fault word was set raises at the read (every read), and the report-ring
+    slot of a loss is not reused before it has been read."""
+    from drnmf_amd import _capi, layers
+
+    class Ev(object):
+        def query(self):
+            return True
+
+        def synchronize(self):
+            pass
+    ok = layers.DeviceLoss(Ev(), np.array([1.5, 0.0, 1.0, 4.0], np.float32), None)
+    assert float(ok) == 1.5 and ok < 2 and 0.9 * ok == pytest.approx(1.35) and abs(3 - ok) == 1.5
+    assert "%.2f" % ok == "1.50" and np.isfinite([ok, ok]).all() and np.mean([ok, ok]) == 1.5
+    assert ok == 1.5 and ok != 2 and round(ok, 1) == 1.5 and -ok == -1.5
+    bad = layers.DeviceLoss(Ev(), np.array([0.0, 1.0, 0.0, 0.0], np.float32), None)
+    for _ in range(2):
+        with pytest.raises(_capi.DrnmfError, match="timed out"):
+            float(bad)
+    ring = np.zeros((3, 4), np.float32)
+    kept = []
+    for i in range(8):                                   # 8 steps through a 3-slot ring
+        slot, register = layers._claim_report_slot(99, 3)
+        ring[slot] = [i, 0, 1, 1]
+        d = layers.DeviceLoss(Ev(), ring[slot], None)
+        register(d)
+        kept.append(d)
+    assert [float(d) for d in kept] == [float(i) for i in range(8)]
