@@ -888,7 +888,7 @@ def test_plain_c_host_program_over_the_c_abi(dev, tmp_path):
 
 @pytest.mark.parametrize("B,split,r,gram", [(100, None, 20, "0"), (100, "1", 20, "0"), (130, "3", 20, "0"),
                                             (250, "2", 20, "0"), (97, "4", 20, "0"), (200, "8", 20, "0"),
-                                            (200, None, 250, None)])
+                                            (200, None, 250, None), (512, None, 20, "0")])
 def test_large_batch_sub_batches_on_side_streams(dev, monkeypatch, B, split, r, gram):
     """Inference batches of 96 rows and more run as independent sub-batches on side streams of the handle
     (csrc/cell_shared.h Workspace::split; batch rows never interact, custom_layers.py:337-338, 346-348).
@@ -896,7 +896,7 @@ def test_large_batch_sub_batches_on_side_streams(dev, monkeypatch, B, split, r, 
     final states read back: every sub-batch count (also uneven ones: 97 rows as 32+32+32+1, 130 as
     64+64+2) against the fp64 oracle, and the final state of every row against the oracle's.  Last case:
     N = 500 at B = 200 -- the whole batch is past the Gram form's size rule (factored, split), its 128- and
-    72-row sub-batches are inside it: each sub-batch takes its own form."""
+    72-row sub-batches are inside it: each sub-batch takes its own form.  B = 512: four sub-batches of 128."""
     from drnmf_amd import ops
     if gram is None:
         monkeypatch.delenv("DRNMF_GRAM", raising=False)
