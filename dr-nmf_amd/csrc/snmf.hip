@@ -635,28 +635,40 @@ w_fold_kernel(const float* __restrict__ W, float* __restrict__ PN, float* __rest
     if (beta_is_one)
         for (int s = 0; s < hs_splits; ++s) hs += hs_part[(size_t)s * N + n];
     float sn = 0.f, sd = 0.f;
-    const int f1 = (g + 1) * W_FB < F ? (g + 1) * W_FB : F;
-    for (int f = g * W_FB; f < f1; ++f) {
-        const size_t o = (size_t)f * N + n;
-        float num = 0.f, den = hs;
-        if (f >= Mg) {                                 // odd rows: tn_tail_kernel's partials
-            for (int s = 0; s < TT_SPLITS; ++s) num += tailp[(((size_t)s * 2 + 0) * TN_TAIL_MAX + (f - Mg)) * N + n];
-        } else {
-            for (int s = 0; s < nsplit; ++s) num += PN[s * stride + o];
-        }
-        PN[o] = num;                                   // (folded in place: slot 0)
-        if (!beta_is_one) {
-            den = 0.f;
-            if (f >= Mg) {
-                for (int s = 0; s < TT_SPLITS; ++s) den += tailp[(((size_t)s * 2 + 1) * TN_TAIL_MAX + (f - Mg)) * N + n];
-            } else {
-                for (int s = 0; s < nsplit; ++s) den += PD[s * stride + o];
+    const int f0 = g * W_FB;
+    // the group's W_FB bins side by side: W_FB (x 2) independent loads in flight per split (bin by bin the
+    // fold was one dependent load after the other: 67 us for 50 MB); per (bin, atom) the splits are still
+    // added in their fixed order
+    float num[W_FB], den[W_FB];
+#pragma unroll
+    for (int i = 0; i < W_FB; ++i) { num[i] = 0.f; den[i] = beta_is_one ? hs : 0.f; }
+    for (int s = 0; s < nsplit; ++s) {
+#pragma unroll
+        for (int i = 0; i < W_FB; ++i) {
+            const int f = f0 + i;
+            if (f < F && f < Mg) {
+                const size_t o = (size_t)f * N + n;
+                num[i] += PN[s * stride + o];
+                if (!beta_is_one) den[i] += PD[s * stride + o];
             }
-            PD[o] = den;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < W_FB; ++i) {
+        const int f = f0 + i;
+        if (f >= F) break;
+        const size_t o = (size_t)f * N + n;
+        if (f >= Mg) {                                 // odd rows: tn_tail_kernel's partials
+            for (int s = 0; s < TT_SPLITS; ++s) {
+                num[i] += tailp[(((size_t)s * 2 + 0) * TN_TAIL_MAX + (f - Mg)) * N + n];
+                if (!beta_is_one) den[i] += tailp[(((size_t)s * 2 + 1) * TN_TAIL_MAX + (f - Mg)) * N + n];
+            }
+        }
+        PN[o] = num[i];                                // (folded in place: slot 0)
+        if (!beta_is_one) PD[o] = den[i];
         const float w = W[o];
-        sn = fmaf(num, w, sn);
-        sd = fmaf(den, w, sd);
+        sn = fmaf(num[i], w, sn);
+        sd = fmaf(den[i], w, sd);
     }
     wpart[((size_t)g * 3 + 0) * N + n] = sn;
     wpart[((size_t)g * 3 + 1) * N + n] = sd;
