@@ -534,7 +534,7 @@ struct EpiPartTN {
 // 1/128 of a tile.  The TN products cover the first Mg = F - F % 128 rows; the 1..TN_TAIL_MAX rows
 // behind them are dot products of H's columns with single columns of V' / P1, one streaming pass over H
 // shared by both statistics: tailp[split][src][j][n], TT_SPLITS row ranges, summed by w_fold_kernel.
-constexpr int TN_TAIL_MAX = 4, TT_SPLITS = 128;
+constexpr int TN_TAIL_MAX = 4, TT_SPLITS = 512;   // (128 row ranges: 101 us for the 131-MB H, half the CUs idle)
 static inline int tn_tail_rows(int F) { return (F > 128 && F % 128 >= 1 && F % 128 <= TN_TAIL_MAX) ? F % 128 : 0; }
 // VEC4 (N % 4 == 0): four columns per thread, 16-byte loads of H, eight rows in flight (one column and
 // four rows per thread ran the 131 MB of a 32k-frame H at 0.56 TB/s: 234 us)
