@@ -592,6 +592,30 @@ tn_tail_kernel(const float* __restrict__ A0, const float* __restrict__ A1, const
         }
 }
 
+// tailp[TT_SPLITS][2][TN_TAIL_MAX][N] -> tailr[2][TN_TAIL_MAX][N] (stored behind the partials): 64 columns x 4
+// lanes of row ranges per workgroup, eight partials in flight per lane, the four lanes added in LDS in a
+// fixed order.  (Summed by w_fold_kernel's one thread per column, the 512 partials were a 178-us serial chain.)
+__global__ void __launch_bounds__(256)
+tn_tail_reduce_kernel(const float* __restrict__ tailp, float* __restrict__ tailr, int N, int ntail) {
+    __shared__ float part[4][64];
+    if ((int)(blockIdx.y % TN_TAIL_MAX) >= ntail) return;                  // (rows the tail pass never wrote)
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl, sj = blockIdx.y;                 // sj = src * TN_TAIL_MAX + j
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        constexpr int PER = TT_SPLITS / 4;
+        for (int s0 = lane * PER; s0 < (lane + 1) * PER; s0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                a8[u] += tailp[((size_t)(s0 + u) * 2 * TN_TAIL_MAX + sj) * N + col];
+        }
+    }
+    part[lane][cl] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    __syncthreads();
+    if (lane == 0 && col < N)
+        tailr[(size_t)sj * N + col] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
 // column sums over frames of H: hs[n] (beta == 1 W update)
 __global__ void __launch_bounds__(256)
 colsum_rows_kernel(const float* __restrict__ H, float* __restrict__ part, int64_t n, int N,
@@ -658,11 +682,10 @@ w_fold_kernel(const float* __restrict__ W, float* __restrict__ PN, float* __rest
         const int f = f0 + i;
         if (f >= F) break;
         const size_t o = (size_t)f * N + n;
-        if (f >= Mg) {                                 // odd rows: tn_tail_kernel's partials
-            for (int s = 0; s < TT_SPLITS; ++s) {
-                num[i] += tailp[(((size_t)s * 2 + 0) * TN_TAIL_MAX + (f - Mg)) * N + n];
-                if (!beta_is_one) den[i] += tailp[(((size_t)s * 2 + 1) * TN_TAIL_MAX + (f - Mg)) * N + n];
-            }
+        if (f >= Mg) {                                 // odd rows: tn_tail_kernel's sums, folded by tn_tail_reduce_kernel
+            const float* tailr = tailp + (size_t)TT_SPLITS * 2 * TN_TAIL_MAX * N;
+            num[i] += tailr[(size_t)(0 * TN_TAIL_MAX + (f - Mg)) * N + n];
+            if (!beta_is_one) den[i] += tailr[(size_t)(1 * TN_TAIL_MAX + (f - Mg)) * N + n];
         }
         PN[o] = num[i];                                // (folded in place: slot 0)
         if (!beta_is_one) PD[o] = den[i];
@@ -763,7 +786,7 @@ TrWs tr_ws(int64_t n, int F, int N) {
     w.off_obj = take((size_t)((n + 127) / 128) * (((F + 127) / 128) + ((N + 127) / 128)) * 4);
     w.off_min = take(256);
     w.off_wpart = take(((size_t)((F + W_FB - 1) / W_FB) * 3 + 1) * N * 4);
-    w.off_tailp = take((size_t)TT_SPLITS * 2 * TN_TAIL_MAX * N * 4);
+    w.off_tailp = take((size_t)(TT_SPLITS + 1) * 2 * TN_TAIL_MAX * N * 4);      // partials + their sums
     w.total = o;
     return w;
 }
@@ -902,6 +925,8 @@ extern "C" int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F,
             else
                 hipLaunchKernelGGL(tn_tail_kernel<false>, dim3((N + 255) / 256, TT_SPLITS), dim3(256), 0, stream,
                                    num_src, den_src, H, tailp, n, N, Fp4, Mg, ntail);
+            hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3((N + 63) / 64, 2 * TN_TAIL_MAX), dim3(256), 0, stream,
+                               tailp, tailp + (size_t)TT_SPLITS * 2 * TN_TAIL_MAX * N, N, ntail);
         }
         gemm_tn::Operands tn{num_src, H, n, Mg, N, Fp4, N};
         DRNMF_HIP(h, gemm_tn::launch(tn, EpiPartTN{PN, N, pstr}, nsplit, stream));

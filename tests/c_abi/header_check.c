@@ -30,3 +30,14 @@ fn_t drnmf_all_exports[] = {
     REF(drnmf_broadcast_params), REF(drnmf_cell_launches_per_frame),
     REF(drnmf_dense_cell_forward_dropout), REF(drnmf_dense_cell_backward_dropout),
 };
+
+/* Layout of the one struct that crosses the ABI in DEVICE memory, built by the host language
+ * (dr-nmf_amd/ops.py adam_block_table: numpy dtype {u8 param, i8 flat_off, i4 count, i4 reserved}): 24 bytes,
+ * no padding.  (C99 has no static assert: a negative array size fails the compilation.) */
+#include <stddef.h>
+typedef char drnmf_adam_block_is_24_bytes[sizeof(drnmf_adam_block_t) == 24 ? 1 : -1];
+typedef char drnmf_adam_block_offsets[(offsetof(drnmf_adam_block_t, param) == 0 &&
+                                       offsetof(drnmf_adam_block_t, flat_off) == 8 &&
+                                       offsetof(drnmf_adam_block_t, count) == 16 &&
+                                       offsetof(drnmf_adam_block_t, reserved) == 20) ? 1 : -1];
+typedef char drnmf_cell_desc_is_12_int32[sizeof(drnmf_cell_desc_t) == 48 ? 1 : -1];
