@@ -599,6 +599,11 @@ class SimpleDeepRNN(_Layer):
         if self._train_blockers:
             raise NotImplementedError('training with %s is not implemented' %
                                       ', '.join(self._train_blockers))
+        if self.stateful:
+            # (Keras would enter each batch with the state the previous one left, as a constant of the
+            # gradient: custom_layers.py:296-318; enhance.py never trains a stateful layer.  The BPTT
+            # kernels start every sequence from softplus(log_h0), so refuse instead of ignoring the state)
+            raise NotImplementedError('training a stateful layer is not implemented')
         if not self.built:
             self.build(tuple(x.shape))
         if self._dense_now or getattr(self, '_train_dense', False) or self.dropout_U:
@@ -682,8 +687,6 @@ class SimpleDeepRNN(_Layer):
         return leaves, U, S, W, b, h0
 
     def _forward_train_dense(self, x, mask_value):
-        if self.stateful:
-            raise NotImplementedError('training a stateful layer is not implemented')
         B, T, F = x.shape
         leaves, U, S, W, b, h0 = self._dense_matrices_torch()
         desc = ops.make_dense_desc(B, T, F, self.output_dim, self.K_layers,

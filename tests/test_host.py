@@ -99,6 +99,8 @@ def test_simple_deep_rnn_config_surface():
     st = layers.SimpleDeepRNN(N, **dict(ok, stateful=True))      # stateful mode is supported
     with pytest.raises(ValueError):
         st.reset_states()                                        # batch size not known yet
+    with pytest.raises(NotImplementedError):                     # ... forward only: the BPTT starts every
+        st.forward_train(None)                                   # sequence from softplus(log_h0)
     # configurations outside build_unfolded_snmf's are accepted (general dense-matrix kernel,
     # forward only) ...
     for generic in (dict(activation="tanh"), dict(flag_nonnegative=False),
