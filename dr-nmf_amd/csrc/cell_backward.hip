@@ -576,8 +576,18 @@ dlogd_sum_kernel(float* __restrict__ P, const float* __restrict__ Dn, float* __r
             const int f = (blockIdx.y * 4 + fl) * bpt + i;
             if (f >= F) break;
             const size_t o = (size_t)f * Np + n;
+            // (eight splits' loads in flight, added in split order: one dependent 16-byte load per split
+            // made N = 200 layers wait 20 us here)
             f32x4 g = *(const f32x4*)(P + o);
-            for (int sidx = 1; sidx < splits; ++sidx) g += *(const f32x4*)(P + sidx * stride + o);
+            for (int s0 = 1; s0 < splits; s0 += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = *(const f32x4*)(P + (size_t)(s0 + u < splits ? s0 + u : splits - 1) * stride + o);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (s0 + u < splits) g += v[u];
+            }
             *(f32x4*)(P + o) = g;
             const f32x4 dn = *(const f32x4*)(Dn + o);
 #pragma unroll
@@ -597,7 +607,15 @@ dlogd_apply_kernel(const float* __restrict__ P, const float* __restrict__ Dn,
     const int n = (blockIdx.x * 64 + qn) * 4;
     if (n >= N) return;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
-    for (int gq = 0; gq < ngroups; ++gq) c += *(const f32x4*)(cpart + (size_t)gq * Np + n);
+    for (int g0 = 0; g0 < ngroups; g0 += 16) {          // (16 loads in flight, added in group order)
+        f32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            v[u] = *(const f32x4*)(cpart + (size_t)(g0 + u < ngroups ? g0 + u : ngroups - 1) * Np + n);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (g0 + u < ngroups) c += v[u];
+    }
     for (int i = 0; i < bpt; ++i) {
         const int f = (blockIdx.y * 4 + fl) * bpt + i;
         if (f >= F) break;
@@ -622,8 +640,7 @@ dlogd_kernel(const float* __restrict__ P, const float* __restrict__ Dn, float* _
     float c = 0.f;
     if (ok) {
         for (int f = fg; f < F; f += 8) {
-            float g = 0.f;
-            for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)f * Np + n];
+            const float g = ordered_sum<8>(P + (size_t)f * Np + n, stride, splits);
             c = fmaf(g, Dn[(size_t)f * Np + n], c);
         }
     }
@@ -634,8 +651,7 @@ dlogd_kernel(const float* __restrict__ P, const float* __restrict__ Dn, float* _
 #pragma unroll
     for (int i = 0; i < 8; ++i) c += cs[i][ln];
     for (int f = fg; f < F; f += 8) {
-        float g = 0.f;
-        for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)f * Np + n];
+        const float g = ordered_sum<8>(P + (size_t)f * Np + n, stride, splits);
         const float dn = Dn[(size_t)f * Np + n];
         const float v = dn * (g - dn * c);
         float* o = dlogD + (size_t)f * N + n;
@@ -914,12 +930,17 @@ colreduce_fold_kernel(float* __restrict__ part, int N, int Np, float* __restrict
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     float sb = 0.f, sg = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int s = 0; s < CR_SPLITS; ++s) {
-        const float* p = part + (size_t)s * CR_SLOTS * Np + n;
-        sb += p[0];
-        sg += p[(size_t)Np];
-        s1 += p[(size_t)2 * Np];
-        s2 += p[(size_t)3 * Np];
+    static_assert(CR_SPLITS % 32 == 0, "colreduce folds walk the splits eight at a time");
+    for (int s0 = 0; s0 < CR_SPLITS; s0 += 8) {          // (32 loads in flight, added in split order)
+        float v[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* p = part + (size_t)(s0 + u) * CR_SLOTS * Np + n;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = p[(size_t)k * Np];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sb += v[u][0]; sg += v[u][1]; s1 += v[u][2]; s2 += v[u][3]; }
     }
     part[n] = sb;
     part[(size_t)Np + n] = sg;
@@ -939,12 +960,16 @@ colreduce_fold_lanes_kernel(float* __restrict__ part, int N, int Np, float* __re
     const int n = blockIdx.x * 64 + c;
     float sb = 0.f, sg = 0.f, s1 = 0.f, s2 = 0.f;
     if (n < N)
-        for (int s = sl; s < CR_SPLITS; s += 4) {
-            const float* p = part + (size_t)s * CR_SLOTS * Np + n;
-            sb += p[0];
-            sg += p[(size_t)Np];
-            s1 += p[(size_t)2 * Np];
-            s2 += p[(size_t)3 * Np];
+        for (int s0 = sl; s0 < CR_SPLITS; s0 += 32) {   // (eight of the lane's splits = 32 loads in flight)
+            float v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* p = part + (size_t)(s0 + 4 * u) * CR_SLOTS * Np + n;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[u][k] = p[(size_t)k * Np];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sb += v[u][0]; sg += v[u][1]; s1 += v[u][2]; s2 += v[u][3]; }
         }
     acc[0][sl][c] = sb; acc[1][sl][c] = sg; acc[2][sl][c] = s1; acc[3][sl][c] = s2;
     __syncthreads();
@@ -997,8 +1022,7 @@ dlogh0_kernel(const float* __restrict__ dh0_part, const float* __restrict__ log_
               float* __restrict__ d_log_h0, int N, int Np, int numM) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
-    float s = 0.f;
-    for (int m = 0; m < numM; ++m) s += dh0_part[(size_t)m * Np + n];
+    const float s = ordered_sum<8>(dh0_part + n, (size_t)Np, numM);
     d_log_h0[n] = s / (1.f + expf(-log_h0[n]));   // d softplus = sigmoid
 }
 

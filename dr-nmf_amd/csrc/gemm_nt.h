@@ -27,6 +27,7 @@ struct Operands {
     int N, K;
     int64_t lda, ldb;
     int ktail = 0;    // extra contraction columns K .. K+ktail-1 (<= 2), see below
+    int thin = 0;     // 1: output column N (row N of Bt) exists BEHIND the N tiled columns, see THIN below
 };
 
 // VEC: lda, ldb, K multiples of 4, base pointers 16-byte aligned -> one branch-free float4 load
@@ -79,7 +80,14 @@ template <class E, class = void> struct epi_early : std::true_type {};
 template <class E> struct epi_early<E, std::void_t<decltype(E::EARLY)>>
     : std::integral_constant<bool, E::EARLY> {};
 
-template <class Epi, bool VEC>
+// THIN (launch() sets it up: VEC, no ktail, N = 128 j + 1 -- the 513 / 257 / 1025 bins of a 2^k + 1 STFT):
+// the one column behind the last full tile is not given a fifth, 1/128-full column of workgroups (a
+// fifth of the launch, even with its MFMAs switched off: NB below).  Every A value passes through the
+// registers of ONE thread of every column tile's workgroup on its way to LDS (gload -> swrite); the
+// thread multiplies them with the matching 16 bytes of Bt's row N -- one extra 16-byte load and 16 FMAs
+// per thread and k-tile, no extra pass over A; the eight k-lanes of a row are added after the loop and
+// the workgroup of column tile tn stores the rows of staging slice i = tn (srow + 32 i).
+template <class Epi, bool VEC, bool THIN = false>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDS_LD];
     const int tid = threadIdx.x;
@@ -108,7 +116,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
     // (swrite).  In the vector path the out-of-range zeroing is therefore applied in swrite, not
     // at the load: a select right behind the load made the compiler wait for every load (vmcnt)
     // ahead of the MFMA phase, i.e. the global-load latency was exposed once per k-tile.
-    f32x4 ra[4], rb[4];
+    f32x4 ra[4], rb[4], rt = {0.f, 0.f, 0.f, 0.f};
+    float tacc[4] = {0.f, 0.f, 0.f, 0.f};
+    // staging slices whose thin-column products this workgroup owns (workgroup-uniform)
+    bool mine[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mine[i] = THIN && (tiles_n >= 4 ? i == tn : i % tiles_n == tn);
     auto raw4 = [&](const float* base, int64_t row, int64_t nrows, int64_t ld, int k) {
         const int64_t rr = row < nrows ? row : nrows - 1;
         const int kc = k < g.K ? k : 0;
@@ -118,6 +131,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (VEC) {
+                // (row N of Bt first: swrite's first use of it then waits for the oldest load only)
+                if (THIN && i == 0) rt = raw4(g.Bt, g.N, g.N + 1, g.ldb, k0 + sk);
                 ra[i] = raw4(g.A, m0 + srow + 32 * i, g.M, g.lda, k0 + sk);
                 rb[i] = raw4(g.Bt, n0 + srow + 32 * i, g.N, g.ldb, k0 + sk);
             } else {
@@ -139,6 +154,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
             }
             *(f32x4*)(As + (srow + 32 * i) * LDS_LD + sk) = va;
             *(f32x4*)(Bs + (srow + 32 * i) * LDS_LD + sk) = vb;
+            if (THIN) {      // (all four slices, branch-free: a workgroup-uniform `if (mine[i])` splits the
+                f32x4 vt = rt;   // k-tile's basic block and with it the MFMA / LDS-write interleave)
+                if (!kok) vt = f32x4{0.f, 0.f, 0.f, 0.f};
+                tacc[i] += (va[0] * vt[0] + va[1] * vt[1]) + (va[2] * vt[2] + va[3] * vt[3]);
+            }
         }
     };
     // One k-tile = 4 chunks of 8 contraction slots = 64 MFMAs per wave.  Everything else a k-tile
@@ -206,6 +226,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 global load
                 }
+                if (THIN) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // (row N of Bt)
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);       // reads land under these
             }
@@ -326,6 +347,22 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
     };
     if (m032 + BM <= M32) finish(std::true_type{});
     else finish(std::false_type{});
+    if (THIN) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!mine[i]) continue;
+            float t = tacc[i];
+            t += __shfl_xor(t, 1, 64);          // the eight k-lanes (tid & 7) of staging row tid >> 3
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            const int row = m032 + srow + 32 * i;
+            if ((tid & 7) == 0 && row < M32) {
+                const f32x2 pv = epi.pre(row, g.N);
+                if constexpr (RED) red += epi(row, g.N, t, pv);
+                else epi(row, g.N, t, pv);
+            }
+        }
+    }
     if constexpr (RED) {
         __syncthreads();                       // every wave is done with the staged tiles
         lds[tid] = red;
@@ -339,13 +376,21 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
 }
 
 template <class Epi>
-inline hipError_t launch(const Operands& g, const Epi& epi, hipStream_t stream) {
+inline hipError_t launch(const Operands& g_in, const Epi& epi, hipStream_t stream) {
+    Operands g = g_in;
     const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) &&
                      (((uintptr_t)g.A & 15) == 0) && (((uintptr_t)g.Bt & 15) == 0);
+    // N = 128 j + 1: the odd column rides on the full tiles' staging (THIN above)
+    const char* te = tune_env("DRNMF_THIN");                  // measurement aid: 0 = a tile column of its own
+    const bool thin = vec && g.ktail == 0 && g.N > BN && g.N % BN == 1 && !(te && atoi(te) == 0);
+    if (thin) { g.N -= 1; g.thin = 1; }
     const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (tiles <= 0 || tiles > 0x7fffffff || g.M > 0x7fffff00 || g.ktail < 0 || g.ktail > 2)
         return hipErrorInvalidValue;
-    if (vec)
+    if (thin)
+        hipLaunchKernelGGL((gemm_nt_kernel<Epi, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream,
+                           g, epi);
+    else if (vec)
         hipLaunchKernelGGL((gemm_nt_kernel<Epi, true>), dim3((unsigned)tiles), dim3(256), 0, stream,
                            g, epi);
     else

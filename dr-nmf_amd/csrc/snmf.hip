@@ -380,21 +380,26 @@ extern "C" int32_t drnmf_ista_forward(drnmf_handle_t h, int64_t n, int32_t F, in
     // odd bins (F = 16 j + 1 | 2, the 2^k + 1 STFT sizes) stay out of the GEMM tiles
     const int nt = (F % 16 != 0 && F % 16 <= 2 && F > 16) ? F % 16 : 0;
     const int Fm = F - nt;
-    gemm::Operands g1{H, W, n, Fm, N, N, N};                     // X^ = H . W^T  (contract atoms)
+    // ... riding on the X^ product's full tiles (gemm_nt.h THIN) when there is one of them behind whole
+    // 128-column tiles and the operands allow 16-byte loads, else by ista_tail_kernel
+    const char* te = tune_env("DRNMF_THIN");
+    const bool thin = nt == 1 && Fm % gemm::BN == 0 && N % 4 == 0 && (((uintptr_t)H | (uintptr_t)W) & 15) == 0 &&
+                      !(te && atoi(te) == 0);
+    gemm::Operands g1{H, W, n, thin ? F : Fm, N, N, N};          // X^ = H . W^T  (contract atoms)
     gemm::Operands g2{R, Wt, n, N, nt ? Fm : Fp4, Fp4, Fp4, nt};   // G = R . W (contract bins; odd bins: ktail)
     const dim3 tgrid((unsigned)((n + 3) / 4));
     for (int k = 0; k < K; ++k) {
         if (divergence == DRNMF_DIV_ED) {
             DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_ED>{X, R, F, Fp4, beta}, stream));
-            if (nt) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_ED>, tgrid, dim3(256), 0, stream,
+            if (nt && !thin) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_ED>, tgrid, dim3(256), 0, stream,
                                        X, W, H, R, n, F, N, Fm, nt, Fp4, beta);
         } else if (divergence == DRNMF_DIV_KL) {
             DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_KL>{X, R, F, Fp4, beta}, stream));
-            if (nt) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_KL>, tgrid, dim3(256), 0, stream,
+            if (nt && !thin) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_KL>, tgrid, dim3(256), 0, stream,
                                        X, W, H, R, n, F, N, Fm, nt, Fp4, beta);
         } else {
             DRNMF_HIP(h, gemm::launch(g1, EpiResidual<DRNMF_DIV_BETA>{X, R, F, Fp4, beta}, stream));
-            if (nt) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_BETA>, tgrid, dim3(256), 0,
+            if (nt && !thin) hipLaunchKernelGGL(ista_tail_kernel<DRNMF_DIV_BETA>, tgrid, dim3(256), 0,
                                        stream, X, W, H, R, n, F, N, Fm, nt, Fp4, beta);
         }
         const float c0 = -lam1 / alph, c1 = 1.f / alph;
@@ -464,11 +469,16 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
     // beta == 2: odd bins (F = 16 j + 1 | 2) stay out of the GEMM tiles, as in drnmf_ista_forward
     const int nt = (beta == 2.f && F % 16 != 0 && F % 16 <= 2 && F > 16) ? F % 16 : 0;
     const int Fm = F - nt;
-    gemm::Operands gl{H, Wn, n, Fm, N, N, N};           // W H  (row layout: H . Wn^T)
+    // (the odd bin's lambda: rides on the product's full tiles when the shape allows, as in
+    // drnmf_ista_forward, else mu_tail_kernel)
+    const char* te = tune_env("DRNMF_THIN");
+    const bool thin = nt == 1 && Fm % gemm::BN == 0 && N % 4 == 0 && (((uintptr_t)H | (uintptr_t)Wn) & 15) == 0 &&
+                      !(te && atoi(te) == 0);
+    gemm::Operands gl{H, Wn, n, thin ? F : Fm, N, N, N};           // W H  (row layout: H . Wn^T)
     auto launch_lambda = [&]() -> hipError_t {
         if (beta == 2.f) {
             hipError_t e = gemm::launch(gl, EpiLambda<2>{Vuse, P1, P2, nullptr, F, Fp4, beta, flr}, stream);
-            if (e == hipSuccess && nt)
+            if (e == hipSuccess && nt && !thin)
                 hipLaunchKernelGGL(mu_tail_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
                                    stream, Wn, H, P1, n, N, Fm, nt, Fp4, flr);
             return e;
@@ -656,8 +666,7 @@ w_fold_kernel(const float* __restrict__ W, float* __restrict__ PN, float* __rest
     const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (n >= N) return;
     float hs = 0.f;
-    if (beta_is_one)
-        for (int s = 0; s < hs_splits; ++s) hs += hs_part[(size_t)s * N + n];
+    if (beta_is_one) hs = ordered_sum<16>(hs_part + n, (size_t)N, hs_splits);
     float sn = 0.f, sd = 0.f;
     const int f0 = g * W_FB;
     // the group's W_FB bins side by side: W_FB (x 2) independent loads in flight per split (bin by bin the
@@ -666,14 +675,29 @@ w_fold_kernel(const float* __restrict__ W, float* __restrict__ PN, float* __rest
     float num[W_FB], den[W_FB];
 #pragma unroll
     for (int i = 0; i < W_FB; ++i) { num[i] = 0.f; den[i] = beta_is_one ? hs : 0.f; }
-    for (int s = 0; s < nsplit; ++s) {
+    // (four splits' loads in flight; bins outside the products re-read a valid element and add +0)
+    for (int s0 = 0; s0 < nsplit; s0 += 4) {
+        float vn[4][W_FB], vd[4][W_FB];
 #pragma unroll
-        for (int i = 0; i < W_FB; ++i) {
-            const int f = f0 + i;
-            if (f < F && f < Mg) {
-                const size_t o = (size_t)f * N + n;
-                num[i] += PN[s * stride + o];
-                if (!beta_is_one) den[i] += PD[s * stride + o];
+        for (int u = 0; u < 4; ++u) {
+            const int sp = s0 + u < nsplit ? s0 + u : nsplit - 1;
+#pragma unroll
+            for (int i = 0; i < W_FB; ++i) {
+                const int f = f0 + i;
+                const size_t o = (size_t)((f < F && f < Mg) ? f : 0) * N + n;
+                vn[u][i] = PN[sp * stride + o];
+                if (!beta_is_one) vd[u][i] = PD[sp * stride + o];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool su = s0 + u < nsplit;
+#pragma unroll
+            for (int i = 0; i < W_FB; ++i) {
+                const int f = f0 + i;
+                const bool ok = su && f < F && f < Mg;
+                num[i] += ok ? vn[u][i] : 0.f;
+                if (!beta_is_one) den[i] += ok ? vd[u][i] : 0.f;
             }
         }
     }
@@ -704,23 +728,29 @@ w_apply_kernel(float* __restrict__ W, const float* __restrict__ PN, const float*
     const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, ng = gridDim.y;
     if (n >= N) return;
     const bool do_upd = upd ? upd[n] != 0 : true;
-    float sn = 0.f, sd = 0.f;
-    for (int q = 0; q < ng; ++q) {
-        sn += wpart[((size_t)q * 3 + 0) * N + n];
-        sd += wpart[((size_t)q * 3 + 1) * N + n];
-    }
+    const float sn = ordered_sum<16>(wpart + n, (size_t)3 * N, ng);
+    const float sd = ordered_sum<16>(wpart + (size_t)N + n, (size_t)3 * N, ng);
     const float hs = beta_is_one ? wpart[((size_t)ng * 3) * N + n] : 0.f;
     float s2 = 0.f;
-    const int f1 = (g + 1) * W_FB < F ? (g + 1) * W_FB : F;
-    for (int f = g * W_FB; f < f1; ++f) {
-        const size_t o = (size_t)f * N + n;
-        float w = W[o];
+    float wv[W_FB], nv[W_FB], dv[W_FB];
+#pragma unroll
+    for (int i = 0; i < W_FB; ++i) {                   // (all loads first: bins past F re-read the group's first)
+        const int f = g * W_FB + i;
+        const size_t o = (size_t)(f < F ? f : g * W_FB) * N + n;
+        wv[i] = W[o];
+        nv[i] = PN[o];
+        dv[i] = beta_is_one ? hs : PD[o];
+    }
+#pragma unroll
+    for (int i = 0; i < W_FB; ++i) {
+        const int f = g * W_FB + i;
+        if (f >= F) break;
+        float w = wv[i];
         if (do_upd) {
-            const float num = PN[o], den = beta_is_one ? hs : PD[o];
-            const float dpw = fmaxf(den + w * sn, flr);
-            const float dmw = num + w * sd;
+            const float dpw = fmaxf(dv[i] + w * sn, flr);
+            const float dmw = nv[i] + w * sd;
             w = w * dmw / dpw;
-            W[o] = w;
+            W[(size_t)f * N + n] = w;
         }
         s2 = fmaf(w, w, s2);
     }
@@ -730,11 +760,19 @@ __global__ void __launch_bounds__(256)
 w_norm_kernel(float* __restrict__ W, const float* __restrict__ wpart, int F, int N) {
     const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, ng = gridDim.y;
     if (n >= N) return;
-    float s2 = 0.f;
-    for (int q = 0; q < ng; ++q) s2 += wpart[((size_t)q * 3 + 2) * N + n];
+    const float s2 = ordered_sum<16>(wpart + (size_t)2 * N + n, (size_t)3 * N, ng);
     const float inv = 1.f / sqrtf(s2);
-    const int f1 = (g + 1) * W_FB < F ? (g + 1) * W_FB : F;
-    for (int f = g * W_FB; f < f1; ++f) W[(size_t)f * N + n] *= inv;
+    float wv[W_FB];
+#pragma unroll
+    for (int i = 0; i < W_FB; ++i) {
+        const int f = g * W_FB + i;
+        wv[i] = W[(size_t)(f < F ? f : g * W_FB) * N + n];
+    }
+#pragma unroll
+    for (int i = 0; i < W_FB; ++i) {
+        const int f = g * W_FB + i;
+        if (f < F) W[(size_t)f * N + n] = wv[i] * inv;
+    }
 }
 
 // objective from the per-workgroup partials of the two fused reductions (EpiLambdaObj, EpiMuUpdateSum)

@@ -177,8 +177,7 @@ dkernel_kernel(const float* __restrict__ P, const float* __restrict__ E, float* 
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)r * F) return;
     const int n = (int)(i / F), f = (int)(i % F);
-    float g = 0.f;
-    for (int s = 0; s < splits; ++s) g += P[s * stride + (size_t)n * Fp4 + f];
+    const float g = ordered_sum<8>(P + (size_t)n * Fp4 + f, stride, splits);
     dK[i] = g * E[(size_t)n * Fp4 + f];
 }
 

@@ -1078,9 +1078,15 @@ class UnfoldedSNMFModel(object):
                 raise NotImplementedError("operand_dtype='float16' trains on the fused path only")
             self._train_items = cell.trainable_weight_items()
         else:
-            self._train_items = [('log_h0', cell.log_h0)]
-            self._train_items += [(k, cell._alt[k]) for k in cell._alt
-                                  if k in cell.keys_trainable]
+            # flat-buffer order = the order of the BPTT's stacked outputs (d_log_D [n_D,F,N], d_log_h0,
+            # d_log_alph, d_log_lam1), so that the kernels write their gradients straight into the flat
+            # buffer (_grad_targets) instead of 2K+3 device-to-device copies per step
+            sl = cell.grad_slices()
+            names = [w for w, gk, _ in sl if gk == 'd_log_D'] + ['log_h0'] + \
+                    [w for w, gk, _ in sl if gk != 'd_log_D']
+            names += [k for k in cell._alt if k not in names]
+            self._train_items = [(k, cell.log_h0 if k == 'log_h0' else cell._alt[k]) for k in names
+                                 if k == 'log_h0' or k in cell.keys_trainable]
         self._train_items += [('kernel_clean', self.clean.kernel), ('kernel_noise', self.noise.kernel)]
         total = sum(int(t.numel()) for _, t in self._train_items)
         self._flat = torch.zeros(total + self.N_SCALARS, dtype=torch.float32, device=cell.device)
@@ -1094,12 +1100,50 @@ class UnfoldedSNMFModel(object):
             self._opt_state[n] = (self._mflat[o:o + t.numel()].view(t.shape),
                                   self._vflat[o:o + t.numel()].view(t.shape))
             o += t.numel()
+        self._grad_targets = self._make_grad_targets()
         self._adam_table = None          # (table, n_blocks, storage pointers it was built for)
         self._sumsq = torch.zeros(256, dtype=torch.float32, device=cell.device)
         self._pending = []               # DeviceLoss of recent steps, oldest first
         self._step_no = 0
         self.sync_replicas()
         return self
+
+    def _make_grad_targets(self):
+        """Views of the flat gradient buffer the kernels write into: (`grads` of cell.backward -- a
+        stacked output whose slices are ALL trained and lie next to each other in stack order --,
+        (sums, d_kernel_clean, d_kernel_noise) of the loss head).  What has no view is copied."""
+        cell, gv, ns = self.cell, self._gview, self.N_SCALARS
+        head = (self._flat[-ns:-ns + 2], gv['kernel_clean'], gv['kernel_noise'])
+        if cell._train_dense:
+            return {}, head
+        off, o = {}, 0
+        for n, t in self._train_items:
+            off[n] = (o, int(t.numel()))
+            o += int(t.numel())
+        grads = {'d_log_h0': gv['log_h0'].view(-1)}
+        by_key = {}
+        for wname, gkey, idx in cell.grad_slices():
+            by_key.setdefault(gkey, []).append((idx, wname))
+        for gkey, lst in by_key.items():
+            lst.sort()
+            if any(w not in off for _, w in lst):
+                continue
+            start, size = off[lst[0][1]]
+            if all(off[w] == (start + i * size, size) for i, (_, w) in enumerate(lst)):
+                grads[gkey] = self._flat[start:start + len(lst) * size].view(len(lst), -1)
+        return grads, head
+
+    def _collect_grads(self, g):
+        """Whatever cell.backward did not write into the flat buffer itself."""
+        gv = self._gview
+        if 'by_name' in g:                          # dense-matrix path: gradients per weight name
+            for wname, gw in g['by_name'].items():
+                gv[wname].copy_(gw.reshape(gv[wname].shape))
+            return
+        direct = self._grad_targets[0]
+        for wname, gkey, idx in self.cell.grad_slices():
+            if wname in gv and gkey not in direct:
+                gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
 
     def sync_replicas(self, root=0):
         """Data parallelism: every weight of the model (trainable or not) is replaced by rank
@@ -1139,34 +1183,24 @@ class UnfoldedSNMFModel(object):
         h_off = (K - 1) * N
         mask, A, Bn = ops.head_forward(hall, self.clean.kernel, self.noise.kernel,
                                        square=self.square, want_ab=True, h_off=h_off)
-        sums, d_hidden, dkc, dkn = ops.loss_head_backward(
+        grads, head_out = self._grad_targets
+        _, d_hidden, _, _ = ops.loss_head_backward(
             x, hall, self.clean.kernel, self.noise.kernel, mask, A, Bn, y, sample_weight,
-            square=self.square, h_off=h_off)
+            square=self.square, h_off=h_off, out=head_out)
         mark('head_and_loss', 1)
         mark('cell_backward', 0)
-        g = cell.backward(x, hall, d_hidden, profile=getattr(self, 'backward_profile', None))
+        g = cell.backward(x, hall, d_hidden, grads=grads,
+                          profile=getattr(self, 'backward_profile', None))
         mark('cell_backward', 1)
-        self._flat.zero_()
-        gv = self._gview
-        if 'by_name' in g:                          # dense-matrix path: gradients per weight name
-            for wname, gw in g['by_name'].items():
-                gv[wname].copy_(gw.reshape(gv[wname].shape))
-        else:
-            gv['log_h0'].copy_(g['d_log_h0'])
-            for wname, gkey, idx in cell.grad_slices():
-                if wname in gv:
-                    gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
-        gv['kernel_clean'].copy_(dkc)
-        gv['kernel_noise'].copy_(dkn)
-        self._set_scalars(sums, x, live)
+        self._collect_grads(g)
+        self._set_scalars(x, live)
         return self._flat
 
-    def _set_scalars(self, sums, x, live=True):
-        # (a step that is not live -- fit() on a rank whose shard has run out replays a batch with
-        # zero weights -- contributes no rows either: 'rows' feeds p = count / rows of
+    def _set_scalars(self, x, live=True):
+        # tail of the flat buffer: [sum w*mse, count] were written by the loss head (_grad_targets), then
+        # rows and the fault word.  (A step that is not live -- fit() on a rank whose shard has run out
+        # replays a batch with zero weights -- contributes no rows either: 'rows' feeds p = count / rows of
         # loss_norm='keras204', which must be the GLOBAL batch's, not inflated by the replay)
-        ns = self.N_SCALARS
-        self._flat[-ns:-ns + 2].copy_(sums)
         # (fill_, a kernel: `tensor[i] = python_float` is a BLOCKING host-to-device copy of a CPU scalar --
         # one hidden hipMemcpyWithStream per step in rounds 1-3, profiles/r04g_step_hip_api_delta.txt)
         self._flat[-2:-1].fill_(float(x.shape[0] * x.shape[1]) if live else 0.0)
@@ -1545,23 +1579,13 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
         _, A, Bn = ops.head_forward(hall, self.clean.kernel, self.noise.kernel, want_ab=True,
                                     h_off=h_off)
         # the targets are the input itself (enhance.py:1110); y is accepted for API symmetry
-        sums, d_hidden, dkc, dkn = ops.snmf_cost_head_backward(
+        grads, head_out = self._grad_targets
+        _, d_hidden, _, _ = ops.snmf_cost_head_backward(
             self._first(y), hall, self.clean.kernel, self.noise.kernel, A, Bn,
-            self._first(sample_weight), self.loss_weights[1], h_off=h_off)
-        g = cell.backward(x, hall, d_hidden)
-        self._flat.zero_()
-        gv = self._gview
-        if 'by_name' in g:                          # dense-matrix path: gradients per weight name
-            for wname, gw in g['by_name'].items():
-                gv[wname].copy_(gw.reshape(gv[wname].shape))
-        else:
-            gv['log_h0'].copy_(g['d_log_h0'])
-            for wname, gkey, idx in cell.grad_slices():
-                if wname in gv:
-                    gv[wname].copy_(g[gkey][idx].reshape(gv[wname].shape))
-        gv['kernel_clean'].copy_(dkc)
-        gv['kernel_noise'].copy_(dkn)
-        self._set_scalars(sums, x, live)
+            self._first(sample_weight), self.loss_weights[1], h_off=h_off, out=head_out)
+        g = cell.backward(x, hall, d_hidden, grads=grads)
+        self._collect_grads(g)
+        self._set_scalars(x, live)
         return self._flat
 
     def train_on_batch(self, x, y=None, sample_weight=None, _live=True):

@@ -363,10 +363,25 @@ def head_forward(hidden, kernel_clean, kernel_noise, square=False, want_ab=False
     return (mask, A, Bn) if want_ab else mask
 
 
+def _head_grad_outputs(out, kc, kn, dev):
+    """(sums[2], d_kernel_clean, d_kernel_noise): the caller's `out` triple (contiguous fp32 device
+    tensors of those sizes, e.g. views of a flat gradient buffer) or fresh tensors."""
+    if out is None:
+        return (torch.empty(2, dtype=torch.float32, device=dev), torch.empty_like(kc),
+                torch.empty_like(kn))
+    sums, dkc, dkn = out
+    for t, n, ref in ((sums, 2, None), (dkc, kc.numel(), kc), (dkn, kn.numel(), kn)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n or t.device != dev:
+            raise ValueError("head gradient outputs must be contiguous float32 device tensors of the "
+                             "sizes of sums[2] / kernel_clean / kernel_noise")
+    return sums, dkc, dkn
+
+
 def loss_head_backward(x_raw, hidden, kernel_clean, kernel_noise, mask, A, Bn, y, w, square=False,
-                       h_off=0):
+                       h_off=0, out=None):
     """Unnormalised loss + gradients of the mask head (see drnmf_loss_head_backward).
-    Returns (sums[2] device tensor, d_hidden [..., 2r], d_kernel_clean, d_kernel_noise)."""
+    Returns (sums[2] device tensor, d_hidden [..., 2r], d_kernel_clean, d_kernel_noise); `out` =
+    (sums, d_kernel_clean, d_kernel_noise) to write into."""
     L = _capi.lib()
     h = _capi.handle(_dev_index(hidden))
     x_raw, hidden, mask, A, Bn, y = (_f32c(t, n) for t, n in
@@ -380,9 +395,8 @@ def loss_head_backward(x_raw, hidden, kernel_clean, kernel_noise, mask, A, Bn, y
     if x_raw.numel() != rows * F or w.numel() != rows:
         raise ValueError("loss_head_backward: shape mismatch")
     dev = hidden.device
-    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    sums, dkc, dkn = _head_grad_outputs(out, kc, kn, dev)
     d_hidden = torch.empty(tuple(hidden.shape[:-1]) + (2 * r,), dtype=torch.float32, device=dev)
-    dkc, dkn = torch.empty_like(kc), torch.empty_like(kn)
     nbytes = L.drnmf_loss_head_workspace_bytes(rows, F, r)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rc = L.drnmf_loss_head_backward(h, rows, F, r, _capi.ptr(x_raw), _capi.ptr(hidden), ld,
@@ -396,7 +410,7 @@ def loss_head_backward(x_raw, hidden, kernel_clean, kernel_noise, mask, A, Bn, y
 
 
 def snmf_cost_head_backward(x_raw, hidden, kernel_clean, kernel_noise, A, Bn, w, l1_weight,
-                            h_off=0):
+                            h_off=0, out=None):
     """Unnormalised SNMF-cost pretraining loss + head gradients (drnmf_snmf_cost_head_backward):
     per frame 0.5*mean_f (A+Bn-x)^2 + l1_weight*mean_n |h|.  Same returns as loss_head_backward."""
     L = _capi.lib()
@@ -411,9 +425,8 @@ def snmf_cost_head_backward(x_raw, hidden, kernel_clean, kernel_noise, A, Bn, w,
     if x_raw.numel() != rows * F or w.numel() != rows or A.numel() != rows * F:
         raise ValueError("snmf_cost_head_backward: shape mismatch")
     dev = hidden.device
-    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    sums, dkc, dkn = _head_grad_outputs(out, kc, kn, dev)
     d_hidden = torch.empty(tuple(hidden.shape[:-1]) + (2 * r,), dtype=torch.float32, device=dev)
-    dkc, dkn = torch.empty_like(kc), torch.empty_like(kn)
     nbytes = L.drnmf_loss_head_workspace_bytes(rows, F, r)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rc = L.drnmf_snmf_cost_head_backward(h, rows, F, r, _capi.ptr(x_raw), _capi.ptr(hidden), ld,
