@@ -252,7 +252,8 @@ __device__ __forceinline__ f32x4 mfma32h(f16x8 a, f16x8 b, f32x4 c) {
 // latency, not work) and N x N per stored layer is affordable; the prepared block then also holds
 //   off_gram: G packed as cell_b's operand, [n_D][Np/16][Np/16][q][o%16][e] = G[o][16 ac + 4q + e]
 //   off_dnT:  Dn^T row-major [n_D][Np][Fp] (operand of the frame-parallel x Dn_k product)
-//   off_dn_rm: scratch, one layer of Dn row-major [Fp][Np]
+//   off_dn_rm: scratch, Dn row-major [n_D][round_up(Fp,32)][Np] (zero rows behind Fp): the operand of ONE
+//              split-by-layer TN product for all Gram matrices
 // for fp32 Euclidean descriptors with N <= GRAM_MAX_N (a property of the descriptor's F, N, K only:
 // the same block serves every batch size).
 // The bound is the one gram_wanted() (cell_shared.h) applies to a single row tile: a dictionary wider
@@ -298,7 +299,7 @@ static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     if (gram_eligible(d)) {
         L.off_gram = o;  o += (size_t)d->n_D * L.Np * L.Np * sizeof(float);
         L.off_dnT = o;   o += (size_t)d->n_D * L.Np * L.Fp * sizeof(float);
-        L.off_dn_rm = o; o += (size_t)L.Fp * L.Np * sizeof(float);
+        L.off_dn_rm = o; o += (size_t)d->n_D * round_up(L.Fp, 32) * L.Np * sizeof(float);
     }
     L.total = o;
     return L;

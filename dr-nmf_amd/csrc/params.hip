@@ -268,25 +268,31 @@ int validate_cell_desc(drnmf_handle_t h, const drnmf_cell_desc_t* d) {
     return DRNMF_OK;
 }
 
-// Dp (cell_b's fp32 packing) -> Dn row-major [Fp][Np] and its transpose [Np][Fp]
+// Dp (cell_b's fp32 packing) -> Dn row-major [Fr][Np] (Fr = round_up(Fp, 32), zero rows behind Fp) and its
+// transpose [Np][Fp]; blockIdx.y = stored layer
 __global__ void __launch_bounds__(256)
 unpack_both_kernel(const float* __restrict__ Dp, float* __restrict__ Dn_rm,
-                   float* __restrict__ DnT, int Fp, int Np) {
+                   float* __restrict__ DnT, int Fp, int Np, int Fr) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)Fp * Np) return;
+    if (i >= (size_t)Fr * Np) return;
     const int f = (int)(i / Np), n = (int)(i % Np);
-    const float v = Dp[((size_t)(f >> 4) * (Np / 16) + (n >> 4)) * 256 +
-                       (((n & 15) >> 2) * 16 + (f & 15)) * 4 + (n & 3)];
-    Dn_rm[i] = v;
-    DnT[(size_t)n * Fp + f] = v;
+    const size_t lstride = (size_t)Fp * Np;
+    Dp += blockIdx.y * lstride;
+    float v = 0.f;
+    if (f < Fp) {
+        v = Dp[((size_t)(f >> 4) * (Np / 16) + (n >> 4)) * 256 + (((n & 15) >> 2) * 16 + (f & 15)) * 4 + (n & 3)];
+        DnT[blockIdx.y * lstride + (size_t)n * Fp + f] = v;
+    }
+    Dn_rm[blockIdx.y * (size_t)Fr * Np + i] = v;
 }
 
-struct EpiGramPack {   // G[o][i] = sum_f Dn[f][o] Dn[f][i] -> cell_b operand packing (common.h)
+struct EpiGramPack {   // G_k[o][i] = sum_f Dn_k[f][o] Dn_k[f][i] -> cell_b operand packing (common.h); split = layer k
     float* Gp;
     int NAC;
+    size_t gstride;
     __device__ float pre(int, int, int) const { return 0.f; }
-    __device__ void operator()(int, int o, int i, float acc, float) const {
-        Gp[((size_t)(o >> 4) * NAC + (i >> 4)) * 256 + (((i & 15) >> 2) * 16 + (o & 15)) * 4 +
+    __device__ void operator()(int k, int o, int i, float acc, float) const {
+        Gp[k * gstride + ((size_t)(o >> 4) * NAC + (i >> 4)) * 256 + (((i & 15) >> 2) * 16 + (o & 15)) * 4 +
            (i & 3)] = acc;
     }
 };
@@ -459,18 +465,17 @@ extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_
                        d->n_alph, d->alph_len, d->n_lam);
     DRNMF_HIP(h, hipGetLastError());
     if (gram_eligible(d)) {
-        // G_k = Dn_k^T Dn_k per stored layer (2 N^2 F flops each) + the transposed dictionary
-        const size_t lstride = (size_t)L.Fp * L.Np;
+        // G_k = Dn_k^T Dn_k per stored layer (2 N^2 F flops each) + the transposed dictionary: ONE TN
+        // product over the layers stacked along the contraction, its split s = the k-tiles of layer s
+        // (a launch pair per layer was 5 x 31 us of a 9.5-ms training step at N = 200)
+        const int Fr = round_up(L.Fp, 32);
         float* Dn_rm = (float*)(base + L.off_dn_rm);
-        for (int k = 0; k < d->n_D; ++k) {
-            hipLaunchKernelGGL(unpack_both_kernel, dim3((unsigned)((lstride + 255) / 256)),
-                               dim3(256), 0, stream,
-                               (const float*)(base + L.off_dn) + (size_t)k * lstride, Dn_rm,
-                               (float*)(base + L.off_dnT) + (size_t)k * lstride, L.Fp, L.Np);
-            gemm_tn::Operands g{Dn_rm, Dn_rm, L.Fp, L.Np, L.Np, L.Np, L.Np};
-            EpiGramPack epi{(float*)(base + L.off_gram) + (size_t)k * L.Np * L.Np, L.Np / 16};
-            DRNMF_HIP(h, gemm_tn::launch(g, epi, 1, stream));
-        }
+        hipLaunchKernelGGL(unpack_both_kernel, dim3((unsigned)(((size_t)Fr * L.Np + 255) / 256), d->n_D),
+                           dim3(256), 0, stream, (const float*)(base + L.off_dn), Dn_rm,
+                           (float*)(base + L.off_dnT), L.Fp, L.Np, Fr);
+        gemm_tn::Operands g{Dn_rm, Dn_rm, (int64_t)d->n_D * Fr, L.Np, L.Np, L.Np, L.Np};
+        EpiGramPack epi{(float*)(base + L.off_gram), L.Np / 16, (size_t)L.Np * L.Np};
+        DRNMF_HIP(h, gemm_tn::launch(g, epi, d->n_D, stream));
     }
     return DRNMF_OK;
 }
