@@ -362,11 +362,12 @@ def test_ista_large_ragged_shape_vs_oracle(dev):
     assert err <= 2e-5, err
 
 
-@pytest.mark.parametrize("F", [64, 34, 48, 130])
+@pytest.mark.parametrize("F", [64, 34, 48, 130, 129, 257])
 @pytest.mark.parametrize("name", ["ed", "kl", "beta"])
 def test_ista_bin_counts_around_the_tile_size(dev, F, name):
     """The X^ / G GEMMs run on whole 16-bin tiles and the 1-2 odd bins of a 2^k+1 STFT go through
-    a separate rank-1 path: F = 64, 48 (no odd bins), 34, 130 (two), with the goldens covering one."""
+    a separate rank-1 path: F = 64, 48 (no odd bins), 34, 130 (two), with the goldens covering one;
+    F = 129, 257: the one odd bin behind whole 128-column tiles rides on the X^ product (gemm_nt.h THIN)."""
     from drnmf_amd import ops
     rng = np.random.default_rng(F)
     N, n, K = 24, 37, 6
@@ -386,11 +387,14 @@ def test_ista_bin_counts_around_the_tile_size(dev, F, name):
     assert np.max(np.abs(got - want)) <= 2e-5 * max(np.max(np.abs(want)), 1e-6)
 
 
-@pytest.mark.parametrize("beta", [2.0, 1.0, 1.5, 0.0, 0.5, 3.0])
-def test_mu_inference_and_irm_vs_oracle(dev, beta):
+@pytest.mark.parametrize("beta,F", [(2.0, 65), (1.0, 65), (1.5, 65), (0.0, 65), (0.5, 65), (3.0, 65),
+                                    (2.0, 129), (2.0, 257), (1.0, 129)])
+def test_mu_inference_and_irm_vs_oracle(dev, beta, F):
+    """F = 129, 257: one bin behind whole 128-column tiles -- the odd output column of W H rides on the full
+    tiles' staging (csrc/gemm_nt.h THIN; one and two column tiles)."""
     from drnmf_amd import ops
     rng = np.random.default_rng(6)
-    n, F, N, iters = 150, 65, 24, 30
+    n, N, iters = 150, 24, 30
     W = rng.random((F, N)).astype(np.float32) * 3            # deliberately NOT normalised
     V = (W @ ((rng.random((N, n)) < 0.3) * rng.random((N, n))) + 1e-3).astype(np.float32)
     if beta != 2.0:
@@ -440,14 +444,18 @@ def test_stft_mag_vs_oracle(dev, N, hop, nsampl, int16):
 
 
 # ------------------------------------------------------------------ sparse-NMF dictionary training
-@pytest.mark.parametrize("beta,cf", [(2.0, "ed"), (1.0, "kl"), (1.5, None), (0.0, "is"),
-                                     (0.5, None), (3.0, None)])
-def test_snmf_training_matches_oracle(dev, beta, cf):
+@pytest.mark.parametrize("beta,cf,F", [(2.0, "ed", 65), (1.0, "kl", 65), (1.5, None, 65), (0.0, "is", 65),
+                                       (0.5, None, 65), (3.0, None, 65),
+                                       (2.0, "ed", 129), (1.0, "kl", 129), (1.5, None, 129),
+                                       (2.0, "ed", 257), (1.0, "kl", 257)])
+def test_snmf_training_matches_oracle(dev, beta, cf, F):
     """W/H multiplicative updates + renormalisation + objective vs the numpy restatement of
-    sparse_nmf_gpu.m (same explicit inits), incl. a frozen half of the dictionary."""
+    sparse_nmf_gpu.m (same explicit inits), incl. a frozen half of the dictionary.  F = 129 / 257: the
+    513-bin shape in small -- the odd bin as the rider column of the lambda products (with the objective
+    summed in the same epilogue) and as the streamed odd row of the W statistics."""
     from drnmf_amd import ops
     rng = np.random.default_rng(8)
-    F, r, n, iters = 65, 12, 300, 25
+    r, n, iters = 12, 300, 25
     Wt = rng.random((F, r))
     V = (Wt @ (rng.random((r, n)) * (rng.random((r, n)) < 0.4)) + 1e-3).astype(np.float32)
     if beta != 2.0:
