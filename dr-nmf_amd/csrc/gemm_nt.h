@@ -70,7 +70,7 @@ __device__ __forceinline__ f32x4 load4(const float* base, int64_t row, int64_t n
 // a 2^k+1 STFT (K = 513 = 16 tiles + 1) ride along without a 17th, almost empty k-tile.
 // `static constexpr bool REDUCE = true` in the functor: its operator() RETURNS a float per output element;
 // the kernel sums them per thread (fixed order), per workgroup (LDS tree, fixed order) and stores ONE
-// partial per workgroup at epi.red_out[blockIdx.x] -- a grid-wide sum (the objective of the dictionary
+// partial per workgroup at epi.red_out[blockIdx.x] (blockIdx.x < launch_tiles(g)) -- a grid-wide sum (the objective of the dictionary
 // training) rides on a GEMM's epilogue instead of costing its own pass over the outputs; deterministic.
 template <class E, class = void> struct epi_reduce : std::false_type {};
 template <class E> struct epi_reduce<E, std::void_t<decltype(E::REDUCE)>>
@@ -375,14 +375,26 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const Operands g, const
     }
 }
 
+inline bool vec_ok(const Operands& g) {
+    return (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
+           (((uintptr_t)g.Bt & 15) == 0);
+}
+// N = 128 j + 1: the odd column rides on the full tiles' staging (THIN above)
+inline bool thin_applies(const Operands& g) {
+    const char* te = tune_env("DRNMF_THIN");                  // measurement aid: 0 = a tile column of its own
+    return vec_ok(g) && g.ktail == 0 && g.N > BN && g.N % BN == 1 && !(te && atoi(te) == 0);
+}
+// workgroups of launch(g, ...) = partials a REDUCE epilogue leaves at red_out[0 .. launch_tiles)
+inline int64_t launch_tiles(const Operands& g) {
+    const int n = thin_applies(g) ? g.N - 1 : g.N;
+    return ((g.M + BM - 1) / BM) * ((n + BN - 1) / BN);
+}
+
 template <class Epi>
 inline hipError_t launch(const Operands& g_in, const Epi& epi, hipStream_t stream) {
     Operands g = g_in;
-    const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) &&
-                     (((uintptr_t)g.A & 15) == 0) && (((uintptr_t)g.Bt & 15) == 0);
-    // N = 128 j + 1: the odd column rides on the full tiles' staging (THIN above)
-    const char* te = tune_env("DRNMF_THIN");                  // measurement aid: 0 = a tile column of its own
-    const bool thin = vec && g.ktail == 0 && g.N > BN && g.N % BN == 1 && !(te && atoi(te) == 0);
+    const bool vec = vec_ok(g);
+    const bool thin = thin_applies(g);
     if (thin) { g.N -= 1; g.thin = 1; }
     const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (tiles <= 0 || tiles > 0x7fffffff || g.M > 0x7fffff00 || g.ktail < 0 || g.ktail > 2)

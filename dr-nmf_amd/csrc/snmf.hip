@@ -926,12 +926,16 @@ extern "C" int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F,
     float* colsum = (float*)(ws + L.off_colsum);
     float* PN = (float*)(ws + L.off_PN); float* PD = (float*)(ws + L.off_PD);
     float* hs = (float*)(ws + L.off_hs);
-    const int nd = (int)((n + 127) / 128) * ((F + 127) / 128), nh = (int)((n + 127) / 128) * ((N + 127) / 128);
+    const int nd = (int)((n + 127) / 128) * ((F + 127) / 128);      // (capacity of dpart: tr_ws)
     float* dpart = (float*)(ws + L.off_obj);
     float* hpart = dpart + nd;
     const int Fp4 = L.Fp4;
     const float flr = 1e-9f;
     gemm::Operands gl{H, W, n, F, N, N, N};
+    // (nd / nh size the two partial arrays; what the REDUCE launches below actually leave there is one
+    // partial per workgroup THEY run -- fewer when the odd column rides on the full tiles)
+    const int nd_used = (int)gemm::launch_tiles(gl);
+    const int nh_used = (int)gemm::launch_tiles(gemm::Operands{P1, Wt, n, N, Fp4, Fp4, Fp4});
     // ---- H update (:210-229) -------------------------------------------------------------------
     if (beta == 1.f) {
         // dph = sum_f w + sparsity needs the column sums of the CURRENT W
@@ -990,7 +994,7 @@ extern "C" int32_t drnmf_snmf_train_step(drnmf_handle_t h, int64_t n, int32_t F,
         DRNMF_HIP(h, lambda_train_obj(gl, Vp, P1, P2, dpart, Fp4, beta, flr, stream));   // (:263)
     }
     // ---- objective (:267-281): D(V | lambda) and sum(H) were summed in the epilogues above ------
-    hipLaunchKernelGGL(objective_final2_kernel, dim3(1), dim3(256), 0, stream, dpart, nd, hpart, nh,
+    hipLaunchKernelGGL(objective_final2_kernel, dim3(1), dim3(256), 0, stream, dpart, nd_used, hpart, nh_used,
                        sparsity, obj);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;

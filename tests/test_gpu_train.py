@@ -427,6 +427,36 @@ def test_training_steps_are_bitwise_reproducible(dev, cell_form, trainable):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(B=5, T=9, F=65, r=16, K=5, untied=("log_D", "log_alph")),                       # Gram form (persistent chains)
+    dict(B=4, T=6, F=257, r=300, K=3, untied=("log_D", "log_alph")),                     # factored, odd bin
+    dict(B=3, T=7, F=40, r=10, K=3, untied=("log_D", "log_alph"), divergence="kl"),      # KL cell
+])
+def test_fresh_workspace_memory_does_not_reach_the_gradients(dev, cfg):
+    """Every scratch buffer of a training step (hidden states, head buffers, the BPTT workspace) is a fresh
+    torch allocation that the kernels must write before they read: the same step on memory that held NaN
+    and on memory that held 1e30 gives the gradients of the first run, bit for bit."""
+    cfg = dict(cfg)
+    model, P, wmask = _setup(**cfg)
+    model.compile(lr=1e-3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    x, y, w = t(P["X"]), t(P["Y"]), t(wmask)
+
+    def run(poison):
+        if poison is not None:
+            torch.cuda.empty_cache()
+            big = torch.full((64 << 20,), poison, dtype=torch.float32, device=dev)    # 256 MiB of the pattern
+            del big                                       # ... stays in torch's cache: the next allocations
+        model._flat.fill_(float("nan"))
+        flat = model.loss_and_grads(x, y, w).clone()
+        torch.cuda.synchronize()
+        return flat
+    ref = run(None)
+    assert bool(torch.isfinite(ref).all())
+    for poison in (float("nan"), 1e30):
+        assert torch.equal(run(poison), ref), "fresh memory filled with %r changed the gradients" % poison
+
+
 @pytest.mark.parametrize("opts", [
     dict(),                                         # plain Adam, masked-mean normalisation
     dict(clipnorm="half"),                          # global-norm clip active: half of this batch's gradient norm
