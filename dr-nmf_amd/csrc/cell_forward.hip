@@ -719,6 +719,10 @@ void* a_func_g(int per_wave, bool first, bool last, bool qred = false) {
 template <bool AH, bool HALF>
 void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last, bool qred) {
     // row-blocked variants exist for KS <= 2 (workspace_layout never pairs RB > 1 with more)
+    if constexpr (!AH && !HALF) {
+        if (RB == 4) return KS == 1 ? a_func_g<1, 4, AH, HALF>(per_wave, first, last, qred)
+                                    : a_func_g<2, 4, AH, HALF>(per_wave, first, last, qred);
+    }
     if (RB == 2) return KS == 1 ? a_func_g<1, 2, AH, HALF>(per_wave, first, last, qred)
                                 : a_func_g<2, 2, AH, HALF>(per_wave, first, last, qred);
     switch (KS) {

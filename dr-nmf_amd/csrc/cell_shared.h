@@ -415,7 +415,8 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     // Row blocks per workgroup.  Measured on MI355X (F=513, N=2000, K=25; frames/s with 1 / 2 / 4
     // row blocks): B=128 343k / 332k / 206k, B=256 431k / 486k / 399k, B=512 526k / 572k / 537k,
     // B=1024 577k / 636k / 595k -- two blocks pay once every CU holds >= 2 such workgroups; four
-    // leave too few waves per CU to hide the operand latency.
+    // leave too few waves per CU to hide the operand latency (round 4, sub-batches on side streams, four
+    // against the rule below: B=512 639k / 848k, B=1024 640k / 982k: profiles/r04j_rb4_sweep.txt).
     W.RB = 1;
     {
         const int groups = round_up(d->B, ROWS * 2) / (ROWS * 2);
@@ -428,6 +429,8 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     if (const char* e = tune_env("DRNMF_RB")) {   // tuning aid: force the row blocking
         const int v = atoi(e);
         if (v == 1 || v == 2) W.RB = v;
+        // (four: fp32 inference only -- measured, never chosen: DESIGN.md 4.2)
+        if (v == 4 && !W.half && !d->return_all_hidden && d->B >= 64) W.RB = 4;
     }
     if (W.gram) W.RB = 1;   // (one row block per workgroup: gram_wanted() counts 16-row tiles)
     // fp16 operand mode: cell_b keeps one row block per workgroup (its 16 x 16 output tiles with
@@ -566,9 +569,11 @@ void* pick_b_func(int nch_ks, int RB = 1, bool half = false, bool qred = false) 
     // fp16: nch_ks counts 32-atom chunks; eight rotating operand slots where a wave owns that many
     if (qred) {
         if (half) return RB == 2 ? pick_b_func_rb<2, true, true>(nch_ks) : pick_b_func_rb<1, true, true>(nch_ks);
+        if (RB == 4) return pick_b_func_rb<4, false, true>(nch_ks);
         return RB == 2 ? pick_b_func_rb<2, false, true>(nch_ks) : pick_b_func_rb<1, false, true>(nch_ks);
     }
     if (half) return RB == 2 ? pick_b_func_rb<2, true, false>(nch_ks) : pick_b_func_rb<1, true, false>(nch_ks);
+    if (RB == 4) return pick_b_func_rb<4, false, false>(nch_ks);
     if (RB == 2) return pick_b_func_rb<2, false, false>(nch_ks);
     return pick_b_func_rb<1, false, false>(nch_ks);
 }
