@@ -92,8 +92,14 @@ struct CellAArgs {
 // QRED: the odd-bin x^ of the previous layer arrives already summed (cell_b, more than 64 atom blocks);
 // a template parameter, not a runtime switch: the epilogue-operand block of the headline
 // instantiation is sensitive to every extra register and branch (a runtime `if` cost 3 % there).
+// LDSB (fp32 inference, RB = 4, G = 4): the workgroup still covers 4 row blocks x 32 atoms, but wave w owns ROW
+// BLOCK w over ALL bins instead of a quarter of the bins of all four row blocks: the dictionary chunk
+// (16 bins x 32 atoms, 2 KB) is fetched once per workgroup -- wave c mod 4 loads chunk c -- and handed to the
+// other waves through a two-slot LDS ring (one barrier per group of four chunks); a wave keeps one row
+// block's registers, and there is no cross-wave reduction.  The large-batch variant the round-3 review
+// asked for; measurements in DESIGN.md 4.2.
 template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN, bool HALF = false,
-          bool LATE = false, bool QRED = false>
+          bool LATE = false, bool QRED = false, bool LDSB = false>
 __global__ void __launch_bounds__(64 * NW_A)
 cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, int Fp_, int Np_,
               int numA_, int nchunks_, const CellAArgs a_in) {
@@ -233,8 +239,51 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 if (!A16) av[g][rb][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    // LDSB: staging registers of the dictionary ring (group g of four chunks lives in st[g & 1] until it is
+    // written to LDS) and this wave's residual slots (chunk c in slot c % 8: loads run seven chunks = 1800
+    // matrix-pipe cycles ahead; with three the wave waited for its residual at every chunk: 14 us per launch)
+    static_assert(!LDSB || (G == 8 && RB == 4 && NW_A == 4 && !HALF && !ALL_HIDDEN && !LATE),
+                  "LDSB: four waves, four row blocks, eight residual slots (two groups of chunks), fp32 inference");
+    __shared__ __attribute__((aligned(16))) float bl[LDSB ? 2 * NW_A * 512 : 4];
+    f32x4 st[LDSB ? 2 : 1][2];
+    f32x4 avw[LDSB ? G : 1][NP];
+    const float* arow_w = arow + (size_t)w * astep;              // LDSB: this wave's row block
+    auto ldsb_load_b = [&](int g, auto par) {                    // this wave's chunk of group g -> staging
+        constexpr int P = decltype(par)::value;
+        int c = 4 * g + w;
+        c = c > clast ? clast : c;
+        st[P][0] = *(const f32x4*)(brow + (size_t)c * bstep);
+        st[P][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
+    };
+    auto ldsb_write_b = [&](auto par) {                          // staging -> ring slot P, chunk w
+        constexpr int P = decltype(par)::value;
+        float* p = bl + (P * NW_A + w) * 512 + l * 4;
+        *(f32x4*)p = st[P][0];
+        *(f32x4*)(p + 256) = st[P][1];
+    };
+    auto ldsb_load_a = [&](int c, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        const int cc = c > clast ? clast : c;
 #pragma unroll
-    for (int g = 0; g < PF; ++g) load_chunk(g, g);
+        for (int ks = 0; ks < NP; ++ks)
+            avw[SLOT][ks] = *(const f32x4*)(arow_w + 256 * cc + (size_t)ks * pstride);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if constexpr (LDSB) {
+        ldsb_load_b(0, I0{});
+        ldsb_load_b(1, I1{});
+        ldsb_load_a(0, std::integral_constant<int, 0>{});
+        ldsb_load_a(1, std::integral_constant<int, 1>{});
+        ldsb_load_a(2, std::integral_constant<int, 2>{});
+        ldsb_load_a(3, std::integral_constant<int, 3>{});
+        ldsb_load_a(4, std::integral_constant<int, 4>{});
+        ldsb_load_a(5, std::integral_constant<int, 5>{});
+        ldsb_load_a(6, std::integral_constant<int, 6>{});
+    } else {
+#pragma unroll
+        for (int g = 0; g < PF; ++g) load_chunk(g, g);
+    }
     // everything below depends on struct fields that are still being fetched by scalar loads:
     // keep it (and the wait for those loads) behind the first operand loads
     __builtin_amdgcn_sched_barrier(0);
@@ -408,7 +457,51 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // load latency.  Both orders in ONE kernel behind a runtime switch cost up to 35 % at other
     // shapes, hence the template parameter.  Measured, not derived: the same order without the
     // (unreached) single-group branch below compiles to a kernel that gains nothing (309.9 k).
-    if (LATE) {
+    if constexpr (LDSB) {
+        load_epilogue_operands();
+        ldsb_write_b(I0{});
+        const int ngroups = (a.nchunks + 3) >> 2;
+        auto group_body = [&](int g, auto par) {
+            constexpr int P = decltype(par)::value;              // g & 1: ring slot, staging set, residual slots 4P..4P+3
+            using Q = std::integral_constant<int, P ^ 1>;
+            __syncthreads();             // group g is in the ring; everybody is done reading group g - 1
+            if (g + 1 < ngroups) ldsb_write_b(Q{});
+            if (g + 2 < ngroups) ldsb_load_b(g + 2, par);
+            const float* bs = bl + P * NW_A * 512 + l * 4;
+            f32x4 b0[4], b1[4];
+#pragma unroll
+            for (int sc = 0; sc < 4; ++sc) {                     // the group's dictionary fragments, up front
+                b0[sc] = *(const f32x4*)(bs + sc * 512);
+                b1[sc] = *(const f32x4*)(bs + sc * 512 + 256);
+            }
+            auto chunk = [&](auto sc_tag) {
+                constexpr int SC = decltype(sc_tag)::value;
+                const int c = 4 * g + SC;
+                ldsb_load_a(c + 7, std::integral_constant<int, (4 * P + SC + 7) % 8>{});
+                f32x4 r4 = avw[4 * P + SC][0];
+#pragma unroll
+                for (int ks = 1; ks < NP; ++ks) r4 += avw[4 * P + SC][ks];
+                const bool ok = c < a.nchunks;
+                if (IS_FIRST && ab_raw == 0 && ok)      // (republish x_t at a frame-independent address)
+                    *(f32x4*)(a.xcur + (size_t)(mb0 + w) * nft * 256 + 256 * c + l * 4) = r4;
+                if (!ok) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const f32x4 bb = (s2 >> 1) ? b1[SC] : b0[SC];
+                    acc[0][0] = mfma16(r4[s2], bb[(s2 & 1) * 2], acc[0][0]);
+                    acc[0][1] = mfma16(r4[s2], bb[(s2 & 1) * 2 + 1], acc[0][1]);
+                }
+            };
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{});
+            chunk(std::integral_constant<int, 3>{});
+        };
+        for (int g = 0; g < ngroups; g += 2) {
+            group_body(g, I0{});
+            if (g + 1 < ngroups) group_body(g + 1, I1{});
+        }
+    } else if (LATE) {
         if (exact && per_wave <= G) {      // (not reached with the shapes pick_a_func sends here)
             load_chunk(PF, PF % G);
 #pragma unroll
@@ -448,13 +541,21 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
 
     // ---- cross-wave reduction of the 4 F-splits through LDS --------------------------------
     DRNMF_STAMP(1, 3);
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    if constexpr (LDSB) {       // one complete row block per wave: no partials to add, only the layout change
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            f32x2 pr = {acc[rb][0][v], acc[rb][1][v]};
-            *(f32x2*)(red + ((w * RB + rb) * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
+            f32x2 pr = {acc[0][0][v], acc[0][1][v]};
+            *(f32x2*)(red + ((0 * RB + w) * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
         }
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                f32x2 pr = {acc[rb][0][v], acc[rb][1][v]};
+                *(f32x2*)(red + ((w * RB + rb) * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
+            }
+    }
     __syncthreads();
     DRNMF_STAMP(1, 4);
     if (NW_A > 4 && tid >= 256) return;   // the elementwise epilogue is 256 threads wide
@@ -465,7 +566,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
         const size_t hoff = hoff0 + rb * hstep;
         f32x2 gsum = *(const f32x2*)(red + ((0 * RB + rb) * ROWS + erow) * ATOMS + ec);
 #pragma unroll
-        for (int ww = 1; ww < NW_A; ++ww) {
+        for (int ww = 1; ww < (LDSB ? 1 : NW_A); ++ww) {
             const f32x2 p2 = *(const f32x2*)(red + ((ww * RB + rb) * ROWS + erow) * ATOMS + ec);
             gsum[0] += p2[0];
             gsum[1] += p2[1];
@@ -701,6 +802,18 @@ void* a_func(bool first, bool last, bool qred = false) {
     return (void*)&cell_a_kernel<G, KS, RB, false, false, AH, HALF, LATE>;
 }
 
+template <int KS>
+void* a_func_ldsb(bool first, bool last, bool qred) {
+    if (qred) {
+        if (last) return (void*)&cell_a_kernel<8, KS, 4, false, true, false, false, false, true, true>;
+        if (!first) return (void*)&cell_a_kernel<8, KS, 4, false, false, false, false, false, true, true>;
+    }
+    if (first && last) return (void*)&cell_a_kernel<8, KS, 4, true, true, false, false, false, false, true>;
+    if (first) return (void*)&cell_a_kernel<8, KS, 4, true, false, false, false, false, false, true>;
+    if (last) return (void*)&cell_a_kernel<8, KS, 4, false, true, false, false, false, false, true>;
+    return (void*)&cell_a_kernel<8, KS, 4, false, false, false, false, false, false, true>;
+}
+
 template <int KS, int RB, bool AH, bool HALF>
 void* a_func_g(int per_wave, bool first, bool last, bool qred = false) {
     // G operand slots; operand registers G * (4*KS*RB + 8)
@@ -720,8 +833,14 @@ template <bool AH, bool HALF>
 void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last, bool qred) {
     // row-blocked variants exist for KS <= 2 (workspace_layout never pairs RB > 1 with more)
     if constexpr (!AH && !HALF) {
-        if (RB == 4) return KS == 1 ? a_func_g<1, 4, AH, HALF>(per_wave, first, last, qred)
-                                    : a_func_g<2, 4, AH, HALF>(per_wave, first, last, qred);
+        if (RB == 4) {
+            // four row blocks: the LDS-shared form (DRNMF_LDSB=0: the register form, four row blocks per wave)
+            const char* e = tune_env("DRNMF_LDSB");
+            if (!(e && atoi(e) == 0))
+                return KS == 1 ? a_func_ldsb<1>(first, last, qred) : a_func_ldsb<2>(first, last, qred);
+            return KS == 1 ? a_func_g<1, 4, AH, HALF>(per_wave, first, last, qred)
+                           : a_func_g<2, 4, AH, HALF>(per_wave, first, last, qred);
+        }
     }
     if (RB == 2) return KS == 1 ? a_func_g<1, 2, AH, HALF>(per_wave, first, last, qred)
                                 : a_func_g<2, 2, AH, HALF>(per_wave, first, last, qred);

@@ -437,6 +437,11 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     // the whole contraction are what fills the chip), cell_a may still carry two, which halves the
     // number of times a dictionary slice is pulled out of the L2
     W.RBa = W.RB;
+    if (!W.half && !W.gram && !d->return_all_hidden && d->B >= 64) {
+        // tuning aid: fp32 inference, cell_a alone on 64-row workgroups (4 = the LDS-shared form, cell_forward.hip LDSB)
+        if (const char* e = tune_env("DRNMF_RBA"))
+            if (atoi(e) == 4) W.RBa = 4;
+    }
     if (W.half && W.RB == 1) {
         const int groups = round_up(d->B, ROWS * 2) / (ROWS * 2);
         // measured at F=1025, N=8000, B=64 (once the odd-bin partials were out of cell_a's tail): one row
@@ -458,10 +463,11 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     // B=32 F=513 166k / 171k / -; B=48 242k / 231k / -; B=64 291k / 279k / -: never more than 4, and
     // the smallest count that gives ~192 workgroups -- each extra range is another residual partial
     // for every cell_a workgroup to read)
-    while (KS < (W.RB > 1 ? 2 : 4) && tiles * KS < 192 && nchN / (KS * 2) >= 4) KS *= 2;
+    const bool blocked = W.RB > 1 || (!W.half && W.RBa > 1);     // (row-blocked cell_a / cell_b: KS <= 2)
+    while (KS < (blocked ? 2 : 4) && tiles * KS < 192 && nchN / (KS * 2) >= 4) KS *= 2;
     if (const char* e = tune_env("DRNMF_KS")) {   // tuning aid: force the number of atom ranges
         const int v = atoi(e);
-        if ((v == 1 || v == 2 || v == 4 || v == 8) && (W.RB == 1 || v <= 2) && nchN / v >= 1) KS = v;
+        if ((v == 1 || v == 2 || v == 4 || v == 8) && (!blocked || v <= 2) && nchN / v >= 1) KS = v;
     }
     if (nonlin) KS = 1;
     if (W.half) KS = 1;        // the fp16 residual is stored once, already rounded (cell_b_kernel)
