@@ -24,7 +24,11 @@ ARCH = ["--offload-arch=" + os.environ.get("DRNMF_OFFLOAD_ARCH", "gfx950:xnack-"
 # DRNMF_TIMELINE=1: measurement build with s_memtime stamps in the cell kernels (tools/timeline.py)
 FLAGS = ARCH + (["-DDRNMF_TIMELINE"] if os.environ.get("DRNMF_TIMELINE") else []) + os.environ.get("DRNMF_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          # scalar kernel arguments arrive preloaded in SGPRs (no kernarg load on the critical path)
-         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=16",
+         # `#pragma unroll` means it: with the default threshold the optimiser refused to unroll the output-tile
+         # loops of gemm_nt_kernel under the powf epilogues of the general beta-divergence (24 "loop not
+         # unrolled" warnings); acc[a][b] was then indexed dynamically = 832 bytes of scratch per lane
+         "-mllvm", "-pragma-unroll-threshold=262144"]
 
 
 def _sources():

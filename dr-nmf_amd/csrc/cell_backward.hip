@@ -1577,6 +1577,7 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
                                        size_t bwd_workspace_bytes, float* d_log_D,
                                        float* d_log_alph, float* d_log_lam1, float* d_log_h0,
                                        void* stream_) {
+    DRNMF_LOCK(h);
     if (h && d && d->divergence != DRNMF_DIV_ED)
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
                    "cell_backward is the reference's (Euclidean) cell; KL / beta: drnmf_cell_backward_ista");
@@ -1592,6 +1593,7 @@ extern "C" int32_t drnmf_cell_backward_ista(drnmf_handle_t h, const drnmf_cell_d
                                             void* bwd_workspace, size_t bwd_workspace_bytes,
                                             float* d_log_D, float* d_log_alph, float* d_log_lam1,
                                             float* d_log_h0, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!d || (d->divergence != DRNMF_DIV_KL && d->divergence != DRNMF_DIV_BETA))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG,
@@ -1607,6 +1609,7 @@ extern "C" int32_t drnmf_cell_backward_profile(
     const float* d_out, const void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
     size_t bwd_workspace_bytes, float* d_log_D, float* d_log_alph, float* d_log_lam1,
     float* d_log_h0, void* stream_, float* out_ms_host) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!out_ms_host) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_backward_profile: NULL out_ms_host");
     if (d && d->divergence != DRNMF_DIV_ED)

@@ -303,6 +303,7 @@ extern "C" size_t drnmf_dense_workspace_bytes(const drnmf_dense_desc_t* d) {
 extern "C" int32_t drnmf_dense_prepare_params(drnmf_handle_t h, const drnmf_dense_desc_t* d,
                                               const float* U, const float* S, const float* W,
                                               const float* b, void* params, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_dense_desc(h, d);
     if (rc) return rc;
@@ -498,6 +499,7 @@ extern "C" int32_t drnmf_dense_cell_forward(drnmf_handle_t h, const drnmf_dense_
                                             const float* h0, const float* initial_state,
                                             float* final_state, float* h_out, void* workspace,
                                             size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     return dense_forward_impl(h, d, x, mask_value, params, h0, initial_state, final_state, h_out,
                               workspace, workspace_bytes, stream_, nullptr);
 }
@@ -510,6 +512,7 @@ extern "C" int32_t drnmf_dense_cell_forward_dropout(drnmf_handle_t h, const drnm
                                                     const float* drop_u, float* h_out,
                                                     void* workspace, size_t workspace_bytes,
                                                     void* stream_) {
+    DRNMF_LOCK(h);
     if (h && !drop_u) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_forward_dropout: NULL mask");
     return dense_forward_impl(h, d, x, mask_value, params, h0, nullptr, nullptr, h_out, workspace,
                               workspace_bytes, stream_, drop_u);

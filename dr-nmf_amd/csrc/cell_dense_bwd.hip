@@ -335,6 +335,7 @@ extern "C" int32_t drnmf_dense_cell_backward(drnmf_handle_t h, const drnmf_dense
                                              const float* d_out, float* dU, float* dS, float* dW,
                                              float* db, float* dh0, void* workspace,
                                              size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     return dense_backward_impl(h, d, x, mask_value, U, S, W, b, h0, hall, d_out, dU, dS, dW, db, dh0,
                                workspace, workspace_bytes, stream_, nullptr);
 }
@@ -346,6 +347,7 @@ extern "C" int32_t drnmf_dense_cell_backward_dropout(
     const float* S, const float* W, const float* b, const float* h0, const float* drop_u,
     const float* hall, const float* d_out, float* dU, float* dS, float* dW, float* db, float* dh0,
     void* workspace, size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     if (h && !drop_u) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_backward_dropout: NULL mask");
     return dense_backward_impl(h, d, x, mask_value, U, S, W, b, h0, hall, d_out, dU, dS, dW, db, dh0,
                                workspace, workspace_bytes, stream_, drop_u);

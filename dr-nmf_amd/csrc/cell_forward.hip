@@ -78,6 +78,7 @@ struct CellAArgs {
                              // the saved order (common.h tile_unpermute), for the weight gradients of
                              // the BPTT (saves its recomputation as a frame-parallel GEMM); else NULL
     int out_width, out_off, write_out;
+    unsigned* prog;          // cell_a launches started in this call (read by dict_prefetch_kernel), or NULL
 };
 
 // G = operand slots (16-bin chunks in flight per wave, prefetch distance G-1).  RB = 16-row blocks per
@@ -86,20 +87,24 @@ struct CellAArgs {
 // v_mfma_f32_16x16x32_f16 (two MFMAs per 32-bin chunk, 16-byte operands per lane; KS = 1; the
 // first layer converts x_t from the fp32 input blocks), fp32 accumulation; state, sums, update and
 // the odd bins stay fp32; h goes out in fp32 (next epilogue) AND as fp16 (cell_b's operand).
+// The fp16 dictionary exists in ONE packing, cell_b's (atoms contiguous per lane: params.hip), so that
+// the cell_b / cell_a pair of a layer reads the same bytes (the second read is an Infinity-Cache hit,
+// the prepared block is half the size).  This kernel contracts over BINS: a wave stages the two 1-KB
+// blocks of its 32-bin chunk (16 bins x 32 atoms each, 16 bytes per lane as they lie in memory)
+// through a wave-private LDS buffer and reads them back with ds_read_b64_tr_b16, which hands lane
+// (atom j, slot q) the four bins 4e + q (e = 0..3) of atom j out of a [4 bins][4 atoms] gather per 16 lanes
+// -- exactly the slot order of the fp16 residual Rp16 (cell_shared.h).
 // What the operand addresses need is passed as leading scalar arguments (preloaded into SGPRs by
 // the command processor, see cell_b_kernel); the rest of the struct is fetched by scalar loads that
 // are not on the path to the first operand load.
 // QRED: the odd-bin x^ of the previous layer arrives already summed (cell_b, more than 64 atom blocks);
 // a template parameter, not a runtime switch: the epilogue-operand block of the headline
 // instantiation is sensitive to every extra register and branch (a runtime `if` cost 3 % there).
-// LDSB (fp32 inference, RB = 4, G = 4): the workgroup still covers 4 row blocks x 32 atoms, but wave w owns ROW
-// BLOCK w over ALL bins instead of a quarter of the bins of all four row blocks: the dictionary chunk
-// (16 bins x 32 atoms, 2 KB) is fetched once per workgroup -- wave c mod 4 loads chunk c -- and handed to the
-// other waves through a two-slot LDS ring (one barrier per group of four chunks); a wave keeps one row
-// block's registers, and there is no cross-wave reduction.  The large-batch variant the round-3 review
-// asked for; measurements in DESIGN.md 4.2.
+// (A 64-row form that shares the dictionary chunk between the waves through LDS, and one with four row
+// blocks per wave in registers, were built, measured and rejected in round 4: profiles/r04j_ldsb_sweep.txt,
+// r04j_rb4_sweep.txt)
 template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN, bool HALF = false,
-          bool LATE = false, bool QRED = false, bool LDSB = false>
+          bool LATE = false, bool QRED = false>
 __global__ void __launch_bounds__(64 * NW_A)
 cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, int Fp_, int Np_,
               int numA_, int nchunks_, const CellAArgs a_in) {
@@ -133,7 +138,10 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     int t = 0;
     if (IS_FIRST) {
         t = *a.t_rd;
-        if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
+        if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+            *a.t_wr = t + a.t_wr_add;
+            if (a.prog) __hip_atomic_fetch_add(a.prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     const float* rsrc = IS_FIRST ? a.rsrc + (size_t)t * pstride : a.rsrc;
     const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
@@ -143,9 +151,10 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // B: blocks (c, ac0 | ac0+1) of Dp, rows 4s+q, atoms 2j, 2j+1 of the 32
     // fp32: the cell_a packing (common.h): block (c, ab) of 512 floats, lane l reads 2 x 16 bytes
     const float* brow = (const float*)a.Dn + (size_t)ab * 512 + l * 4;
-    // fp16: blocks (c, 2ab | 2ab+1) of 512 halves of the A packing (params.hip), 16 bytes per lane
-    const f16* brow16 = (const f16*)a.Dn + (size_t)ab * 1024 + l * 8;
+    // fp16: blocks (2c | 2c+1, ab) of 512 halves of the one fp16 packing (params.hip), 16 bytes per lane
+    const f16* brow16 = (const f16*)a.Dn + (size_t)ab * 512 + l * 8;
     const size_t bstep = HALF ? (size_t)NAC * 512 : (size_t)NAC * 256;             // per chunk c
+    const size_t bstep_blk = (size_t)NAC * 256;                                     // fp16: block 2c -> 2c+1
     // fp16 residual Rp16 (cell_shared.h): block (mb, c) of 512 halves
     const f16* arow16 = (const f16*)rsrc + (size_t)mb0 * (Fp / 32) * 512 + l * 8;
     const size_t astep16 = (size_t)(Fp / 32) * 512;
@@ -212,8 +221,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                     av[g][rb][ks] = *(const f32x4*)(arow + rb * astep + 256 * c + (size_t)ks * pstride);
         }
         if (HALF) {
-            bh[g][0] = *(const f16x8*)(brow16 + (size_t)cb * bstep);
-            bh[g][1] = *(const f16x8*)(brow16 + (size_t)cb * bstep + 512);
+            bh[g][0] = *(const f16x8*)(brow16 + (size_t)cb * bstep);                // bins 32c .. 32c+15
+            bh[g][1] = *(const f16x8*)(brow16 + (size_t)cb * bstep + bstep_blk);    // bins 32c+16 .. 32c+31
         } else {
             bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
             bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
@@ -239,51 +248,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                 if (!A16) av[g][rb][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    // LDSB: staging registers of the dictionary ring (group g of four chunks lives in st[g & 1] until it is
-    // written to LDS) and this wave's residual slots (chunk c in slot c % 8: loads run seven chunks = 1800
-    // matrix-pipe cycles ahead; with three the wave waited for its residual at every chunk: 14 us per launch)
-    static_assert(!LDSB || (G == 8 && RB == 4 && NW_A == 4 && !HALF && !ALL_HIDDEN && !LATE),
-                  "LDSB: four waves, four row blocks, eight residual slots (two groups of chunks), fp32 inference");
-    __shared__ __attribute__((aligned(16))) float bl[LDSB ? 2 * NW_A * 512 : 4];
-    f32x4 st[LDSB ? 2 : 1][2];
-    f32x4 avw[LDSB ? G : 1][NP];
-    const float* arow_w = arow + (size_t)w * astep;              // LDSB: this wave's row block
-    auto ldsb_load_b = [&](int g, auto par) {                    // this wave's chunk of group g -> staging
-        constexpr int P = decltype(par)::value;
-        int c = 4 * g + w;
-        c = c > clast ? clast : c;
-        st[P][0] = *(const f32x4*)(brow + (size_t)c * bstep);
-        st[P][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
-    };
-    auto ldsb_write_b = [&](auto par) {                          // staging -> ring slot P, chunk w
-        constexpr int P = decltype(par)::value;
-        float* p = bl + (P * NW_A + w) * 512 + l * 4;
-        *(f32x4*)p = st[P][0];
-        *(f32x4*)(p + 256) = st[P][1];
-    };
-    auto ldsb_load_a = [&](int c, auto slot_tag) {
-        constexpr int SLOT = decltype(slot_tag)::value;
-        const int cc = c > clast ? clast : c;
 #pragma unroll
-        for (int ks = 0; ks < NP; ++ks)
-            avw[SLOT][ks] = *(const f32x4*)(arow_w + 256 * cc + (size_t)ks * pstride);
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    if constexpr (LDSB) {
-        ldsb_load_b(0, I0{});
-        ldsb_load_b(1, I1{});
-        ldsb_load_a(0, std::integral_constant<int, 0>{});
-        ldsb_load_a(1, std::integral_constant<int, 1>{});
-        ldsb_load_a(2, std::integral_constant<int, 2>{});
-        ldsb_load_a(3, std::integral_constant<int, 3>{});
-        ldsb_load_a(4, std::integral_constant<int, 4>{});
-        ldsb_load_a(5, std::integral_constant<int, 5>{});
-        ldsb_load_a(6, std::integral_constant<int, 6>{});
-    } else {
-#pragma unroll
-        for (int g = 0; g < PF; ++g) load_chunk(g, g);
-    }
+    for (int g = 0; g < PF; ++g) load_chunk(g, g);
     // everything below depends on struct fields that are still being fetched by scalar loads:
     // keep it (and the wait for those loads) behind the first operand loads
     __builtin_amdgcn_sched_barrier(0);
@@ -310,6 +276,13 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     float qv[QRED ? 1 : RB][MAX_TAIL][4];
     f32x2 dt[MAX_TAIL], dtn[MAX_TAIL];   // tail rows of this layer's and the next layer's dictionary
     auto load_epilogue_operands = [&]() {
+    // progress counter of the dictionary prefetch (dict_prefetch_kernel): compiled into the kernels of the
+    // shapes it serves only (fp16 operands; fp32 with more than 64 atom blocks) -- the headline
+    // instantiations are sensitive to every extra branch here.  The first layer counts below.
+    if constexpr ((HALF || QRED) && !IS_FIRST) {
+        if (a.prog && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)      // (no return value: nothing waits for it)
+            __hip_atomic_fetch_add(a.prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     ia = *(const f32x2*)(a.inv_alpha + n);
     bs = *(const f32x2*)(a.bias + n);
     if (!IS_FIRST && WRITE_OUT) {
@@ -369,9 +342,40 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     };
 
     // ---- GEMM:  g[16*RB x 32] = r[16*RB x F] . Dn[F x 32] ---------------------------------------
+    // fp16: wave-private staging for the transposed dictionary reads, two slots of two padded blocks
+    // (288 bytes per atom octet q: the [4 bins][4 atoms] gathers of a 32-lane half then cover all 64 banks)
+    constexpr int TRQ = 144, TRBLK = 4 * TRQ, TRSLOT = 2 * TRBLK;          // halves
+    __shared__ __attribute__((aligned(16))) f16 trbuf[HALF ? NW_A * 2 * TRSLOT : 8];
+    f16* const trw = trbuf + (HALF ? w * 2 * TRSLOT : 0);
+    // this lane's gather (native lane i = l & 15: bin row i >> 2, atom quad i & 3; lane group l >> 4 = slot q):
+    // bins 4 (i >> 2) + q, atoms 16 a + 4 (i & 3) .. + 3 -> octet 2a + ((i & 3) >> 1), halves 4 (i & 1) ..
+    const int tr_rd = (((l & 3) >> 1) * TRQ) + (4 * ((l & 15) >> 2) + (l >> 4)) * 8 + (l & 1) * 4;
+    const int tr_wr = (l >> 4) * TRQ + (l & 15) * 8;
+    int tr_par = 0;
+    f16x8 bt0, bt1;     // the chunk's two operands: atoms j / 16 + j of the block (j = l & 15), 8 bins per lane
+    auto transpose_chunk = [&](int g) {
+        f16* slot = trw + tr_par * TRSLOT;
+        tr_par ^= 1;
+        *(f16x8*)(slot + tr_wr) = bh[g][0];
+        *(f16x8*)(slot + TRBLK + tr_wr) = bh[g][1];
+        // (wave-private: the LDS serves one wave's instructions in order; the fence keeps the compiler
+        // from moving the gathers, which touch other lanes' stores, above them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        using s16x4 = __attribute__((__vector_size__(4 * sizeof(short)))) short;
+        using s16x8 = __attribute__((__vector_size__(8 * sizeof(short)))) short;
+        using lds_s16x4 = __attribute__((address_space(3))) s16x4;
+        const s16x4 t00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(slot + tr_rd));
+        const s16x4 t01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(slot + TRBLK + tr_rd));
+        const s16x4 t10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(slot + 2 * TRQ + tr_rd));
+        const s16x4 t11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(slot + TRBLK + 2 * TRQ + tr_rd));
+        bt0 = __builtin_bit_cast(f16x8, (s16x8)__builtin_shufflevector(t00, t01, 0, 1, 2, 3, 4, 5, 6, 7));
+        bt1 = __builtin_bit_cast(f16x8, (s16x8)__builtin_shufflevector(t10, t11, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     auto compute_chunk = [&](int base, int g) {
         const bool ok = base + g < per_wave;
         if (HALF) {
+            transpose_chunk(g);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 f16x8 a8;
@@ -390,8 +394,8 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
                                (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
                 }
                 if (!ok) a8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                acc[rb][0] = mfma32h(a8, bh[g][0], acc[rb][0]);
-                acc[rb][1] = mfma32h(a8, bh[g][1], acc[rb][1]);
+                acc[rb][0] = mfma32h(a8, bt0, acc[rb][0]);
+                acc[rb][1] = mfma32h(a8, bt1, acc[rb][1]);
             }
             return;
         }
@@ -457,51 +461,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // load latency.  Both orders in ONE kernel behind a runtime switch cost up to 35 % at other
     // shapes, hence the template parameter.  Measured, not derived: the same order without the
     // (unreached) single-group branch below compiles to a kernel that gains nothing (309.9 k).
-    if constexpr (LDSB) {
-        load_epilogue_operands();
-        ldsb_write_b(I0{});
-        const int ngroups = (a.nchunks + 3) >> 2;
-        auto group_body = [&](int g, auto par) {
-            constexpr int P = decltype(par)::value;              // g & 1: ring slot, staging set, residual slots 4P..4P+3
-            using Q = std::integral_constant<int, P ^ 1>;
-            __syncthreads();             // group g is in the ring; everybody is done reading group g - 1
-            if (g + 1 < ngroups) ldsb_write_b(Q{});
-            if (g + 2 < ngroups) ldsb_load_b(g + 2, par);
-            const float* bs = bl + P * NW_A * 512 + l * 4;
-            f32x4 b0[4], b1[4];
-#pragma unroll
-            for (int sc = 0; sc < 4; ++sc) {                     // the group's dictionary fragments, up front
-                b0[sc] = *(const f32x4*)(bs + sc * 512);
-                b1[sc] = *(const f32x4*)(bs + sc * 512 + 256);
-            }
-            auto chunk = [&](auto sc_tag) {
-                constexpr int SC = decltype(sc_tag)::value;
-                const int c = 4 * g + SC;
-                ldsb_load_a(c + 7, std::integral_constant<int, (4 * P + SC + 7) % 8>{});
-                f32x4 r4 = avw[4 * P + SC][0];
-#pragma unroll
-                for (int ks = 1; ks < NP; ++ks) r4 += avw[4 * P + SC][ks];
-                const bool ok = c < a.nchunks;
-                if (IS_FIRST && ab_raw == 0 && ok)      // (republish x_t at a frame-independent address)
-                    *(f32x4*)(a.xcur + (size_t)(mb0 + w) * nft * 256 + 256 * c + l * 4) = r4;
-                if (!ok) r4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    const f32x4 bb = (s2 >> 1) ? b1[SC] : b0[SC];
-                    acc[0][0] = mfma16(r4[s2], bb[(s2 & 1) * 2], acc[0][0]);
-                    acc[0][1] = mfma16(r4[s2], bb[(s2 & 1) * 2 + 1], acc[0][1]);
-                }
-            };
-            chunk(std::integral_constant<int, 0>{});
-            chunk(std::integral_constant<int, 1>{});
-            chunk(std::integral_constant<int, 2>{});
-            chunk(std::integral_constant<int, 3>{});
-        };
-        for (int g = 0; g < ngroups; g += 2) {
-            group_body(g, I0{});
-            if (g + 1 < ngroups) group_body(g + 1, I1{});
-        }
-    } else if (LATE) {
+    if (LATE) {
         if (exact && per_wave <= G) {      // (not reached with the shapes pick_a_func sends here)
             load_chunk(PF, PF % G);
 #pragma unroll
@@ -541,21 +501,19 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
 
     // ---- cross-wave reduction of the 4 F-splits through LDS --------------------------------
     DRNMF_STAMP(1, 3);
-    if constexpr (LDSB) {       // one complete row block per wave: no partials to add, only the layout change
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            f32x2 pr = {acc[0][0][v], acc[0][1][v]};
-            *(f32x2*)(red + ((0 * RB + w) * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
-        }
-    } else {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            float* rr = red + ((w * RB + rb) * ROWS + 4 * q + v) * ATOMS;
+            if (HALF) {     // (transposed dictionary reads: accumulator a holds atoms 16 a + j)
+                rr[j] = acc[rb][0][v];
+                rr[16 + j] = acc[rb][1][v];
+            } else {        // (fp32 cell_a packing: atoms 2 j + a)
                 f32x2 pr = {acc[rb][0][v], acc[rb][1][v]};
-                *(f32x2*)(red + ((w * RB + rb) * ROWS + 4 * q + v) * ATOMS + 2 * j) = pr;
+                *(f32x2*)(rr + 2 * j) = pr;
             }
-    }
+        }
     __syncthreads();
     DRNMF_STAMP(1, 4);
     if (NW_A > 4 && tid >= 256) return;   // the elementwise epilogue is 256 threads wide
@@ -566,7 +524,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
         const size_t hoff = hoff0 + rb * hstep;
         f32x2 gsum = *(const f32x2*)(red + ((0 * RB + rb) * ROWS + erow) * ATOMS + ec);
 #pragma unroll
-        for (int ww = 1; ww < (LDSB ? 1 : NW_A); ++ww) {
+        for (int ww = 1; ww < NW_A; ++ww) {
             const f32x2 p2 = *(const f32x2*)(red + ((ww * RB + rb) * ROWS + erow) * ATOMS + ec);
             gsum[0] += p2[0];
             gsum[1] += p2[1];
@@ -694,7 +652,7 @@ load_state_kernel(const float* __restrict__ init, float* __restrict__ state,
                   float* __restrict__ rs_part, int* tptr, int B, int N, int Np, int Bp, int numA) {
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wv;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { tptr[0] = 0; tptr[16] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { tptr[0] = 0; tptr[16] = 0; tptr[32] = 0; }
     if (b >= Bp) return;
     float s = 0.f;
     for (int n = l; n < Np; n += 64) {
@@ -759,7 +717,7 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
     __syncthreads();
     const float tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     for (int i = tid; i < 2 * numA * Bp; i += 256) rs_part[i] = (i < Bp) ? tot : 0.f;
-    if (tid == 0) { tptr[0] = 0; tptr[16] = 0; }
+    if (tid == 0) { tptr[0] = 0; tptr[16] = 0; tptr[32] = 0; }
 }
 
 // KL / beta cell: r = g(x_t, x^) on the packed [Bp][Fp] residual buffer, in place (x^ was left
@@ -790,6 +748,58 @@ resid_div_kernel(const float* __restrict__ xp, float* __restrict__ r, const int*
     r[i] = g;
 }
 
+// Dictionary prefetch for chains whose untied dictionaries exceed the 256-MB Infinity Cache (BASELINE
+// configs[4]: F = 1025, N = 8000, K = 50 -- 0.8 GB of fp16 dictionaries, every layer-step a first touch that
+// waits ~2.8 us for HBM).  A few workgroups on a side stream of the handle run AHEAD of the chain: step
+// s = t K + k uses stored layer s mod K; the kernel reads that layer's packing(s) -- the loads' only purpose
+// is the allocation in the memory-side cache -- once the chain's progress counter (cell_a launches started,
+// CellAArgs::prog) has come within `ahead` steps of s, and skips steps the chain has already passed.  The
+// chain never waits for it; it waits for the chain with a bounded poll and simply ends when the bound is
+// hit (a prefetch is a hint: no fault).  Workgroup b of gridDim.x streams the b-th slice of every layer.
+__global__ void __launch_bounds__(256)
+dict_prefetch_kernel(const char* base0, const char* base1, size_t layer_bytes, int n_layers,
+                     unsigned steps_total, const unsigned* prog, unsigned ahead, int nt) {
+    __shared__ unsigned sh_cur;
+    const int tid = threadIdx.x;
+    // whole 4-KB rows (256 lanes x 16 bytes) per workgroup
+    const size_t rows = (layer_bytes + 4095) / 4096;
+    const size_t r0 = rows * blockIdx.x / gridDim.x, r1 = rows * (blockIdx.x + 1) / gridDim.x;
+    for (unsigned s = 0; s < steps_total; ++s) {
+        if (tid == 0) {
+            unsigned cur = 0, spins = 0;
+            for (;;) {
+                cur = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur + ahead >= s) break;
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1u << 20)) { cur = 0xffffffffu; break; }       // (~1 s without progress: give up)
+            }
+            sh_cur = cur;
+        }
+        __syncthreads();
+        const unsigned cur = sh_cur;
+        __syncthreads();
+        if (cur == 0xffffffffu) return;
+        if (cur > s) continue;                                // the chain is past this step already
+        const size_t lo = (size_t)(s % (unsigned)n_layers) * layer_bytes;
+        for (int which = 0; which < 2; ++which) {
+            const char* base = which ? base1 : base0;
+            if (!base) continue;
+            const char* p = base + lo;
+            for (size_t r = r0; r < r1; r += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    size_t off = (r + u < r1 ? r + u : r1 - 1) * 4096 + (size_t)tid * 16;
+                    if (off + 16 > layer_bytes) off = layer_bytes - 16;
+                    if (nt) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v[u]) : "v"(p + off) : "memory");
+                    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(p + off) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+    }
+}
+
 template <int G, int KS, int RB, bool AH, bool HALF, bool LATE = false>
 void* a_func(bool first, bool last, bool qred = false) {
     if (qred && !LATE) {        // (first layers never read the previous layer's odd bins)
@@ -800,18 +810,6 @@ void* a_func(bool first, bool last, bool qred = false) {
     if (first) return (void*)&cell_a_kernel<G, KS, RB, true, false, AH, HALF, LATE>;
     if (last) return (void*)&cell_a_kernel<G, KS, RB, false, true, AH, HALF, LATE>;
     return (void*)&cell_a_kernel<G, KS, RB, false, false, AH, HALF, LATE>;
-}
-
-template <int KS>
-void* a_func_ldsb(bool first, bool last, bool qred) {
-    if (qred) {
-        if (last) return (void*)&cell_a_kernel<8, KS, 4, false, true, false, false, false, true, true>;
-        if (!first) return (void*)&cell_a_kernel<8, KS, 4, false, false, false, false, false, true, true>;
-    }
-    if (first && last) return (void*)&cell_a_kernel<8, KS, 4, true, true, false, false, false, false, true>;
-    if (first) return (void*)&cell_a_kernel<8, KS, 4, true, false, false, false, false, false, true>;
-    if (last) return (void*)&cell_a_kernel<8, KS, 4, false, true, false, false, false, false, true>;
-    return (void*)&cell_a_kernel<8, KS, 4, false, false, false, false, false, false, true>;
 }
 
 template <int KS, int RB, bool AH, bool HALF>
@@ -832,16 +830,6 @@ void* a_func_g(int per_wave, bool first, bool last, bool qred = false) {
 template <bool AH, bool HALF>
 void* pick_a_func_ah(int per_wave, int KS, int RB, bool first, bool last, bool qred) {
     // row-blocked variants exist for KS <= 2 (workspace_layout never pairs RB > 1 with more)
-    if constexpr (!AH && !HALF) {
-        if (RB == 4) {
-            // four row blocks: the LDS-shared form (DRNMF_LDSB=0: the register form, four row blocks per wave)
-            const char* e = tune_env("DRNMF_LDSB");
-            if (!(e && atoi(e) == 0))
-                return KS == 1 ? a_func_ldsb<1>(first, last, qred) : a_func_ldsb<2>(first, last, qred);
-            return KS == 1 ? a_func_g<1, 4, AH, HALF>(per_wave, first, last, qred)
-                           : a_func_g<2, 4, AH, HALF>(per_wave, first, last, qred);
-        }
-    }
     if (RB == 2) return KS == 1 ? a_func_g<1, 2, AH, HALF>(per_wave, first, last, qred)
                                 : a_func_g<2, 2, AH, HALF>(per_wave, first, last, qred);
     switch (KS) {
@@ -859,7 +847,6 @@ void* pick_a_func(int nchunks, int KS, int RB, bool first, bool last, bool all_h
         if (all_hidden)   // (training: every hidden layer goes out in fp32 for the fp32 BPTT)
             return RB == 2 ? a_func_g<1, 2, true, true>(per_wave, first, last, qred)
                            : a_func_g<1, 1, true, true>(per_wave, first, last, qred);
-        if (RB == 4) return a_func_g<1, 4, false, true>(per_wave, first, last, qred);
         return RB == 2 ? a_func_g<1, 2, false, true>(per_wave, first, last, qred)
                        : a_func_g<1, 1, false, true>(per_wave, first, last, qred);
     }
@@ -1326,12 +1313,13 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     const dim3 grid_a(8u * (unsigned)(W.Bp / (ROWS * W.RBa)), (unsigned)(round_up(W.numA, 8) / 8));
     const dim3 grid_b(8u * (unsigned)numM, (unsigned)(round_up(nft * W.KS, 8) / 8));
     const bool qred = qred_wanted(W.numA, W.ntail, nft, W.KS, W.RB);
-    // per stored layer Fp*Np*4 bytes: the fp32 packing, or the fp16 DpA packing followed by DpB
+    // per stored layer: the fp32 packing of cell_b (Fp*Np*4 bytes; cell_a's lies at off_dnA), or the ONE
+    // fp16 packing both kernels read (Fp*Np*2 bytes)
     const char* Dn_base = pb + L.off_dn;
-    const size_t dstride = (size_t)L.Fp * L.Np * 4;
+    const size_t dstride = (size_t)L.Fp * L.Np * (half ? 2 : 4);
     auto Dn_of = [&](int k) { return Dn_base + (d->n_D == 1 ? 0 : (size_t)k * dstride); };
-    auto DnB_of = [&](int k) { return Dn_of(k) + (half ? dstride / 2 : 0); };
-    auto DnA_of = [&](int k) {      // cell_a's operand: fp16 DpA, or the fp32 cell_a packing
+    auto DnB_of = [&](int k) { return Dn_of(k); };
+    auto DnA_of = [&](int k) {      // cell_a's operand: the fp16 packing again, or the fp32 cell_a packing
         return half ? Dn_of(k) : pb + L.off_dnA + (d->n_D == 1 ? 0 : (size_t)k * dstride);
     };
     auto tail_of = [&](int k) {
@@ -1379,6 +1367,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.ablate = tune_env("DRNMF_ABLATE_A") ? atoi(tune_env("DRNMF_ABLATE_A")) : 0;
         a.Rsave = (W.off_rsave != 0 && k >= 1)
                       ? (float*)(ws + W.off_rsave) + (size_t)(k - 1) * d->B * d->T * W.Fp : nullptr;
+        a.prog = (unsigned*)(tA + 32);
         return a;
     };
     auto make_b = [&](int k) {   // between layer k and k+1
@@ -1519,6 +1508,39 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     hipGraphExec_t exec_n = nullptr, exec_1 = nullptr;
     int32_t grc = get_graph(fpg_max, &exec_n);
     if (grc) return grc;
+    // ---- dictionary prefetch on a side stream (dict_prefetch_kernel) -----------------------------
+    // Untied dictionaries past the Infinity Cache, kernels that count their launches (fp16 operands, or
+    // fp32 with more than 64 atom blocks), a whole (unsplit) call.  DRNMF_PREFETCH=0|1 forces the choice,
+    // DRNMF_PF_WGS / DRNMF_PF_AHEAD / DRNMF_PF_NT its geometry (measurement aids).
+    bool prefetch = false;
+    if (!plan && K > 1 && d->n_D == K && (half || qred)) {
+        const size_t per_layer = dstride * (half ? 1 : 2);
+        prefetch = per_layer * (size_t)K > ((size_t)192 << 20);
+        if (const char* e = tune_env("DRNMF_PREFETCH")) prefetch = atoi(e) != 0;
+    }
+    if (prefetch) {
+        if (!h->side_stream[0]) DRNMF_HIP(h, hipStreamCreateWithFlags(&h->side_stream[0], hipStreamNonBlocking));
+        if (!h->join_ev[0]) DRNMF_HIP(h, hipEventCreateWithFlags(&h->join_ev[0], hipEventDisableTiming));
+        if (!h->fork_ev) DRNMF_HIP(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+        // (behind the prologue: the progress counter is zero)
+        DRNMF_HIP(h, hipEventRecord(h->fork_ev, stream));
+        DRNMF_HIP(h, hipStreamWaitEvent(h->side_stream[0], h->fork_ev, 0));
+        int wgs = 64, ahead = 2, nt = 0;
+        if (const char* e = tune_env("DRNMF_PF_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) wgs = v; }
+        if (const char* e = tune_env("DRNMF_PF_AHEAD")) { const int v = atoi(e); if (v >= 0 && v <= 16) ahead = v; }
+        if (const char* e = tune_env("DRNMF_PF_NT")) nt = atoi(e) != 0;
+        hipLaunchKernelGGL(dict_prefetch_kernel, dim3((unsigned)wgs), dim3(256), 0, h->side_stream[0],
+                           Dn_base, half ? (const char*)nullptr : pb + L.off_dnA, dstride, K,
+                           (unsigned)d->T * (unsigned)K, (const unsigned*)(tA + 32), (unsigned)ahead, nt);
+        DRNMF_HIP(h, hipGetLastError());
+    }
+    // (the caller's stream takes the prefetch kernel's end in: it exits with the chain's last step)
+    auto join_prefetch = [&]() -> int32_t {
+        if (!prefetch) return DRNMF_OK;
+        DRNMF_HIP(h, hipEventRecord(h->join_ev[0], h->side_stream[0]));
+        DRNMF_HIP(h, hipStreamWaitEvent(stream, h->join_ev[0], 0));
+        return DRNMF_OK;
+    };
     if (plan) {
         plan->exec_n = exec_n;
         plan->fpg = fpg_max;
@@ -1532,12 +1554,20 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         return DRNMF_OK;
     }
     int t = 0;
-    for (; t + fpg_max <= d->T; t += fpg_max) DRNMF_HIP(h, hipGraphLaunch(exec_n, stream));
-    if (t < d->T) {
-        grc = get_graph(1, &exec_1);     // (may evict; exec_n is not used again)
-        if (grc) return grc;
-        for (; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(exec_1, stream));
+    int32_t lrc = DRNMF_OK;
+    for (; t + fpg_max <= d->T && !lrc; t += fpg_max)
+        if (hipGraphLaunch(exec_n, stream) != hipSuccess) lrc = DRNMF_ERR_HIP;
+    if (t < d->T && !lrc) {
+        lrc = get_graph(1, &exec_1);     // (may evict; exec_n is not used again)
+        for (; t < d->T && !lrc; ++t)
+            if (hipGraphLaunch(exec_1, stream) != hipSuccess) lrc = DRNMF_ERR_HIP;
     }
+    // (also after a failed launch: the prefetch kernel gives up by itself within its poll bound, and the
+    // caller's stream must not run ahead of it)
+    const int32_t jrc = join_prefetch();
+    if (lrc == DRNMF_ERR_HIP) DRNMF_FAIL(h, DRNMF_ERR_HIP, "cell_forward: hipGraphLaunch failed (%s)", hipGetErrorString(hipGetLastError()));
+    if (lrc) return lrc;
+    if (jrc) return jrc;
     return store_final(W);
 }
 
@@ -1545,6 +1575,7 @@ extern "C" int32_t drnmf_cell_forward(drnmf_handle_t h, const drnmf_cell_desc_t*
                                       float mask_value, const void* params, const float* log_h0,
                                       float u0_diag, float u0_off, float uk_off, float* h_out,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
                              workspace, workspace_bytes, stream_, 0, nullptr);
 }
@@ -1555,6 +1586,7 @@ extern "C" int32_t drnmf_cell_forward_stateful(drnmf_handle_t h, const drnmf_cel
                                                float uk_off, const float* initial_state,
                                                float* final_state, float* h_out, void* workspace,
                                                size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     return cell_forward_impl(h, d, x, mask_value, params, log_h0, u0_diag, u0_off, uk_off, h_out,
                              workspace, workspace_bytes, stream_, 0, nullptr, initial_state, final_state);
 }
@@ -1564,6 +1596,7 @@ extern "C" int32_t drnmf_cell_profile(drnmf_handle_t h, const drnmf_cell_desc_t*
                                       float u0_diag, float u0_off, float uk_off, float* h_out,
                                       void* workspace, size_t workspace_bytes, void* stream_,
                                       int32_t frames, float* out_us_host) {
+    DRNMF_LOCK(h);
     if (frames <= 0 || !out_us_host) {
         if (h) snprintf(h->err, sizeof(h->err), "cell_profile: frames must be > 0, out non-NULL");
         return DRNMF_ERR_INVALID_ARG;
@@ -1578,6 +1611,7 @@ extern "C" int32_t drnmf_cell_forward_ista(drnmf_handle_t h, const drnmf_cell_de
                                            const float* initial_state, float* final_state,
                                            float* h_out, void* workspace, size_t workspace_bytes,
                                            void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;

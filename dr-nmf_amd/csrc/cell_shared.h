@@ -428,20 +428,13 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     }
     if (const char* e = tune_env("DRNMF_RB")) {   // tuning aid: force the row blocking
         const int v = atoi(e);
-        if (v == 1 || v == 2) W.RB = v;
-        // (four: fp32 inference only -- measured, never chosen: DESIGN.md 4.2)
-        if (v == 4 && !W.half && !d->return_all_hidden && d->B >= 64) W.RB = 4;
+        if (v == 1 || v == 2) W.RB = v;     // (four: measured in round 4, never chosen, removed: DESIGN.md 4.2)
     }
     if (W.gram) W.RB = 1;   // (one row block per workgroup: gram_wanted() counts 16-row tiles)
     // fp16 operand mode: cell_b keeps one row block per workgroup (its 16 x 16 output tiles with
     // the whole contraction are what fills the chip), cell_a may still carry two, which halves the
     // number of times a dictionary slice is pulled out of the L2
     W.RBa = W.RB;
-    if (!W.half && !W.gram && !d->return_all_hidden && d->B >= 64) {
-        // tuning aid: fp32 inference, cell_a alone on 64-row workgroups (4 = the LDS-shared form, cell_forward.hip LDSB)
-        if (const char* e = tune_env("DRNMF_RBA"))
-            if (atoi(e) == 4) W.RBa = 4;
-    }
     if (W.half && W.RB == 1) {
         const int groups = round_up(d->B, ROWS * 2) / (ROWS * 2);
         // measured at F=1025, N=8000, B=64 (once the odd-bin partials were out of cell_a's tail): one row
@@ -449,7 +442,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
         if (groups * W.numA >= 256) W.RBa = 2;
         if (const char* e = tune_env("DRNMF_RBA")) {
             const int v = atoi(e);
-            if (v == 1 || v == 2 || (v == 4 && !d->return_all_hidden)) W.RBa = v;
+            if (v == 1 || v == 2) W.RBa = v;
         }
     }
     W.Bp = round_up(d->B, ROWS * (W.RBa > W.RB ? W.RBa : W.RB));
@@ -575,11 +568,9 @@ void* pick_b_func(int nch_ks, int RB = 1, bool half = false, bool qred = false) 
     // fp16: nch_ks counts 32-atom chunks; eight rotating operand slots where a wave owns that many
     if (qred) {
         if (half) return RB == 2 ? pick_b_func_rb<2, true, true>(nch_ks) : pick_b_func_rb<1, true, true>(nch_ks);
-        if (RB == 4) return pick_b_func_rb<4, false, true>(nch_ks);
         return RB == 2 ? pick_b_func_rb<2, false, true>(nch_ks) : pick_b_func_rb<1, false, true>(nch_ks);
     }
     if (half) return RB == 2 ? pick_b_func_rb<2, true, false>(nch_ks) : pick_b_func_rb<1, true, false>(nch_ks);
-    if (RB == 4) return pick_b_func_rb<4, false, false>(nch_ks);
     if (RB == 2) return pick_b_func_rb<2, false, false>(nch_ks);
     return pick_b_func_rb<1, false, false>(nch_ks);
 }

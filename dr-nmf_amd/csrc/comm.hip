@@ -77,6 +77,7 @@ Rccl* rccl() {
 }  // namespace
 
 extern "C" int32_t drnmf_comm_unique_id(drnmf_handle_t h, void* id_out_host) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!id_out_host) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "comm_unique_id: NULL id buffer");
     Rccl* R = rccl();
@@ -89,6 +90,7 @@ extern "C" int32_t drnmf_comm_unique_id(drnmf_handle_t h, void* id_out_host) {
 
 extern "C" int32_t drnmf_comm_init(drnmf_handle_t h, const void* id_host, int32_t rank,
                                    int32_t world) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!id_host || world < 1 || rank < 0 || rank >= world)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "comm_init: need an id and 0 <= rank (%d) < world (%d)",
@@ -108,6 +110,7 @@ extern "C" int32_t drnmf_comm_init(drnmf_handle_t h, const void* id_host, int32_
 }
 
 extern "C" int32_t drnmf_comm_destroy(drnmf_handle_t h) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!h->comm) return DRNMF_OK;
     Rccl* R = rccl();
@@ -120,6 +123,7 @@ extern "C" int32_t drnmf_comm_destroy(drnmf_handle_t h) {
 }
 
 extern "C" int32_t drnmf_comm_info(drnmf_handle_t h, int32_t* rank, int32_t* world) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (rank) *rank = h->comm_rank;
     if (world) *world = h->comm ? h->comm_world : 1;
@@ -127,6 +131,7 @@ extern "C" int32_t drnmf_comm_info(drnmf_handle_t h, int32_t* rank, int32_t* wor
 }
 
 extern "C" int32_t drnmf_allreduce_grads(drnmf_handle_t h, float* flat, int64_t n, void* stream) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!flat || n <= 0) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "allreduce_grads: empty buffer");
     if (!h->comm)
@@ -139,6 +144,7 @@ extern "C" int32_t drnmf_allreduce_grads(drnmf_handle_t h, float* flat, int64_t 
 
 extern "C" int32_t drnmf_broadcast_params(drnmf_handle_t h, float* buf, int64_t n, int32_t root,
                                           void* stream) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!buf || n <= 0) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "broadcast_params: empty buffer");
     if (!h->comm)

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/drnmf.h"
@@ -142,6 +143,11 @@ struct GraphEntry {
 };
 
 struct drnmf_handle_s {
+    // Calls on ONE handle from several host threads are serialised here (every entry point of the ABI
+    // that takes a handle holds it while it validates and ENQUEUES -- the graph cache, the side streams
+    // and fork / join events of split calls, the FFT tables and the error string are per-handle state);
+    // handles are independent of each other.  Recursive: drnmf_destroy -> drnmf_comm_destroy.
+    std::recursive_mutex mu;
     int device = 0;
     char err[512] = {0};
     std::vector<GraphEntry> graphs;
@@ -199,6 +205,10 @@ void persist_query_occupancy(int device, int* per_cu, int* n_cu);   // cell_forw
 int32_t graph_cache_make_room(drnmf_handle_t h, hipStream_t stream, size_t max_entries);
 
 extern char g_create_err[512];
+
+#define DRNMF_LOCK(h)                                        \
+    std::unique_lock<std::recursive_mutex> handle_lock_;     \
+    if (h) handle_lock_ = std::unique_lock<std::recursive_mutex>((h)->mu)
 
 #define DRNMF_FAIL(h, code, ...)                                  \
     do {                                                          \
@@ -283,7 +293,8 @@ static inline ParamsLayout params_layout(const drnmf_cell_desc_t* d) {
     L.Fp = pad_f_mode(d->F, d->operand_f16 != 0);
     L.Np = pad_n(d->N);
     size_t o = 0;
-    L.off_dn = o;        o += (size_t)d->n_D * L.Fp * L.Np * sizeof(float);
+    // (fp32: cell_b's packing, cell_a's at off_dnA; operand_f16: the ONE fp16 packing both kernels read)
+    L.off_dn = o;        o += round_up_sz((size_t)d->n_D * L.Fp * L.Np * (d->operand_f16 ? 2 : 4), 256);
     L.off_colnorm = o;   o += round_up_sz((size_t)d->n_D * L.Np * sizeof(float), 256);
     L.off_inv_alpha = o; o += round_up_sz((size_t)d->K * L.Np * sizeof(float), 256);
     L.off_bias = o;      o += round_up_sz((size_t)d->K * L.Np * sizeof(float), 256);

@@ -127,6 +127,7 @@ to_int16_kernel(const float* __restrict__ x, const float* __restrict__ amax,
 
 extern "C" int32_t drnmf_divide_a_by_aplusb(drnmf_handle_t h, int64_t n, const float* A,
                                             const float* B, float* out, void* stream) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n < 0 || (n > 0 && (!A || !B || !out)))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "divide_a_by_aplusb: bad argument");
@@ -139,6 +140,7 @@ extern "C" int32_t drnmf_divide_a_by_aplusb(drnmf_handle_t h, int64_t n, const f
 
 extern "C" int32_t drnmf_add(drnmf_handle_t h, int64_t n, const float* a, const float* b,
                              float* out, void* stream) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n < 0 || (n > 0 && (!a || !b || !out))) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "add: bad argument");
     if (n == 0) return DRNMF_OK;
@@ -158,6 +160,7 @@ extern "C" int32_t drnmf_loss_forward(drnmf_handle_t h, int64_t rows, int32_t F,
                                       const float* y, const float* w, const float* hidden,
                                       int64_t ld_h, int32_t N2, float l1_weight, float* sums,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (rows <= 0 || F <= 0 || (mode != 0 && mode != 1))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "loss_forward: rows, F must be positive, mode 0 or 1");
@@ -180,6 +183,7 @@ extern "C" size_t drnmf_wav_int16_workspace_bytes(void) { return (AM_BLOCKS + 1)
 
 extern "C" int32_t drnmf_wav_int16(drnmf_handle_t h, int64_t n, const float* x, int16_t* out,
                                    void* workspace, size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n < 0 || (n > 0 && (!x || !out || !workspace)))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "wav_int16: bad argument");

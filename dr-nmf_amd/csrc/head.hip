@@ -268,6 +268,7 @@ extern "C" int32_t drnmf_head_forward(drnmf_handle_t h, int64_t rows, int32_t F,
                                       const float* kernel_clean, const float* kernel_noise,
                                       int32_t square, float* mask, float* A_out, float* Bn_out,
                                       float* ecat, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (rows <= 0 || F <= 0 || r <= 0 || ld_h < 2 * (int64_t)r + h_off || h_off < 0)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "head_forward: bad shape rows=%lld F=%d r=%d ld_h=%lld",

@@ -20,7 +20,7 @@ const char* const kTuneNames[] = {
     "DRNMF_ABLATE", "DRNMF_ABLATE_A", "DRNMF_ABLATE_B", "DRNMF_CP_FULL", "DRNMF_DENSE_NW", "DRNMF_FPG",
     "DRNMF_G8", "DRNMF_GRAM", "DRNMF_KS", "DRNMF_LATE", "DRNMF_NO_ALLB", "DRNMF_NO_GRAPH",
     "DRNMF_PERSIST", "DRNMF_PERSIST_FAULT", "DRNMF_RB", "DRNMF_RBA", "DRNMF_BIG", "DRNMF_SPLIT",
-    "DRNMF_THIN", "DRNMF_LDSB"};
+    "DRNMF_THIN", "DRNMF_PREFETCH", "DRNMF_PF_WGS", "DRNMF_PF_AHEAD", "DRNMF_PF_NT"};
 std::mutex g_tune_mu;
 // (values are never erased or overwritten in place: a pointer handed out stays valid for the
 // process lifetime; a reload appends a new generation)
@@ -112,6 +112,7 @@ extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
 // up), read AND cleared.  Meaningful after the caller has synchronised the stream of the call in
 // question: that call itself returned DRNMF_OK when it was enqueued.
 extern "C" int32_t drnmf_check_status(drnmf_handle_t h) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     return persist_check_flag(h);
 }
@@ -119,6 +120,7 @@ extern "C" int32_t drnmf_check_status(drnmf_handle_t h) {
 // 1: this handle may run the persistent small-shape chains (it owns the device's cross-process lock and
 // has a fault word); 0: it always takes the launch-per-layer-step graphs (same results).
 extern "C" int32_t drnmf_persist_admitted(drnmf_handle_t h) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     return (h->persist_lock_fd >= 0 && h->persist_flag != nullptr && h->persist_per_cu >= 1) ? 1 : 0;
 }
@@ -127,6 +129,7 @@ extern "C" int32_t drnmf_persist_admitted(drnmf_handle_t h) {
 // drnmf_adam_step_flat): the host reads a slot after waiting for an event recorded behind the kernel --
 // no device-to-host copy, no stream synchronisation.  Owned by the handle.
 extern "C" int32_t drnmf_host_report_ring(drnmf_handle_t h, float** ring_host, int32_t* slots) {
+    DRNMF_LOCK(h);
     if (!h || !ring_host || !slots) return DRNMF_ERR_INVALID_ARG;
     if (!h->persist_flag) DRNMF_FAIL(h, DRNMF_ERR_HIP, "host_report_ring: no host-mapped memory on this handle");
     *ring_host = (float*)((char*)h->persist_flag + 256);
@@ -141,6 +144,7 @@ __global__ void status_take_kernel(unsigned* flag, float* dst) {
     if (v != 0u) *dst += 1.0f;
 }
 extern "C" int32_t drnmf_status_take_device(drnmf_handle_t h, float* dst_device, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h || !dst_device) return DRNMF_ERR_INVALID_ARG;
     if (!h->persist_flag) return DRNMF_OK;       // (no fault word: the persistent chains are never taken)
     hipLaunchKernelGGL(status_take_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, h->persist_flag,
@@ -305,16 +309,16 @@ extern "C" size_t drnmf_params_bytes(const drnmf_cell_desc_t* d) {
 // One thread per (stored layer, atom column): pass 1 accumulates sum_f exp(log_D)^2 in f order,
 // pass 2 writes exp(log_D)/sqrt(sum) -- enhance.py:177-178 / 190-191 -- into the TILE-PACKED
 // dictionary (1 KB blocks of 16 bins x 16 atoms; see cell_forward.hip).  Padded rows/columns are
-// written as zeros.  HALF = false: fp32 Dp[ft][ac][f%16][n%16].  HALF = true: two fp16 packings for
-// v_mfma_f32_16x16x32_f16 (a lane's operand = 8 k-slots (q, e) = 16 bytes; Fp % 32 == 0), 1 KB
-// blocks of 512 halves, lane l = q*16 + j reads at l*16 bytes:
-//   A (cell_a, contracts bins):  block (f/32, 2 (n/32) + a): [q][j][e] = Dn[32 (f/32) + 16 (e/4) +
-//                                4 (e%4) + q][32 (n/32) + 2j + a] -- the bins of slot (q, e) are
-//                                those of the fp32 residual / input blocks 2(f/32) + e/4, element
-//                                s = e%4 of lane q; a = 0 / 1: cell_a's two accumulators
-//   B (cell_b, contracts atoms): block (f/16, n/32): [q][j = f%16][e] = Dn[f][32 (n/32) + 8q + e]
-// each Fp*Np halves.  With HALF the bins from 16*(F/16) up when F % 16 <= MAX_TAIL (the odd bins
-// handled outside the matrix cores) are ZERO in packing A and B.
+// written as zeros.  HALF = false: fp32 Dp[ft][ac][f%16][n%16].  HALF = true: ONE fp16 packing for
+// v_mfma_f32_16x16x32_f16 (a lane's operand = 8 k-slots = 16 bytes; Fp % 32 == 0), 1 KB blocks of 512
+// halves, lane l = q*16 + j reads at l*16 bytes:
+//   block (f/16, n/32): [q][j = f%16][e] = Dn[f][32 (n/32) + 8q + e]
+// Fp*Np halves per layer: cell_b (contracts atoms) takes a lane's 16 bytes as they are; cell_a (contracts
+// bins) reads the SAME blocks and transposes them on the way through LDS (ds_read_b64_tr_b16,
+// cell_forward.hip) -- a layer's dictionary is fetched from HBM once per layer-step, by cell_b, and the
+// cell_a launch behind it finds it in the Infinity Cache.  (Rounds 2-4 kept a second packing for cell_a:
+// 1.6 GB instead of 0.8 GB at F = 1025, N = 8000, K = 50, every layer-step reading both from HBM.)  With HALF
+// the bins from 16*(F/16) up when F % 16 <= MAX_TAIL (the odd bins handled outside the matrix cores) are ZERO.
 // tail[layer][i][n] = Dn[16*(F/16) + i][n] for the (at most MAX_TAIL) bins past the last full tile.
 template <bool HALF>
 __global__ void __launch_bounds__(256)
@@ -333,8 +337,7 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
     // cell_b reads its four atoms at l*16 bytes: consecutive lanes, consecutive 16 bytes
     float* dn = (float*)Dn_ + (size_t)layer * lstride + (size_t)(n >> 4) * 256 +
                 ((n & 15) >> 2) * 64 + (n & 3);
-    f16* dA = (f16*)Dn_ + (size_t)layer * 2 * lstride;
-    f16* dB = dA + lstride;
+    f16* dB = (f16*)Dn_ + (size_t)layer * lstride;
     float* dnA = HALF ? nullptr : DnA_ + (size_t)layer * lstride;
     auto put = [&](int f, float v) {   // (v by value: zeroed past f_mfma in the fp16 packings)
         if (!HALF) {
@@ -345,12 +348,8 @@ prep_dict_kernel(const float* __restrict__ log_D, void* __restrict__ Dn_,
                 ((fi & 3) * 16 + (n32 >> 1)) * 4 + ((fi >> 2) & 1) * 2 + (n32 & 1)] = v;
         } else {
             if (f >= f_mfma) v = 0.f;      // odd bins: outside the matrix cores (tail rows below)
-            const int fi = f & 31, n32 = n & 31;
-            // A: block (f/32, 2 (n/32) + a), column j: atom n = 32 (n/32) + 2j + a (cell_a's two
-            //    accumulators hold the even / odd atoms of its 32); slot q = fi%4, e = 4*(fi/16) + (fi%16)/4
-            dA[((size_t)(f >> 5) * NAC + 2 * (n >> 5) + (n32 & 1)) * 512 +
-               ((fi & 3) * 16 + (n32 >> 1)) * 8 + (fi >> 4) * 4 + ((fi & 15) >> 2)] = (f16)v;
-            // B: block (f/16, n/32): slot q = n32/8, e = n32%8
+            const int n32 = n & 31;
+            // block (f/16, n/32): slot q = n32/8, e = n32%8
             dB[((size_t)(f >> 4) * (Np / 32) + (n >> 5)) * 512 + ((n32 >> 3) * 16 + (f & 15)) * 8 +
                (n32 & 7)] = (f16)v;
         }
@@ -429,6 +428,7 @@ prep_scalars_kernel(const float* __restrict__ log_alph, const float* __restrict_
 extern "C" int32_t drnmf_prepare_params(drnmf_handle_t h, const drnmf_cell_desc_t* d,
                                         const float* log_D, const float* log_alph,
                                         const float* log_lam1, void* params, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;

@@ -145,6 +145,7 @@ extern "C" int32_t drnmf_sdr_corr(drnmf_handle_t h, int32_t n_sig, int64_t nsamp
                                   const float* est, const float* ref, double* r_out,
                                   double* d_out, void* workspace, size_t workspace_bytes,
                                   void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n_sig <= 0 || nsampl <= 0 || flen <= 0 || flen > MAX_FLEN || n_sig > 65535 || !est ||
         !ref || !r_out || !d_out || !workspace)
@@ -166,6 +167,7 @@ extern "C" int32_t drnmf_sdr_project(drnmf_handle_t h, int32_t n_sig, int64_t ns
                                      int32_t flen, const float* est, const float* ref,
                                      const double* coef, double* energies, float* out_db,
                                      void* workspace, size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n_sig <= 0 || nsampl <= 0 || flen <= 0 || flen > MAX_FLEN || n_sig > 65535 || !est ||
         !ref || !coef || !energies || !out_db || !workspace)

@@ -390,6 +390,7 @@ extern "C" int32_t drnmf_stft_frames(int64_t nsampl, int32_t N, int32_t hop) {
 extern "C" int32_t drnmf_stft_mag(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32_t N,
                                   int32_t hop, int32_t is_int16, const void* pcm, float* mag,
                                   void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n_sig <= 0 || nsampl <= 0 || hop <= 0)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "stft_mag: bad shape n_sig=%d nsampl=%lld hop=%d",
@@ -426,6 +427,7 @@ static int check_fft_size(drnmf_handle_t h, int N, const char* who) {
 extern "C" int32_t drnmf_stft(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, int32_t N,
                               int32_t hop, int32_t is_int16, const void* pcm, float* re, float* im,
                               float* mag, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n_sig <= 0 || nsampl <= 0 || hop <= 0 || !pcm || !re || !im)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "stft: bad argument");
@@ -459,6 +461,7 @@ extern "C" int32_t drnmf_istft_masked(drnmf_handle_t h, int32_t n_sig, int32_t n
                                       int64_t nsampl, int32_t N, int32_t hop, const float* re,
                                       const float* im, const float* mask, float* y,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n_sig <= 0 || n_frames <= 0 || nsampl <= 0 || hop <= 0 || !re || !im || !y || !workspace)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "istft_masked: bad argument");
@@ -485,6 +488,7 @@ extern "C" int32_t drnmf_istft_masked(drnmf_handle_t h, int32_t n_sig, int32_t n
 
 extern "C" int32_t drnmf_snr(drnmf_handle_t h, int32_t n_sig, int64_t nsampl, const float* est,
                              const float* ref, float* out_db, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n_sig <= 0 || nsampl <= 0 || !est || !ref || !out_db)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "snr: bad argument");

@@ -324,6 +324,7 @@ extern "C" int32_t drnmf_loss_head_backward(drnmf_handle_t h, int64_t rows, int3
                                             float* d_hidden, float* d_kernel_clean,
                                             float* d_kernel_noise, void* workspace,
                                             size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (rows <= 0 || F <= 0 || r <= 0 || h_off < 0 || ld_h < h_off + 2 * (int64_t)r)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "loss_head_backward: bad shape");
@@ -365,6 +366,7 @@ extern "C" int32_t drnmf_snmf_cost_head_backward(drnmf_handle_t h, int64_t rows,
                                                  float* d_kernel_clean, float* d_kernel_noise,
                                                  void* workspace, size_t workspace_bytes,
                                                  void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (rows <= 0 || F <= 0 || r <= 0 || h_off < 0 || ld_h < h_off + 2 * (int64_t)r)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "snmf_cost_head_backward: bad shape");
@@ -406,6 +408,7 @@ extern "C" int32_t drnmf_snmf_cost_head_backward(drnmf_handle_t h, int64_t rows,
 extern "C" int32_t drnmf_adam_step(drnmf_handle_t h, int64_t n, float* param, const float* grad,
                                    float* m, float* v, float lr_t, float beta1, float beta2,
                                    float eps, float grad_scale, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n <= 0 || !param || !grad || !m || !v)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step: bad argument");
@@ -422,6 +425,7 @@ extern "C" int32_t drnmf_adam_step_flat(drnmf_handle_t h, int64_t n_blocks,
                                         const float* sumsq256, float lr_t, float beta1, float beta2,
                                         float eps, float clipnorm, int32_t loss_norm, float reg_loss,
                                         float* report4, void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n_blocks <= 0 || n_blocks > 0x7fffffff || !blocks || !flat_grad || !flat_m || !flat_v || !scalars4)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat: bad argument");
@@ -438,6 +442,7 @@ extern "C" int32_t drnmf_adam_step_flat(drnmf_handle_t h, int64_t n_blocks,
 
 extern "C" int32_t drnmf_sumsq(drnmf_handle_t h, int64_t n, const float* g, float* out256,
                                void* stream_) {
+    DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (n <= 0 || !g || !out256) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "sumsq: bad argument");
     hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream_, g, n, out256);

@@ -213,7 +213,7 @@ int main(void) {
     /* layouts under every tuning variable that switches a branch of them */
     static const char* const env[][2] = {
         {NULL, NULL}, {"DRNMF_GRAM", "0"}, {"DRNMF_GRAM", "1"}, {"DRNMF_RB", "1"}, {"DRNMF_RB", "2"},
-        {"DRNMF_KS", "1"}, {"DRNMF_KS", "8"}, {"DRNMF_RBA", "4"}, {"DRNMF_CP_FULL", "0"},
+        {"DRNMF_KS", "1"}, {"DRNMF_KS", "8"}, {"DRNMF_RBA", "2"}, {"DRNMF_CP_FULL", "0"},
         {"DRNMF_SPLIT", "1"}, {"DRNMF_SPLIT", "3"}, {"DRNMF_SPLIT", "4"}, {"DRNMF_SPLIT", "8"}, {"DRNMF_PERSIST", "0"}};
     for (size_t i = 0; i < sizeof(env) / sizeof(*env); ++i) {
         if (env[i][0]) setenv(env[i][0], env[i][1], 1);

@@ -894,14 +894,11 @@ def test_plain_c_host_program_over_the_c_abi(dev, tmp_path):
     assert mx > 0 and err <= H_TOL * mx, out.stdout
 
 
-@pytest.mark.parametrize("B,split,r,gram,rba", [
-    (100, None, 20, "0", None), (100, "1", 20, "0", None), (130, "3", 20, "0", None), (250, "2", 20, "0", None),
-    (97, "4", 20, "0", None), (200, "8", 20, "0", None), (200, None, 250, None, None), (512, None, 20, "0", None),
-    # the large-batch cell_a variant (64 rows per workgroup, dictionary chunk shared through LDS:
-    # cell_forward.hip LDSB), never chosen by the rule: forced, whole and as sub-batches
-    (130, "1", 20, "0", "4"), (250, "2", 20, "0", "4"), (200, "1", 250, "0", "4"), (512, None, 250, "0", "4")],
+@pytest.mark.parametrize("B,split,r,gram", [
+    (100, None, 20, "0"), (100, "1", 20, "0"), (130, "3", 20, "0"), (250, "2", 20, "0"),
+    (97, "4", 20, "0"), (200, "8", 20, "0"), (200, None, 250, None), (512, None, 20, "0")],
     ids=lambda v: "-" if v is None else str(v))
-def test_large_batch_sub_batches_on_side_streams(dev, monkeypatch, B, split, r, gram, rba):
+def test_large_batch_sub_batches_on_side_streams(dev, monkeypatch, B, split, r, gram):
     """Inference batches of 96 rows and more run as independent sub-batches on side streams of the handle
     (csrc/cell_shared.h Workspace::split; batch rows never interact, custom_layers.py:337-338, 346-348).
     Ragged lengths, a masked first frame in the LAST sub-batch, caller-supplied initial states and the
@@ -918,10 +915,6 @@ def test_large_batch_sub_batches_on_side_streams(dev, monkeypatch, B, split, r, 
         monkeypatch.delenv("DRNMF_SPLIT", raising=False)
     else:
         monkeypatch.setenv("DRNMF_SPLIT", split)
-    if rba is None:
-        monkeypatch.delenv("DRNMF_RBA", raising=False)
-    else:
-        monkeypatch.setenv("DRNMF_RBA", rba)
     K, T, F = 3, 7, 33
     P, alt, labels, N = _problem(B, T, F, r, K, ragged=True, seed=B)
     P["X"][B - 1, 0] = -1.0
