@@ -306,17 +306,133 @@ def config5_bench(torch, dev, frames=64, B=64):
         esz = 2 if name == "f16" else 4
         bytes_launch = float(F) * N * esz + B * (N + F) * esz
         gbs = bytes_launch / (launch_us * 1e-6) / 1e9
+        # ... and priced per LAYER-STEP: a layer's dictionary is algorithmically needed once for the
+        # cell_b / cell_a pair that uses it (fp16: one packing, read from HBM once -- by cell_a's prefetching
+        # wave of the layer before -- and then out of the L2 / the Infinity Cache; fp32: two packings)
+        step_us = sec / (frames * K) * 1e6
+        bytes_step = float(F) * N * esz + 2.0 * B * (N + F) * esz
+        gbs_step = bytes_step / (step_us * 1e-6) / 1e9
         out[name] = {"frames_per_s": B * frames / sec, "tflops": tf, "frac_of_mfma_peak": tf / peak,
-                     "launch_us": launch_us,
+                     "launch_us": launch_us, "layer_step_us": step_us,
                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                   "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                  "bytes_per_launch": bytes_launch}}
+                                  "bytes_per_launch": bytes_launch},
+                     "roofline_per_layer_step": {"bound": "hbm", "achieved": gbs_step, "peak": PEAK_HBM_GBS,
+                                                 "unit": "GB/s", "frac": gbs_step / PEAK_HBM_GBS,
+                                                 "bytes_per_layer_step": bytes_step}}
         masks[name] = m_buf.clone()
         del model
     out["mask_mse_f16_vs_f32"] = float(((masks["f16"] - masks["f32"]) ** 2).mean())
     del X, h_buf, m_buf, masks
     torch.cuda.empty_cache()
     return out
+
+
+def dp_train_bench(torch, dev, dist, world, rank, shape, steps=10, warmup=3):
+    """BASELINE configs[3]: data-parallel training, every rank B utterances of its own (global batch =
+    world x B; 8 x 32 = 256 at the shipped shape), the PRODUCT's train_on_batch -- forward + loss + BPTT on
+    the local shard, ONE all-reduce of the flat gradient buffer over the library's RCCL communicator
+    (drnmf_allreduce_grads), fused Adam -- ragged lengths, weights broadcast from rank 0 by compile().
+    A COLLECTIVE function: every rank calls it.  Timed like the headline (barrier + synchronize on both
+    sides, max over ranks); frames/s is summed over ranks (weak scaling)."""
+    from drnmf_amd import layers, dp
+    B, T, F, r, K = shape
+    N = 2 * r
+    W, _, x, y = synth_on_device(torch, dev, B, T, F, r, seed=7654 + rank, want_clean=True)
+    lens = np.random.Generator(np.random.PCG64(7654 + rank)).integers(int(0.4 * T), T + 1, size=B)
+    keep = torch.arange(T, device=dev)[None, :] < torch.from_numpy(lens).to(dev)[:, None]
+    w = keep.to(torch.float32)
+    x = torch.where(keep[..., None], x, torch.full_like(x, -1.0))
+    y = torch.where(keep[..., None], y, torch.full_like(y, -1.0))
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K,
+             W=W, alph=400.0 if r >= 1000 else 50.0, lam1=1.0,
+             params_untied=["log_D", "log_alph"], params_trainable=["log_D", "log_alph"])
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.compile(lr=1e-3)                        # (broadcasts rank 0's weights)
+    losses = [model.train_on_batch(x, y, w) for _ in range(max(warmup, 1))]
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(model.train_on_batch(x, y, w))
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    flat = model._flat
+    acc = torch.tensor([wall, float(w.sum().item())], dtype=torch.float64, device=dev)
+    tmax = acc[:1].clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    vsum = acc[1:].clone()
+    dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+    sec = float(tmax.item()) / steps
+    # the step's one collective alone
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dp.allreduce_sum_(flat)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0.record()
+    for _ in range(5):
+        dp.allreduce_sum_(flat)
+    e1.record()
+    torch.cuda.synchronize()
+    ar_ms = e0.elapsed_time(e1) / 5.0
+    res = {"config": "F=%d N=%d K=%d untied, %d utterances x %d frames per GPU, ragged; global batch %d" %
+                     (F, N, K, B, T, world * B),
+           "n_gpus": world, "ms_per_step": sec * 1e3, "frames_per_s": world * B * T / sec,
+           "valid_frames_per_s": float(vsum.item()) / sec,
+           "allreduce_bytes": int(flat.numel()) * 4, "allreduce_ms": ar_ms,
+           "allreduce_GBps_bus": (2.0 * (world - 1) / world) * flat.numel() * 4 / (ar_ms * 1e-3) / 1e9,
+           "steps": steps, "warmup": warmup, "timing": "wall clock, barrier + synchronize, max over ranks",
+           "loss_first": float(losses[0]), "loss_last": float(losses[-1])}
+    del model, x, y, w
+    torch.cuda.empty_cache()
+    return res
+
+
+def c5_replicas_bench(torch, dev, dist, world, rank, frames=16, B=64, shape=(1025, 4000, 50)):
+    """BASELINE configs[4] on N GPUs: the path has no exchange step in inference -- every rank runs the
+    config-5 forward (fp16 MFMA operands, fp32 accumulate; cell + mask head) on its own B utterances
+    ("replicas only").  COLLECTIVE (barriers).  frames/s summed over ranks; the
+    per-launch figure is the slowest rank's."""
+    from drnmf_amd import layers, ops
+    F, r, K = shape
+    N = 2 * r
+    W, log_h0, X = synth_on_device(torch, dev, B, frames, F, r, seed=5 + rank)
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=frames, K_layers=K, W=W,
+             alph=0.4 * r, lam1=1.0, params_trainable=["log_D", "log_alph"],
+             params_untied=["log_D", "log_alph"], operand_dtype="float16")
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.cell.log_h0.copy_(torch.from_numpy(log_h0))
+    h_buf = torch.empty((B, frames, N), dtype=torch.float32, device=dev)
+    m_buf = torch.empty((B, frames, F), dtype=torch.float32, device=dev)
+
+    def step():
+        h = model.cell.call(X, mask_value=-1., out=h_buf)
+        ops.head_forward(h, model.clean.kernel, model.noise.kernel, out=m_buf)
+    step()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        best = float(tt.item()) if best is None else min(best, float(tt.item()))
+    ok = bool(torch.isfinite(m_buf).all().item())
+    launch_us = best / (frames * (2 * K - 1)) * 1e6
+    res = {"shape": "F=%d N=%d K=%d untied, fp16 operands, %d utterances x %d frames per GPU" % (F, N, K, B, frames),
+           "n_gpus": world, "frames_per_s": world * B * frames / best, "launch_us_slowest_rank": launch_us,
+           "GBps_per_gpu_algorithmic": (float(F) * N * 2 + B * (N + F) * 2) / (launch_us * 1e-6) / 1e9,
+           "finite_masks": ok, "timing": "wall clock, barrier on both sides, max over ranks, best of 3"}
+    del model, X, h_buf, m_buf
+    torch.cuda.empty_cache()
+    return res
 
 
 def dense_graph_bench(torch, dev, F, r, K, B, frames=40):
@@ -985,7 +1101,50 @@ def main():
             # the other shipped dictionary size (params_unfolded_snmf_ea1e7d48: r = 100, K = 5)
             extra["train_step_configs2_r100"] = safe(train_bench, torch, dev,
                                                      shape=(32, 500, 257, 100, 5))
+    if world > 1 and not a.no_extras:
+        # ---- the 8-GPU configurations of BASELINE.json (configs[3], configs[4]): every rank takes part ----
+        # (DRNMF_BENCH_TINY=1: the same control flow at toy shapes -- several ranks on ONE GPU over gloo,
+        # profiles/r05_n8_gloo_one_gpu.json; never a measurement)
+        tiny = os.environ.get("DRNMF_BENCH_TINY") == "1"
+        del h_buf, m_buf, X
+        model = None
+        torch.cuda.empty_cache()
+
+        def extras_timeout():
+            # a collective that never comes back inside an EXTRA must not cost the headline line
+            if rank == 0:
+                out["extra"] = dict(extra, error="a multi-rank extra timed out")
+                print(json.dumps(out), flush=True)
+            os._exit(0 if out.get("value") is not None else 4)
+
+        def multi():
+            res = {}
+            if not a.no_train:
+                dpt = {}
+                for r_dp in (100, 1000):
+                    shp = (4, 12, 33, 8 if r_dp == 100 else 24, 2) if tiny else (32, 500, 257, r_dp, 5)
+                    dpt["r%d" % r_dp] = dp_train_bench(torch, dev, dist, world, rank, shp,
+                                                       steps=2 if tiny else 10, warmup=1 if tiny else 3)
+                res["configs3_dp_training"] = dpt
+            if not a.no_config5:
+                res["configs4_c5"] = c5_replicas_bench(torch, dev, dist, world, rank,
+                                                       frames=4 if tiny else 16, B=4 if tiny else 64,
+                                                       shape=(65, 40, 3) if tiny else (1025, 4000, 50))
+            return res
+        res = run_guarded(multi, 1200.0, extras_timeout)
+        # (an exception on one rank only would leave the others inside a collective: every rank learns)
+        bad = torch.tensor([1.0 if "error" in res else 0.0], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        extra.update(res if "error" not in res else {"multi_rank_extras_error": res["error"]})
+        if float(bad.item()) > 0 and "error" not in res:
+            extra["multi_rank_extras_error"] = "failed on another rank"
     out["extra"] = extra
+    if rank == 0 and world > 1 and not a.no_cpu_baseline:
+        # (the other ranks wait in destroy_process_group below; the headline's timed region is long over)
+        try:
+            out["cpu_baseline"] = cpu_baseline(F, r, K, B, a.cpu_frames, a.tied)
+        except Exception as e:           # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(F, r, K, B, a.cpu_frames, a.tied)

@@ -85,6 +85,7 @@ SIGNATURES = {
     "drnmf_status_take_device": (_i32, [_vp, _vp, _vp]),
     "drnmf_reload_env": (_i32, []),
     "drnmf_persist_admitted": (_i32, [_vp]),
+    "drnmf_persist_admit_reason": (C.c_char_p, [_vp]),
     "drnmf_host_report_ring": (_i32, [_vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(_i32)]),
     "drnmf_ista_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "drnmf_ista_forward": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp,

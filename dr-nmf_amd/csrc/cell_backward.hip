@@ -1448,6 +1448,9 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     if (prof_ms) DRNMF_HIP(h, hipEventRecord(pev[1], stream));
 
     // ---- time-batched phase ----------------------------------------------------------------------
+    // (Round 5 ran these products in blocks of 256 / 512 frames on a side stream BESIDE the sequential pass --
+    // gemm_tn over row segments of every utterance, one set of split partials per layer -- and the headline
+    // step went from 1014 to 1091 / 1063 ms: profiles/r05_overlap_negative.txt, the patch beside it.)
     DRNMF_HIP(h, hipMemsetAsync(xpad, 0, (size_t)BT * W.Fp * 4, stream));
     DRNMF_HIP(h, hipMemcpy2DAsync(xpad, (size_t)W.Fp * 4, x, (size_t)F * 4, (size_t)F * 4,
                                   (size_t)BT, hipMemcpyDeviceToDevice, stream));

@@ -78,7 +78,10 @@ struct CellAArgs {
                              // the saved order (common.h tile_unpermute), for the weight gradients of
                              // the BPTT (saves its recomputation as a frame-parallel GEMM); else NULL
     int out_width, out_off, write_out;
-    unsigned* prog;          // cell_a launches started in this call (read by dict_prefetch_kernel), or NULL
+    const void* Dn_pf;       // fp16 mode: the NEXT layer's dictionary (the cell_b launch behind this one reads it),
+                             // pulled into the L2s by this launch's fifth wave; NULL: no prefetch
+    int pf_tiles;            // MFMA bin tiles of that cell_b launch (its workgroup (x, y) reads tile 8 y + x % 8)
+    int pf_sleep;            // the prefetching wave starts 8 * 64 * pf_sleep cycles into the launch
 };
 
 // G = operand slots (16-bin chunks in flight per wave, prefetch distance G-1).  RB = 16-row blocks per
@@ -105,7 +108,7 @@ struct CellAArgs {
 // r04j_rb4_sweep.txt)
 template <int G, int KS, int RB, bool IS_FIRST, bool IS_LAST, bool ALL_HIDDEN, bool HALF = false,
           bool LATE = false, bool QRED = false>
-__global__ void __launch_bounds__(64 * NW_A)
+__global__ void __launch_bounds__(64 * (NW_A + (HALF ? 1 : 0)))
 cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, int Fp_, int Np_,
               int numA_, int nchunks_, const CellAArgs a_in) {
     CellAArgs a = a_in;
@@ -135,13 +138,53 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     const int n0 = ab * ATOMS;
     const size_t pstride = (size_t)a.Bp * Fp;     // one r partial
 
+    // ---- fp16 mode: a FIFTH wave that only prefetches ------------------------------------------------
+    // The cell_b launch behind this one reads the next layer's dictionary for the first time -- with untied
+    // layers past the Infinity Cache (BASELINE configs[4]: 0.8 GB) an HBM miss per line, ~2.8 us to first
+    // data and ~3 TB/s under that flood.  Its workgroups with blockIdx.x % 8 = x read the bin tiles
+    // ft = x (mod 8), 16 bins x all atoms = Np/32 contiguous 1-KB blocks each, 2 MB per XCD out of a 4-MB L2;
+    // workgroups are dealt round-robin to the XCDs, so the workgroups of THIS launch with the same x sit on
+    // the same XCD and pull exactly that share through their L2 while the four working waves (whose own
+    // dictionary was left in the Infinity Cache by the previous cell_b) keep the matrix pipes.  The loads
+    // have no consumer (s_endpgm waits for them); this wave takes no part in anything else but the barrier.
+    // A separate prefetch kernel on a side stream, paced by a progress counter, LOST: 8.78 -> 9.05-12.7 us per
+    // launch (profiles/r05_prefetch_side_stream_negative.txt).
+    if (HALF && w == NW_A) {
+        for (int i = 0; i < a.pf_sleep; ++i) __builtin_amdgcn_s_sleep(8);      // (see make_a; DRNMF_PF_SLEEP)
+        if (!IS_LAST && a.Dn_pf != nullptr) {
+            const int x = blockIdx.x & 7;
+            const int nac32 = Np >> 5;
+            const int ntile = (a.pf_tiles - x + 7) >> 3;                 // bin tiles of this XCD's share
+            const int wg = (blockIdx.x >> 3) * gridDim.y + blockIdx.y;   // this workgroup among the XCD's
+            const int nwg = (gridDim.x >> 3) * gridDim.y;
+            // block b of the share = (tile b / nac32, column b % nac32), b = wg, wg + nwg, ...
+            int tj = 0, col = wg;
+            while (col >= nac32) { col -= nac32; ++tj; }
+            const int dj = nwg / nac32, dc = nwg - dj * nac32;
+            const char* base = (const char*)a.Dn_pf + (size_t)l * 16;
+            // (ONE destination register quad, tied through every load and the final wait: the compiler does
+            // not know the loads are asynchronous, and a quad it considered dead would be handed to the next
+            // address -- which the returning data then overwrites)
+            f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+            while (tj < ntile) {
+                const char* p = base + ((size_t)(x + 8 * tj) * nac32 + col) * 1024;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+                tj += dj;
+                col += dc;
+                if (col >= nac32) { col -= nac32; ++tj; }
+            }
+            __syncthreads();           // (the one barrier of the kernel: not held up by the loads)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
+            return;
+        }
+        __syncthreads();
+        return;
+    }
+
     int t = 0;
     if (IS_FIRST) {
         t = *a.t_rd;
-        if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-            *a.t_wr = t + a.t_wr_add;
-            if (a.prog) __hip_atomic_fetch_add(a.prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (a.t_wr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.t_wr = t + a.t_wr_add;
     }
     const float* rsrc = IS_FIRST ? a.rsrc + (size_t)t * pstride : a.rsrc;
     const int NAC = Np / 16, nft = Fp / 16, ac0 = ab * 2;
@@ -276,13 +319,6 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     float qv[QRED ? 1 : RB][MAX_TAIL][4];
     f32x2 dt[MAX_TAIL], dtn[MAX_TAIL];   // tail rows of this layer's and the next layer's dictionary
     auto load_epilogue_operands = [&]() {
-    // progress counter of the dictionary prefetch (dict_prefetch_kernel): compiled into the kernels of the
-    // shapes it serves only (fp16 operands; fp32 with more than 64 atom blocks) -- the headline
-    // instantiations are sensitive to every extra branch here.  The first layer counts below.
-    if constexpr ((HALF || QRED) && !IS_FIRST) {
-        if (a.prog && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)      // (no return value: nothing waits for it)
-            __hip_atomic_fetch_add(a.prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     ia = *(const f32x2*)(a.inv_alpha + n);
     bs = *(const f32x2*)(a.bias + n);
     if (!IS_FIRST && WRITE_OUT) {
@@ -304,7 +340,18 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             // layer, added in block order by 16 lanes + a fixed shuffle tree (deterministic)
             const float* rp = a.rs_part + (size_t)(t & 1) * a.numA * a.Bp + rg;
             float s = 0.f;
-            for (int b2 = (tid & 15); b2 < a.numA; b2 += 16) s += rp[(size_t)b2 * a.Bp];
+            // (eight loads in flight, added in index order: the plain loop is one dependent L2 round trip
+            // per term -- 16 of them at N = 8000, where this first-layer launch took 19 us against 8)
+            for (int b0 = (tid & 15); b0 < a.numA; b0 += 128) {
+                float v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b2 = b0 + 16 * u;
+                    v8[u] = rp[(size_t)(b2 < a.numA ? b2 : b0) * a.Bp];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (b0 + 16 * u < a.numA) ? v8[u] : 0.f;
+            }
             s = row16_sum(s);
             ps[rb] = s;
             if (ab_raw == 0 && (tid & 15) == 0) {
@@ -652,7 +699,7 @@ load_state_kernel(const float* __restrict__ init, float* __restrict__ state,
                   float* __restrict__ rs_part, int* tptr, int B, int N, int Np, int Bp, int numA) {
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wv;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { tptr[0] = 0; tptr[16] = 0; tptr[32] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { tptr[0] = 0; tptr[16] = 0; }
     if (b >= Bp) return;
     float s = 0.f;
     for (int n = l; n < Np; n += 64) {
@@ -717,7 +764,7 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
     __syncthreads();
     const float tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     for (int i = tid; i < 2 * numA * Bp; i += 256) rs_part[i] = (i < Bp) ? tot : 0.f;
-    if (tid == 0) { tptr[0] = 0; tptr[16] = 0; tptr[32] = 0; }
+    if (tid == 0) { tptr[0] = 0; tptr[16] = 0; }
 }
 
 // KL / beta cell: r = g(x_t, x^) on the packed [Bp][Fp] residual buffer, in place (x^ was left
@@ -746,58 +793,6 @@ resid_div_kernel(const float* __restrict__ xp, float* __restrict__ r, const int*
         else g = xv * powf(xe, beta - 2.f) - powf(xe, beta - 1.f);
     }
     r[i] = g;
-}
-
-// Dictionary prefetch for chains whose untied dictionaries exceed the 256-MB Infinity Cache (BASELINE
-// configs[4]: F = 1025, N = 8000, K = 50 -- 0.8 GB of fp16 dictionaries, every layer-step a first touch that
-// waits ~2.8 us for HBM).  A few workgroups on a side stream of the handle run AHEAD of the chain: step
-// s = t K + k uses stored layer s mod K; the kernel reads that layer's packing(s) -- the loads' only purpose
-// is the allocation in the memory-side cache -- once the chain's progress counter (cell_a launches started,
-// CellAArgs::prog) has come within `ahead` steps of s, and skips steps the chain has already passed.  The
-// chain never waits for it; it waits for the chain with a bounded poll and simply ends when the bound is
-// hit (a prefetch is a hint: no fault).  Workgroup b of gridDim.x streams the b-th slice of every layer.
-__global__ void __launch_bounds__(256)
-dict_prefetch_kernel(const char* base0, const char* base1, size_t layer_bytes, int n_layers,
-                     unsigned steps_total, const unsigned* prog, unsigned ahead, int nt) {
-    __shared__ unsigned sh_cur;
-    const int tid = threadIdx.x;
-    // whole 4-KB rows (256 lanes x 16 bytes) per workgroup
-    const size_t rows = (layer_bytes + 4095) / 4096;
-    const size_t r0 = rows * blockIdx.x / gridDim.x, r1 = rows * (blockIdx.x + 1) / gridDim.x;
-    for (unsigned s = 0; s < steps_total; ++s) {
-        if (tid == 0) {
-            unsigned cur = 0, spins = 0;
-            for (;;) {
-                cur = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur + ahead >= s) break;
-                __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1u << 20)) { cur = 0xffffffffu; break; }       // (~1 s without progress: give up)
-            }
-            sh_cur = cur;
-        }
-        __syncthreads();
-        const unsigned cur = sh_cur;
-        __syncthreads();
-        if (cur == 0xffffffffu) return;
-        if (cur > s) continue;                                // the chain is past this step already
-        const size_t lo = (size_t)(s % (unsigned)n_layers) * layer_bytes;
-        for (int which = 0; which < 2; ++which) {
-            const char* base = which ? base1 : base0;
-            if (!base) continue;
-            const char* p = base + lo;
-            for (size_t r = r0; r < r1; r += 8) {
-                f32x4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    size_t off = (r + u < r1 ? r + u : r1 - 1) * 4096 + (size_t)tid * 16;
-                    if (off + 16 > layer_bytes) off = layer_bytes - 16;
-                    if (nt) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v[u]) : "v"(p + off) : "memory");
-                    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(p + off) : "memory");
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-    }
 }
 
 template <int G, int KS, int RB, bool AH, bool HALF, bool LATE = false>
@@ -1141,6 +1136,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     // are reported by drnmf_check_status / drnmf_status_take_device only.)
     int rc = validate_cell_desc(h, d);
     if (rc) return rc;
+    if (!plan) ++h->call_seq;        // (a top-level call: the graphs it takes are pinned until it returns)
     if (d->divergence != DRNMF_DIV_ED)
         DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED,
                    "cell_forward is the reference's (Euclidean) cell; KL / beta: drnmf_cell_forward_ista");
@@ -1178,24 +1174,33 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         if (!h->fork_ev) DRNMF_HIP(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
         DRNMF_HIP(h, hipEventRecord(h->fork_ev, stream));
         const size_t width = (size_t)d->N * (d->return_all_hidden ? d->K : 1);
-        // every sub-batch may add two graphs to the cache: make the room once, up front, so that no
-        // insertion below retires an executable another sub-batch's plan still holds
-        {
-            const int32_t erc = graph_cache_make_room(h, stream, 24 - 2 * (size_t)W.split);
-            if (erc) return erc;
-        }
+        // (every sub-batch may take two graphs from the cache; entries taken by THIS call are pinned -- an
+        // insertion for a later sub-batch never retires an executable an earlier one's plan holds -- and
+        // cache hits cost nothing: room is made only when an entry is actually inserted)
         int32_t first_err = DRNMF_OK;
+        // (from here on a failing HIP call is RECORDED and the code falls through to the join loop: side
+        // streams may already be writing h_out / the workspace, and the caller's stream must not run ahead
+        // of them -- ADVICE r4)
+        auto note = [&](hipError_t e, const char* what) {
+            if (e == hipSuccess || first_err) return;
+            first_err = DRNMF_ERR_HIP;
+            snprintf(h->err, sizeof(h->err), "cell_forward (split): %s failed: %s", what, hipGetErrorString(e));
+        };
         FwdPlan plans[MAX_SPLIT];
         hipStream_t sts[MAX_SPLIT];
         int nsub = 0;
-        for (int sidx = 0; sidx < W.split; ++sidx) {
+        for (int sidx = 0; sidx < W.split && !first_err; ++sidx) {
             const int b0 = sidx * W.split_rows;
             if (b0 >= d->B) break;
             drnmf_cell_desc_t ds = *d;
             ds.B = (d->B - b0 < W.split_rows) ? d->B - b0 : W.split_rows;
             hipStream_t st = sidx == 0 ? stream : h->side_stream[sidx - 1];
             sts[sidx] = st;
-            if (sidx > 0) DRNMF_HIP(h, hipStreamWaitEvent(st, h->fork_ev, 0));
+            nsub = sidx + 1;
+            if (sidx > 0) {
+                note(hipStreamWaitEvent(st, h->fork_ev, 0), "hipStreamWaitEvent");
+                if (first_err) break;
+            }
             // prologue (input packing, initial state) enqueued; the frame graphs come back as a plan
             const int32_t src = cell_forward_impl(
                 h, &ds, x + (size_t)b0 * d->T * d->F, mask_value, params, log_h0, u0_diag, u0_off, uk_off,
@@ -1204,7 +1209,6 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 initial_state ? initial_state + (size_t)b0 * d->N : nullptr, nullptr, false, &plans[sidx]);
             if (src && !first_err) first_err = src;
             if (src) plans[sidx] = FwdPlan{};
-            nsub = sidx + 1;
         }
         // Round-robin over the sub-batches, one graph launch (a block of frames) each: a host that
         // enqueued one sub-batch's whole sequence first would fill the hardware queue with it (T = 2000:
@@ -1214,13 +1218,13 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
             int most = 0;
             for (int i = 0; i < nsub; ++i) most = plans[i].n_full > most ? plans[i].n_full : most;
             for (int c = 0; c < most && !first_err; ++c)
-                for (int i = 0; i < nsub; ++i)
-                    if (c < plans[i].n_full) DRNMF_HIP(h, hipGraphLaunch(plans[i].exec_n, sts[i]));
+                for (int i = 0; i < nsub && !first_err; ++i)
+                    if (c < plans[i].n_full) note(hipGraphLaunch(plans[i].exec_n, sts[i]), "hipGraphLaunch");
             most = 0;
             for (int i = 0; i < nsub; ++i) most = plans[i].n_rem > most ? plans[i].n_rem : most;
             for (int c = 0; c < most && !first_err; ++c)
-                for (int i = 0; i < nsub; ++i)
-                    if (c < plans[i].n_rem) DRNMF_HIP(h, hipGraphLaunch(plans[i].exec_1, sts[i]));
+                for (int i = 0; i < nsub && !first_err; ++i)
+                    if (c < plans[i].n_rem) note(hipGraphLaunch(plans[i].exec_1, sts[i]), "hipGraphLaunch");
         }
         for (int sidx = 0; sidx < nsub; ++sidx) {
             const int b0 = sidx * W.split_rows;
@@ -1233,11 +1237,13 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 hipLaunchKernelGGL(store_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
                                    (const float*)((char*)workspace + (size_t)sidx * W.split_bytes + Ws.off_state),
                                    final_state + (size_t)b0 * d->N, ds.B, d->N, Ws.Np);
+                note(hipGetLastError(), "store_state_kernel launch");
             }
             // (join also after a failed sub-call: the caller's stream must not run ahead of side work)
             if (sidx > 0) {
-                DRNMF_HIP(h, hipEventRecord(h->join_ev[sidx - 1], st));
-                DRNMF_HIP(h, hipStreamWaitEvent(stream, h->join_ev[sidx - 1], 0));
+                const hipError_t e1 = hipEventRecord(h->join_ev[sidx - 1], st);
+                note(e1, "hipEventRecord");
+                if (e1 == hipSuccess) note(hipStreamWaitEvent(stream, h->join_ev[sidx - 1], 0), "hipStreamWaitEvent");
             }
         }
         return first_err;
@@ -1290,7 +1296,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N, (uint64_t)d->K,
         (uint64_t)d->n_D, (uint64_t)d->return_all_hidden + 2 * (uint64_t)(d->operand_f16 != 0),
         (uint64_t)(uintptr_t)params,
-        (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)ablate};
+        (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)ablate,
+        // the layout choices baked into the nodes: a sub-batch of a split call and a direct call of the same
+        // B take different row blockings (workspace_layout's `need`), and the tuning variables move them too
+        (uint64_t)W.RB | ((uint64_t)W.RBa << 8) | ((uint64_t)W.KS << 16) | ((uint64_t)W.nch_ks << 24)};
     {
         uint32_t b0, b1, b2;
         memcpy(&b0, &u0_diag, 4); memcpy(&b1, &u0_off, 4); memcpy(&b2, &uk_off, 4);
@@ -1326,6 +1335,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         return (const float*)(pb + L.off_tail) + (d->n_D == 1 ? 0 : (size_t)k * MAX_TAIL * L.Np);
     };
 
+    // fp16 mode, untied layers: the cell_a launch ahead of a cell_b prefetches that cell_b's dictionary
+    // (cell_a_kernel's fifth wave; DRNMF_PF=0 switches it off: measurement aid)
+    const bool pf_on = half && d->n_D == K && K > 1 && !(tune_env("DRNMF_PF") && atoi(tune_env("DRNMF_PF")) == 0);
     auto make_a = [&](int k) {
         CellAArgs a;
         a.Dn = DnA_of(k);
@@ -1367,7 +1379,14 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.ablate = tune_env("DRNMF_ABLATE_A") ? atoi(tune_env("DRNMF_ABLATE_A")) : 0;
         a.Rsave = (W.off_rsave != 0 && k >= 1)
                       ? (float*)(ws + W.off_rsave) + (size_t)(k - 1) * d->B * d->T * W.Fp : nullptr;
-        a.prog = (unsigned*)(tA + 32);
+        // fp16 mode, a cell_b launch behind this one: its dictionary goes into the L2s meanwhile
+        a.Dn_pf = nullptr;
+        a.pf_tiles = nft;
+        // (the prefetching wave starts ~2 us into the launch: the working waves' first fetches are the
+        // latency-critical part.  Delay in units of 512 cycles, us per launch at the config-5 shape:
+        // 0 8.58-8.62, 2 8.58, 4 8.55, 8 8.47, 12 8.42, 16 8.54, 24 9.28, 32 10.2; no prefetch 8.82)
+        a.pf_sleep = tune_env("DRNMF_PF_SLEEP") ? atoi(tune_env("DRNMF_PF_SLEEP")) : 10;
+        if (pf_on && k + 1 < K) a.Dn_pf = DnB_of(k + 1);
         return a;
     };
     auto make_b = [&](int k) {   // between layer k and k+1
@@ -1411,7 +1430,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 DRNMF_HIP(h, mark((k > 0 && k < K - 1) ? 0 : 2));
                 DRNMF_HIP(h, hipLaunchKernel(pick_a_func(a.nchunks, W.KS, W.RBa, k == 0, k == K - 1,
                                                          d->return_all_hidden != 0, half, qred),
-                                             grid_a, dim3(64 * NW_A), kp, 0, stream));
+                                             grid_a, dim3(64 * (NW_A + (half ? 1 : 0))), kp, 0, stream));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     CellBParams kb(b);
@@ -1454,11 +1473,20 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     std::vector<uint64_t> gkey = key;
     gkey.push_back((uint64_t)fpg);
     GraphEntry* entry = nullptr;
-    for (auto& g : h->graphs)
-        if (g.key == gkey) { entry = &g; break; }
+    for (size_t gi = 0; gi < h->graphs.size(); ++gi)
+        if (h->graphs[gi].key == gkey) {
+            // (a hit moves to the back: eviction is least-recently-used)
+            if (gi + 1 != h->graphs.size()) {
+                GraphEntry hit = h->graphs[gi];
+                h->graphs.erase(h->graphs.begin() + (ptrdiff_t)gi);
+                h->graphs.push_back(hit);
+            }
+            entry = &h->graphs.back();
+            break;
+        }
     if (!entry) {
-        if (!plan) {   // bounded cache: the oldest entry is retired without synchronising (common.h)
-            const int32_t erc = graph_cache_make_room(h, stream, 24);   // (plan mode: the caller made room)
+        {   // bounded cache: the least recently used entry is retired without synchronising (params.hip)
+            const int32_t erc = graph_cache_make_room(h, stream, 24);
             if (erc) return erc;
         }
         GraphEntry ge;
@@ -1485,7 +1513,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                 CellAArgs a = make_a(k);
                 CellAParams ka_(a);
                 void** ka = ka_.p;
-                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(a.nchunks, W.KS, W.RBa, k == 0, k == K - 1, d->return_all_hidden != 0, half, qred), grid_a, 64 * NW_A, ka));
+                DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_a_func(a.nchunks, W.KS, W.RBa, k == 0, k == K - 1, d->return_all_hidden != 0, half, qred), grid_a, 64 * (NW_A + (half ? 1 : 0)), ka));
                 if (k < K - 1) {
                     CellBArgs b = make_b(k);
                     DRNMF_HIP(h, add(ablate ? (void*)&noop_kernel : pick_b_func(W.nch_ks, W.RB, half, qred), grid_b, 64 * NW_B, CellBParams(b).p));
@@ -1502,45 +1530,13 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         entry = &h->graphs.back();
     }
     entry->last_stream = stream;
+    entry->pin = h->call_seq;
     *out = entry->exec;
     return DRNMF_OK;
     };
     hipGraphExec_t exec_n = nullptr, exec_1 = nullptr;
     int32_t grc = get_graph(fpg_max, &exec_n);
     if (grc) return grc;
-    // ---- dictionary prefetch on a side stream (dict_prefetch_kernel) -----------------------------
-    // Untied dictionaries past the Infinity Cache, kernels that count their launches (fp16 operands, or
-    // fp32 with more than 64 atom blocks), a whole (unsplit) call.  DRNMF_PREFETCH=0|1 forces the choice,
-    // DRNMF_PF_WGS / DRNMF_PF_AHEAD / DRNMF_PF_NT its geometry (measurement aids).
-    bool prefetch = false;
-    if (!plan && K > 1 && d->n_D == K && (half || qred)) {
-        const size_t per_layer = dstride * (half ? 1 : 2);
-        prefetch = per_layer * (size_t)K > ((size_t)192 << 20);
-        if (const char* e = tune_env("DRNMF_PREFETCH")) prefetch = atoi(e) != 0;
-    }
-    if (prefetch) {
-        if (!h->side_stream[0]) DRNMF_HIP(h, hipStreamCreateWithFlags(&h->side_stream[0], hipStreamNonBlocking));
-        if (!h->join_ev[0]) DRNMF_HIP(h, hipEventCreateWithFlags(&h->join_ev[0], hipEventDisableTiming));
-        if (!h->fork_ev) DRNMF_HIP(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-        // (behind the prologue: the progress counter is zero)
-        DRNMF_HIP(h, hipEventRecord(h->fork_ev, stream));
-        DRNMF_HIP(h, hipStreamWaitEvent(h->side_stream[0], h->fork_ev, 0));
-        int wgs = 64, ahead = 2, nt = 0;
-        if (const char* e = tune_env("DRNMF_PF_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) wgs = v; }
-        if (const char* e = tune_env("DRNMF_PF_AHEAD")) { const int v = atoi(e); if (v >= 0 && v <= 16) ahead = v; }
-        if (const char* e = tune_env("DRNMF_PF_NT")) nt = atoi(e) != 0;
-        hipLaunchKernelGGL(dict_prefetch_kernel, dim3((unsigned)wgs), dim3(256), 0, h->side_stream[0],
-                           Dn_base, half ? (const char*)nullptr : pb + L.off_dnA, dstride, K,
-                           (unsigned)d->T * (unsigned)K, (const unsigned*)(tA + 32), (unsigned)ahead, nt);
-        DRNMF_HIP(h, hipGetLastError());
-    }
-    // (the caller's stream takes the prefetch kernel's end in: it exits with the chain's last step)
-    auto join_prefetch = [&]() -> int32_t {
-        if (!prefetch) return DRNMF_OK;
-        DRNMF_HIP(h, hipEventRecord(h->join_ev[0], h->side_stream[0]));
-        DRNMF_HIP(h, hipStreamWaitEvent(stream, h->join_ev[0], 0));
-        return DRNMF_OK;
-    };
     if (plan) {
         plan->exec_n = exec_n;
         plan->fpg = fpg_max;
@@ -1554,20 +1550,12 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         return DRNMF_OK;
     }
     int t = 0;
-    int32_t lrc = DRNMF_OK;
-    for (; t + fpg_max <= d->T && !lrc; t += fpg_max)
-        if (hipGraphLaunch(exec_n, stream) != hipSuccess) lrc = DRNMF_ERR_HIP;
-    if (t < d->T && !lrc) {
-        lrc = get_graph(1, &exec_1);     // (may evict; exec_n is not used again)
-        for (; t < d->T && !lrc; ++t)
-            if (hipGraphLaunch(exec_1, stream) != hipSuccess) lrc = DRNMF_ERR_HIP;
+    for (; t + fpg_max <= d->T; t += fpg_max) DRNMF_HIP(h, hipGraphLaunch(exec_n, stream));
+    if (t < d->T) {
+        grc = get_graph(1, &exec_1);     // (may evict; exec_n is not used again)
+        if (grc) return grc;
+        for (; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(exec_1, stream));
     }
-    // (also after a failed launch: the prefetch kernel gives up by itself within its poll bound, and the
-    // caller's stream must not run ahead of it)
-    const int32_t jrc = join_prefetch();
-    if (lrc == DRNMF_ERR_HIP) DRNMF_FAIL(h, DRNMF_ERR_HIP, "cell_forward: hipGraphLaunch failed (%s)", hipGetErrorString(hipGetLastError()));
-    if (lrc) return lrc;
-    if (jrc) return jrc;
     return store_final(W);
 }
 

@@ -60,6 +60,9 @@ struct CellBArgs {
 // The arguments are passed as individual scalars (not as one struct) so that the command
 // processor can preload them into SGPRs (-amdgpu-kernarg-preload-count, build.py): the kernel
 // then starts without a dependent scalar load from the kernarg segment.
+// (Two 16-bin column blocks per workgroup -- 0.25 instead of 0.375 KB of operands per MFMA at RB = 2 -- were built
+// and measured in round 5 for the large batches and LOST at every size: B = 250 / 512 / 1024 680 -> 613, 846 -> 833,
+// 981 -> 967 k frames/s (116 instead of 80 VGPRs, half the workgroups): profiles/r05_cb2_sweep_negative.txt.)
 template <int GB, int RB = 1, int NW = 8, bool HALF = false, bool QRED = false>
 __global__ void __launch_bounds__(64 * NW)
 cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rpart, int Fp_,
@@ -365,6 +368,13 @@ static inline bool gram_wanted(const drnmf_cell_desc_t* d) {
     return want;
 }
 
+// The consumer of cell_b's odd-bin sums (cell_a / bwd_a) and cell_b itself must agree on who adds
+// the partials: cell_b when there are more than 64 atom blocks and enough workgroups to cover the
+// 16*RB rows of a tile group.
+static inline bool qred_wanted(int numA, int ntail, int nft, int KS, int RB) {
+    return ntail > 0 && numA > 64 && nft * KS >= 16 * RB;
+}
+
 struct Workspace {
     size_t off_xp, off_valid, off_seen, off_psum_all, off_rpart, off_h0, off_h1, off_state, off_rs,
         off_psum, off_t, total;
@@ -540,13 +550,6 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
         }
     }
     return W;
-}
-
-// The consumer of cell_b's odd-bin sums (cell_a / bwd_a) and cell_b itself must agree on who adds
-// the partials: cell_b when there are more than 64 atom blocks and enough workgroups to cover the
-// 16*RB rows of a tile group.
-static inline bool qred_wanted(int numA, int ntail, int nft, int KS, int RB) {
-    return ntail > 0 && numA > 64 && nft * KS >= 16 * RB;
 }
 
 template <int RB, bool HALF, bool QRED>

@@ -140,6 +140,8 @@ struct GraphEntry {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the most recent replay (eviction waits on it)
+    uint64_t pin = 0;                    // drnmf_handle_s::call_seq of the call that last took it: never
+                                         // evicted by that same call (its sub-batches' plans hold the exec)
 };
 
 struct drnmf_handle_s {
@@ -150,7 +152,8 @@ struct drnmf_handle_s {
     std::recursive_mutex mu;
     int device = 0;
     char err[512] = {0};
-    std::vector<GraphEntry> graphs;
+    std::vector<GraphEntry> graphs;      // least recently used first
+    uint64_t call_seq = 0;               // top-level forward calls so far (GraphEntry::pin)
     // graphs dropped from the bounded cache: destroyed once the work that was enqueued when they
     // were retired has completed (graph_cache_insert, no device-wide synchronisation)
     struct Retired { GraphEntry g; hipEvent_t done; };
@@ -180,6 +183,7 @@ struct drnmf_handle_s {
     // process) runs the launch-per-layer-step graphs, which compute the same bits.  The kernel drops the
     // lock when its owner dies.  -1: not the owner.
     int persist_lock_fd = -1;
+    char persist_reason[256] = {0};      // why this handle is (not) admitted to the persistent chains
     // side streams + fork / join events of the sub-batch split of large inference batches
     // (cell_shared.h Workspace::split), created at first use, destroyed with the handle
     hipStream_t side_stream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

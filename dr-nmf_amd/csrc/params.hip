@@ -4,7 +4,9 @@
 #include "common.h"
 #include "gemm_tn.h"
 
+#include <errno.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <sys/file.h>
 #include <unistd.h>
 
@@ -20,7 +22,7 @@ const char* const kTuneNames[] = {
     "DRNMF_ABLATE", "DRNMF_ABLATE_A", "DRNMF_ABLATE_B", "DRNMF_CP_FULL", "DRNMF_DENSE_NW", "DRNMF_FPG",
     "DRNMF_G8", "DRNMF_GRAM", "DRNMF_KS", "DRNMF_LATE", "DRNMF_NO_ALLB", "DRNMF_NO_GRAPH",
     "DRNMF_PERSIST", "DRNMF_PERSIST_FAULT", "DRNMF_RB", "DRNMF_RBA", "DRNMF_BIG", "DRNMF_SPLIT",
-    "DRNMF_THIN", "DRNMF_PREFETCH", "DRNMF_PF_WGS", "DRNMF_PF_AHEAD", "DRNMF_PF_NT"};
+    "DRNMF_THIN", "DRNMF_PF", "DRNMF_PF_SLEEP"};
 std::mutex g_tune_mu;
 // (values are never erased or overwritten in place: a pointer handed out stays valid for the
 // process lifetime; a reload appends a new generation)
@@ -100,9 +102,27 @@ extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
         snprintf(path, sizeof(path), "/tmp/drnmf_persist_%s.lock", bus);
         const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
         if (fd >= 0) {
-            if (flock(fd, LOCK_EX | LOCK_NB) == 0) h->persist_lock_fd = fd;
-            else close(fd);
+            // (world-writable whatever the creator's umask: the next user of the box must be able to open it)
+            (void)fchmod(fd, 0666);
+            if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
+                h->persist_lock_fd = fd;
+                snprintf(h->persist_reason, sizeof(h->persist_reason), "admitted (holds %s)", path);
+            } else {
+                snprintf(h->persist_reason, sizeof(h->persist_reason),
+                         "not admitted: %s is held by another handle / process on this GPU (%s)", path,
+                         strerror(errno));
+                close(fd);
+            }
+        } else {
+            snprintf(h->persist_reason, sizeof(h->persist_reason), "not admitted: open(%s) failed: %s", path,
+                     strerror(errno));
         }
+        if (h->persist_lock_fd >= 0 && !h->persist_flag)
+            snprintf(h->persist_reason, sizeof(h->persist_reason),
+                     "not admitted: no host-mapped fault word (hipHostMalloc failed)");
+        else if (h->persist_lock_fd >= 0 && h->persist_per_cu < 1)
+            snprintf(h->persist_reason, sizeof(h->persist_reason),
+                     "not admitted: the persistent kernels do not fit a CU of this device / partition");
     }
     *out = h;
     return DRNMF_OK;
@@ -123,6 +143,11 @@ extern "C" int32_t drnmf_persist_admitted(drnmf_handle_t h) {
     DRNMF_LOCK(h);
     if (!h) return DRNMF_ERR_INVALID_ARG;
     return (h->persist_lock_fd >= 0 && h->persist_flag != nullptr && h->persist_per_cu >= 1) ? 1 : 0;
+}
+
+extern "C" const char* drnmf_persist_admit_reason(drnmf_handle_t h) {
+    if (!h) return "no handle";
+    return h->persist_reason[0] ? h->persist_reason : "not admitted: a handle without a device";
 }
 
 // A small ring of 4-float slots in host-mapped, coherent memory that kernels may write (the report of
@@ -237,9 +262,14 @@ int32_t graph_cache_make_room(drnmf_handle_t h, hipStream_t stream, size_t max_e
     }
     (void)hipGetLastError();          // hipErrorNotReady of the query is not an error
     while (h->graphs.size() >= max_entries) {
+        // the least recently used entry that the CURRENT call does not hold (a split call's sub-batches
+        // each hold up to two executables until their launches are enqueued); all held: grow instead
+        size_t victim = 0;
+        while (victim < h->graphs.size() && h->graphs[victim].pin == h->call_seq && h->call_seq != 0) ++victim;
+        if (victim == h->graphs.size()) break;
         drnmf_handle_s::Retired r;
-        r.g = h->graphs.front();
-        h->graphs.erase(h->graphs.begin());
+        r.g = h->graphs[victim];
+        h->graphs.erase(h->graphs.begin() + (ptrdiff_t)victim);
         DRNMF_HIP(h, hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
         // the evicted executable was last replayed on r.g.last_stream (this call's stream when it
         // never ran): everything enqueued there so far precedes the event

@@ -805,10 +805,11 @@ class DeviceLoss(object):
     that launch and reads the slot.  Behaves like a number wherever one is needed (float(), arithmetic,
     comparisons, formatting); a step whose persistent chain timed out raises here -- on every rank of a
     data-parallel group at the same step, because the fault word is part of the all-reduced buffer."""
-    __slots__ = ('_event', '_slot', '_value', '_device', '_error', '__weakref__')
+    __slots__ = ('_event', '_slot', '_value', '_device', '_error', '_on_fault', '__weakref__')
 
-    def __init__(self, event, slot, device):
+    def __init__(self, event, slot, device, on_fault=None):
         self._event, self._slot, self._value, self._device, self._error = event, slot, None, device, None
+        self._on_fault = on_fault        # called ONCE when the report says the step was skipped
 
     def ready(self):
         return self._value is not None or self._event.query()
@@ -823,6 +824,9 @@ class DeviceLoss(object):
             self._slot = None                # (the ring slot may be reused from here on)
             if fault != 0.0:
                 self._value = float('nan')
+                if self._on_fault is not None:
+                    self._on_fault()
+                    self._on_fault = None
                 self._error = _capi.DrnmfError(
                     'train_on_batch: a persistent small-shape chain of this step timed out on at least '
                     'one rank (DRNMF_ERR_TIMEOUT): the step was SKIPPED on every rank (weights and Adam '
@@ -1169,6 +1173,7 @@ class UnfoldedSNMFModel(object):
         BPTT, recorded on the current stream without synchronising."""
         cell = self.cell
         N, K = cell.output_dim, cell.K_layers
+        self._drop_stale_fault()
         pe = getattr(self, 'phase_events', None)
 
         def mark(name, which):
@@ -1195,6 +1200,17 @@ class UnfoldedSNMFModel(object):
         self._collect_grads(g)
         self._set_scalars(x, live)
         return self._flat
+
+    def _drop_stale_fault(self):
+        """Stream-ordered read-and-clear of the handle's fault word into a scratch, at the START of a
+        training / test / validation step: a fault raised by an EARLIER asynchronous call on this device
+        (model.forward, cell.call, ops.cell_forward -- whose caller is told by ops.check_status after its own
+        synchronisation, or not at all) must not be charged to this step, which would then be skipped, or
+        raised, on every rank.  The count of dropped words stays readable in `self._stale_faults`."""
+        sf = getattr(self, '_stale_faults', None)
+        if sf is None or sf.device != torch.device(self.cell.device):
+            sf = self._stale_faults = torch.zeros(1, dtype=torch.float32, device=self.cell.device)
+        ops.status_take(sf)
 
     def _set_scalars(self, x, live=True):
         # tail of the flat buffer: [sum w*mse, count] were written by the loss head (_grad_targets), then
@@ -1293,7 +1309,12 @@ class UnfoldedSNMFModel(object):
                            report=base + 16 * slot)
         ev = torch.cuda.Event()
         ev.record()
-        loss = DeviceLoss(ev, ring[slot], self.cell.device)
+        # (a step the device skipped -- fault word set -- is not an iteration: the count is taken back when
+        # its report is read, at most PENDING_STEPS steps later; the steps enqueued in between ran with a
+        # bias correction one step ahead, the count is right again from then on)
+        def uncount(o=o):
+            o['iterations'] = max(0, o['iterations'] - 1)
+        loss = DeviceLoss(ev, ring[slot], self.cell.device, on_fault=uncount)
         register(loss)
         o['iterations'] = t
         # the prepared parameter block is stale; the (u0_diag, u0_off, uk_off) scalars are derived
@@ -1341,6 +1362,7 @@ class UnfoldedSNMFModel(object):
         w = tt(sample_weight) if sample_weight is not None else \
             torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
         s3 = torch.empty(4, dtype=torch.float32, device=dev)
+        self._drop_stale_fault()
         s3[:2].copy_(ops.loss_forward(y, w, x_raw=x, mask=self.forward(x)))
         s3[2:3].fill_(float(x.shape[0] * x.shape[1]))      # (fill_: no blocking scalar copy)
         s3[3:].fill_(0.0)
@@ -1487,6 +1509,7 @@ class UnfoldedSNMFModel(object):
         wv = validation_data[2] if len(validation_data) > 2 else None
         nv = xv.shape[0]
         s4 = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._drop_stale_fault()
         for lo in range(0, nv, int(batch_size)):
             b = np.arange(lo, min(nv, lo + int(batch_size)))
             xb, yb = tt(take(xv, b)), tt(take(yv, b))
@@ -1569,11 +1592,14 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
 
     def predict_on_batch(self, x):
         xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.cell.device)
-        return [o.cpu().numpy() for o in self.forward(xt)]
+        out = [o.cpu().numpy() for o in self.forward(xt)]
+        ops.check_status(self.cell.device)      # (the copies synchronised: a chain that timed out raises HERE)
+        return out
 
     def loss_and_grads(self, x, y, sample_weight, live=True):
         cell = self.cell
         N, K = cell.output_dim, cell.K_layers
+        self._drop_stale_fault()
         hall = cell.forward_train(x, mask_value=self.mask_value)
         h_off = (K - 1) * N
         _, A, Bn = ops.head_forward(hall, self.clean.kernel, self.noise.kernel, want_ab=True,
@@ -1602,6 +1628,7 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
         sw = self._first(sample_weight)
         w = tt(sw) if sw is not None else torch.ones(x.shape[:2], dtype=torch.float32, device=dev)
         s3 = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._drop_stale_fault()
         s3[:2].copy_(self._validation_sums(x, y, w))
         ops.status_take(s3[2:])
         dp.allreduce_sum_(s3)

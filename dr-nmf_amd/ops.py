@@ -597,6 +597,12 @@ def persist_admitted(device):
     return int(L.drnmf_persist_admitted(_capi.handle(_dev_of(device)))) == 1
 
 
+def persist_admit_reason(device):
+    """Why this process's handle on `device` is (not) admitted to the persistent chains (a sentence)."""
+    L = _capi.lib()
+    return L.drnmf_persist_admit_reason(_capi.handle(_dev_of(device))).decode()
+
+
 def status_take(dst):
     """Stream-ordered: adds 1.0 to the one-element device tensor `dst` if the handle's fault word is
     raised, and clears it (no synchronisation)."""

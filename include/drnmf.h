@@ -15,7 +15,11 @@
  *    synchronises the device (exceptions, named where they are declared: drnmf_cell_profile, and
  *    drnmf_comm_init, which is a rendezvous), and returns a status (0 = OK, <0 = error; text via
  *    drnmf_last_error).  Nothing throws or aborts across the ABI;
- *  - all tensors are float32, dense, row-major ("C order") with the shapes given.
+ *  - all tensors are float32, dense, row-major ("C order") with the shapes given;
+ *  - threads: every entry point that takes a handle holds that handle's mutex while it validates and
+ *    enqueues (never across a wait for the device, except in the two calls that synchronise by
+ *    definition): calls of several host threads on ONE handle are serialised, handles are independent.
+ *    drnmf_last_error(h) is the text of the most recent failing call on h, from any thread.
  */
 #ifndef DRNMF_H
 #define DRNMF_H
@@ -99,6 +103,10 @@ int32_t drnmf_status_take_device(drnmf_handle_t h, float* dst_device, void* stre
  * the device; the first handle that takes an exclusive flock on /tmp/drnmf_persist_<pci bus id>.lock
  * (at drnmf_create, held until drnmf_destroy / process exit) is the one admitted. */
 int32_t drnmf_persist_admitted(drnmf_handle_t h);
+/* Why (not): a static-lifetime, human-readable sentence owned by the handle ("admitted", "lock file
+ * ... is held by another process", "open(...) failed: Permission denied", ...).  Never NULL for a
+ * valid handle. */
+const char* drnmf_persist_admit_reason(drnmf_handle_t h);
 /* A ring of `*slots` 4-float slots in host-mapped, coherent memory owned by the handle: a valid
  * DEVICE pointer for the `report4` argument of drnmf_adam_step_flat and readable by the host once an
  * event recorded behind that launch has completed (no copy, no stream synchronisation). */

@@ -17,7 +17,7 @@ fn_t drnmf_all_exports[] = {
     REF(drnmf_snmf_cost_head_backward), REF(drnmf_cell_backward_workspace_bytes),
     REF(drnmf_cell_backward), REF(drnmf_cell_backward_ista), REF(drnmf_adam_step), REF(drnmf_sumsq),
     REF(drnmf_adam_step_flat), REF(drnmf_check_status), REF(drnmf_status_take_device),
-    REF(drnmf_host_report_ring), REF(drnmf_reload_env), REF(drnmf_create_unbound), REF(drnmf_persist_admitted),
+    REF(drnmf_host_report_ring), REF(drnmf_reload_env), REF(drnmf_create_unbound), REF(drnmf_persist_admitted), REF(drnmf_persist_admit_reason),
     REF(drnmf_ista_workspace_bytes), REF(drnmf_ista_forward), REF(drnmf_mu_workspace_bytes),
     REF(drnmf_mu_forward), REF(drnmf_snmf_train_workspace_bytes), REF(drnmf_snmf_train_init),
     REF(drnmf_snmf_train_step), REF(drnmf_stft_frames), REF(drnmf_stft_mag), REF(drnmf_stft),

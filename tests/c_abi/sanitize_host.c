@@ -8,6 +8,7 @@
  * with arguments its own checks must refuse.  Exit code 0 = every expectation held and no sanitizer
  * report was printed (a report aborts the process: no-recover build, halt_on_error). */
 #define _POSIX_C_SOURCE 200112L
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -192,12 +193,52 @@ static void refused_calls(drnmf_handle_t h) {
     /* fault word / report ring on a handle without host-mapped memory */
     CHECK(drnmf_check_status(h) == DRNMF_OK);
     CHECK(drnmf_persist_admitted(h) == 0 && drnmf_persist_admitted(NULL) < 0);
+    CHECK(drnmf_persist_admit_reason(h)[0] != 0 && drnmf_persist_admit_reason(NULL)[0] != 0);
     CHECK(drnmf_status_take_device(h, &f, NULL) == DRNMF_OK);    /* no fault word: nothing is launched */
     REFUSED(h, drnmf_status_take_device(h, NULL, NULL));
     float* ring = NULL;
     int32_t slots = 0;
     REFUSED(h, drnmf_host_report_ring(h, &ring, &slots));
     REFUSED(h, drnmf_host_report_ring(h, NULL, NULL));
+}
+
+/* Threads (include/drnmf.h, "threads"): every handle-taking entry point serialises on the handle's mutex.
+ * Two threads on two handles must be independent; two threads hammering ONE handle with calls that fail (each
+ * writes the handle's error string) must neither corrupt memory nor deadlock.  Only return codes are looked
+ * at here -- drnmf_last_error(h) of a handle another thread is failing calls on is that thread's text. */
+typedef struct { drnmf_handle_t h; int iters; int bad; } thread_arg_t;
+static void* thread_body(void* p) {
+    thread_arg_t* a = (thread_arg_t*)p;
+    for (int i = 0; i < a->iters; ++i) {
+        drnmf_cell_desc_t d = cell_desc(4 + i % 5, 7, 21, 34, 3, 1, 0, 0, 0);
+        d.K = (i & 1) ? 0 : 3;                                  /* every other descriptor is invalid */
+        float dummy;
+        const int32_t rc = drnmf_cell_forward(a->h, &d, &dummy, -1.f, NULL, &dummy, 1.f, 0.f, 0.f, &dummy,
+                                              NULL, 0, NULL);
+        if (rc >= 0) a->bad++;                                  /* (NULL params / workspace: always refused) */
+        int32_t rank = -1, world = -1;
+        if (drnmf_comm_info(a->h, &rank, &world) != DRNMF_OK || world != 1) a->bad++;
+        if (drnmf_persist_admitted(a->h) != 0) a->bad++;
+        if (drnmf_check_status(a->h) != DRNMF_OK) a->bad++;
+    }
+    return NULL;
+}
+static void threads(void) {
+    drnmf_handle_t h1 = NULL, h2 = NULL;
+    CHECK(drnmf_create_unbound(&h1) == DRNMF_OK && drnmf_create_unbound(&h2) == DRNMF_OK);
+    pthread_t t[4];
+    thread_arg_t a[4] = {{h1, 2000, 0}, {h2, 2000, 0}, {h1, 2000, 0}, {h1, 2000, 0}};
+    /* two handles, one thread each */
+    CHECK(pthread_create(&t[0], NULL, thread_body, &a[0]) == 0);
+    CHECK(pthread_create(&t[1], NULL, thread_body, &a[1]) == 0);
+    pthread_join(t[0], NULL);
+    pthread_join(t[1], NULL);
+    /* three threads on ONE handle */
+    for (int i = 0; i < 3; ++i) a[i].h = h1;
+    for (int i = 0; i < 3; ++i) CHECK(pthread_create(&t[i], NULL, thread_body, &a[i]) == 0);
+    for (int i = 0; i < 3; ++i) pthread_join(t[i], NULL);
+    for (int i = 0; i < 4; ++i) CHECK(a[i].bad == 0);
+    CHECK(drnmf_destroy(h1) == DRNMF_OK && drnmf_destroy(h2) == DRNMF_OK);
 }
 
 int main(void) {
@@ -224,6 +265,7 @@ int main(void) {
     }
     CHECK(drnmf_reload_env() == DRNMF_OK);
     CHECK(drnmf_destroy(h) == DRNMF_OK);
+    threads();
     printf("sanitize_host: %d checks, %d failed\n", g_calls, g_fail);
     return g_fail ? 1 : 0;
 }

@@ -53,20 +53,24 @@ def _setup(B, T, F, r, K, untied, untie_alph=False, square=False, seed=5, masked
     return model, P, wmask
 
 
-def _autograd(model, P, wmask, K, square, snmf_cost_l1_weight=None, divergence="ed", beta=1.5):
+def _autograd(model, P, wmask, K, square, snmf_cost_l1_weight=None, divergence="ed", beta=1.5,
+              dtype=torch.float64):
+    """torch-CPU autograd of the oracle restatement (oracle/drnmf_torch_ref.py).  dtype=torch.float32: the
+    same arithmetic precision as the GPU path, on the host -- what fp32 itself costs against the fp64
+    reference at a given shape (tests/test_gpu_fullsize.py)."""
     names = ["log_h0"] + list(model.cell._alt.keys()) + ["kc", "kn"]
-    wd = {n: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    wd = {n: torch.tensor(a, dtype=dtype, requires_grad=True)
           for n, a in zip(names, model.get_weights())}
     alt = {k: wd[k] for k in model.cell._alt.keys()}
-    x = torch.tensor(P["X"], dtype=torch.float64)
-    y = torch.tensor(P["X"] if snmf_cost_l1_weight is not None else P["Y"], dtype=torch.float64)
-    w = torch.tensor(wmask, dtype=torch.float64)
+    x = torch.tensor(P["X"], dtype=dtype)
+    y = torch.tensor(P["X"] if snmf_cost_l1_weight is not None else P["Y"], dtype=dtype)
+    w = torch.tensor(wmask, dtype=dtype)
     loss, mask, hs = TR.model_loss(x, y, w, alt, model.cell.maps_from_alt.labels_per_k, K,
                                    wd["log_h0"], wd["kc"], wd["kn"], square=square,
                                    normalise=False, snmf_cost_l1_weight=snmf_cost_l1_weight,
                                    divergence=divergence, beta=beta)
     loss.backward()
-    return float(loss.detach()), {n: (t.grad.numpy() if t.grad is not None else None)
+    return float(loss.detach()), {n: (t.grad.double().numpy() if t.grad is not None else None)
                          for n, t in wd.items()}, float((w != 0).sum())
 
 

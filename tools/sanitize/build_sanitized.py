@@ -26,10 +26,11 @@ ASAN_LIB = os.path.join(ASAN_DIR, "libdrnmf_asan.so")
 ASAN_FLAGS = ARCH + ["-O1", "-g", "-std=c++17", "-fPIC", "-Wno-unused-function",
                      "-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer",
                      "-Xarch_host", "-fno-sanitize-recover=undefined",
-                     "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+                     "-mllvm", "-amdgpu-kernarg-preload-count=16",
+                     "-mllvm", "-pragma-unroll-threshold=262144"]
 
 
-DRIVER_FLAGS = ["-std=c99", "-Wall", "-Werror", "-g", "-fsanitize=address,undefined",
+DRIVER_FLAGS = ["-std=c99", "-Wall", "-Werror", "-g", "-pthread", "-fsanitize=address,undefined",
                 "-fno-sanitize-recover=undefined", "-shared-libsan"]
 RUN_ENV = {"ASAN_OPTIONS": "halt_on_error=1:detect_leaks=0:abort_on_error=0",
            "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}
