@@ -121,8 +121,8 @@ int32_t drnmf_reload_env(void);
  *   log_D    [n_D][F][N]       log_alph [n_alph][alph_len]      log_lam1 [n_lam]
  * writes the prepared block `params` (drnmf_params_bytes; opaque, 256-byte aligned): per stored
  * layer the unit-L2-column dictionary exp(log_D)/||.||_2, zero-padded to [Fp][Np] and stored in the
- * tile-packed operand orders of the two cell kernels (two fp32 copies, or two fp16 copies with
- * operand_f16), its column norms, the rows of the 1-2 odd STFT bins, and per layer 1/alpha[n] and
+ * tile-packed operand orders of the two cell kernels (two fp32 copies; with operand_f16 ONE fp16
+ * copy that both kernels read, beside the fp32 copies of the mixed-precision BPTT), its column norms, the rows of the 1-2 odd STFT bins, and per layer 1/alpha[n] and
  * b[n] = -lam/alpha[n].  Must be re-run after every weight update, with the same descriptor
  * fields F, N, K, n_*, operand_f16 as the calls that consume it. */
 size_t drnmf_params_bytes(const drnmf_cell_desc_t* d);

@@ -58,8 +58,9 @@ DRNMF_BENCH_BACKEND=gloo DRNMF_BENCH_DEVICE=0 DRNMF_DP_BACKEND=torch timeout 900
     --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 "$B" --gpus 2 --frames 400 \
     --steps 2 --warmup 1 --no-extras --no-cpu-baseline > "$OUT/n2_gloo_one_gpu.json" 2> "$OUT/n2_gloo_one_gpu.err"
 # ... and EIGHT ranks on the one device through bench.py's own spawn_ranks (build lock, rendezvous, rank-0 JSON)
-( cd "$ROOT" && DRNMF_BENCH_BACKEND=gloo DRNMF_BENCH_DEVICE=0 DRNMF_DP_BACKEND=torch timeout 900 python3 bench.py --gpus 8 --batch 4 \
-    --frames 8 --steps 2 --warmup 1 --no-extras --no-cpu-baseline 2> "$OUT/n8_gloo_one_gpu.err" | tail -1 > "$OUT/n8_gloo_one_gpu.json" )
+# (round 5: with the multi-rank extras -- configs[3] data-parallel training, configs[4] replicas -- at toy shapes, and rank 0's CPU baseline)
+( cd "$ROOT" && DRNMF_BENCH_TINY=1 DRNMF_BENCH_BACKEND=gloo DRNMF_BENCH_DEVICE=0 DRNMF_DP_BACKEND=torch timeout 900 python3 bench.py --gpus 8 --batch 4 \
+    --frames 8 --steps 2 --warmup 1 2> "$OUT/n8_gloo_one_gpu.err" | tail -1 > "$OUT/n8_gloo_one_gpu.json" )
 # 5. PMC passes, 20 frames of the headline forward (cell + head only)
 SMALL="--forward-only --frames 20 --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch" -o p -- python3 "$B" $SMALL \
@@ -80,6 +81,18 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_sq_b250" -o p -- python3 "$B" $SLAB \
     > /dev/null 2> "$OUT/pmc_sq_b250.err"
 python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_b250_summary.json" "$OUT/pmc_fetch_b250" "$OUT/pmc_write_b250" "$OUT/pmc_sq_b250"
+# 5c. config 5 (F=1025, N=8000, K=50 untied, B=64, fp16 operands), 8 frames: L2-side traffic of the two cell kernels with
+#     and without cell_a's prefetching wave (FETCH_SIZE counts Infinity-Cache hits too: it shows how often a layer's
+#     dictionary CROSSES the fabric, not where from)
+for pf in 1 0; do
+  export DRNMF_PF=$pf
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_c5_fetch_pf$pf" -o p -- python3 "$ROOT/tools/profile_shape.py" 64 8 1025 4000 50 f16 \
+      > /dev/null 2> "$OUT/pmc_c5_fetch_pf$pf.err"
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d "$OUT/pmc_c5_write_pf$pf" -o p -- python3 "$ROOT/tools/profile_shape.py" 64 8 1025 4000 50 f16 \
+      > /dev/null 2> "$OUT/pmc_c5_write_pf$pf.err"
+  python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_c5_pf${pf}_summary.json" "$OUT/pmc_c5_fetch_pf$pf" "$OUT/pmc_c5_write_pf$pf"
+done
+unset DRNMF_PF
 # 6. the persistent chains of the shipped r = 100 training step: wave-cycle split and matrix-pipe time
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_r100" -o p -- python3 "$ROOT/tools/train_profile.py" 32 500 257 100 5 3 \
