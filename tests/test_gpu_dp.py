@@ -404,6 +404,9 @@ def test_persistent_timeout_is_reported_not_swallowed(dev, monkeypatch):
     from drnmf_amd import _capi
     monkeypatch.setenv("DRNMF_GRAM", "1")
     monkeypatch.setenv("DRNMF_PERSIST", "1")
+    from drnmf_amd import ops as _ops
+    if not _ops.persist_admitted(dev):       # (the fault is injected into the persistent chains only)
+        pytest.skip("not admitted to the persistent chains: " + _ops.persist_admit_reason(dev))
     B, T, F, r, K = 3, 4, 21, 6, 2
     P, alt, labels, N = TP._problem(B, T, F, r, K, untied=("log_D", "log_alph"), seed=9)
     good = TP._run_cell(dev, P, alt, labels, N, K)[0].copy()
@@ -484,6 +487,8 @@ def test_timed_out_training_step_is_skipped_and_reported(dev, monkeypatch):
     from drnmf_amd import _capi, layers, ops
     monkeypatch.setenv("DRNMF_GRAM", "1")
     monkeypatch.setenv("DRNMF_PERSIST", "1")
+    if not ops.persist_admitted(dev):        # (the fault is injected into the persistent chains only)
+        pytest.skip("not admitted to the persistent chains: " + ops.persist_admit_reason(dev))
     B, T, F, r, K = 5, 6, 21, 6, 3
     P = O.synth_problem(B, T, F, r, seed=31, ragged=True, density=0.15)
     N = 2 * r
