@@ -894,6 +894,41 @@ def test_plain_c_host_program_over_the_c_abi(dev, tmp_path):
     assert mx > 0 and err <= H_TOL * mx, out.stdout
 
 
+def test_graph_cache_key_carries_the_layout_choices(dev, monkeypatch):
+    """the cached frame graphs of a call are keyed by its pointers and shapes -- and by the layout
+    choices baked into their nodes (row blocks, atom ranges).  Two calls with the SAME tensors (input, prepared
+    block, output, workspace) under different row blockings -- what a sub-batch of a split call and a direct
+    call of the same B can take, here forced through DRNMF_RB -- lay the workspace out differently (Bp = 48
+    against 64 at B = 48): replaying the first call's graphs in the second would read the packed input with
+    the wrong strides.  Both calls must match the oracle."""
+    from drnmf_amd import ops
+    monkeypatch.setenv("DRNMF_GRAM", "0")
+    monkeypatch.setenv("DRNMF_SPLIT", "1")
+    B, T, F, r, K = 48, 5, 33, 20, 3
+    P, alt, labels, N = _problem(B, T, F, r, K, ragged=True, seed=3)
+    stack = lambda name: np.stack([alt[k] for k in dict.fromkeys(labels[name])], 0)
+    logD, logA, logL = stack("log_D"), stack("log_alph"), stack("log_lam1")
+    desc = ops.make_desc(B, T, F, N, K, n_D=logD.shape[0], n_alph=logA.shape[0],
+                         alph_len=int(np.asarray(logA[0]).size), n_lam=logL.shape[0])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    params = ops.prepare_params(desc, t(logD), t(logA.reshape(logA.shape[0], -1)), t(logL.reshape(-1)))
+    x, h0 = t(P["X"]), t(P["log_h0"])
+    u = O.u_scalars(alt, np.float32)
+    sizes = []
+    for rb in ("1", "2"):
+        monkeypatch.setenv("DRNMF_RB", rb)
+        sizes.append(ops.cell_workspace(desc, dev).numel())
+    ws = torch.empty(max(sizes), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, T, N), dtype=torch.float32, device=dev)
+    ref = O.cell_forward_factored(P["X"], O.maps_factored(alt, labels, K), O.u_scalars(alt), P["log_h0"],
+                                  mask_value=-1.0)
+    for rb in ("1", "2", "1"):
+        monkeypatch.setenv("DRNMF_RB", rb)
+        ops.cell_forward(x, -1.0, params, desc, h0, u, out=out, workspace=ws)
+        torch.cuda.synchronize()
+        _check_h(out.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("B,split,r,gram", [
     (100, None, 20, "0"), (100, "1", 20, "0"), (130, "3", 20, "0"), (250, "2", 20, "0"),
     (97, "4", 20, "0"), (200, "8", 20, "0"), (200, None, 250, None), (512, None, 20, "0")],
