@@ -72,6 +72,8 @@ SIGNATURES = {
     "drnmf_cell_backward_workspace_bytes": (_sz, [_DP]),
     "drnmf_cell_backward": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _sz,
                                    _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "drnmf_cell_backward_stateful": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _sz,
+                                            _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "drnmf_cell_backward_ista": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _sz, _vp, _sz,
                                         _vp, _vp, _vp, _vp, _vp]),
     "drnmf_cell_backward_profile": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp,

@@ -672,6 +672,8 @@ struct ColRedArgs {
     const float* psum_all;   // [T][Bp]
     const unsigned char* seen;
     const float* log_h0;
+    const float* init;       // stateful training: the state every sequence ENTERS with, [B][N] (a constant of
+                             // the gradient, custom_layers.py:296-318), instead of softplus(log_h0); or NULL
     float* part;             // [CR_SPLITS][CR_SLOTS][Np]
     const float* rt;         // r_k[.][Fm]  (row stride ldr) or nullptr: no odd-bin row
     const float* drt;        // d r_k[.][Fm] (row stride ldr), k >= 1
@@ -729,7 +731,8 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const ColRedArgs a) {
             float base;
             if (a.k == 0) {
                 const float p = a.seen[(size_t)t * a.Bp + b]
-                                    ? a.hall[(bt - 1) * KN + (size_t)(a.K - 1) * a.N + n] : h0v;
+                                    ? a.hall[(bt - 1) * KN + (size_t)(a.K - 1) * a.N + n]
+                                    : (a.init ? a.init[(size_t)b * a.N + n] : h0v);
                 base = a.u0d * p + a.u0o * (ps - p) + bk;
             } else {
                 base = (tail2 ? hpv[u] : a.hall[bt * KN + (size_t)(a.k - 1) * a.N + n]) + bk +
@@ -805,6 +808,8 @@ __global__ void __launch_bounds__(256) colreduce4_kernel(const ColRedArgs a) {
                 f32x4 p = h0v;
                 if (a.seen[(size_t)t * a.Bp + b])
                     p = *(const f32x4*)(a.hall + (bt - 1) * KN + (size_t)(a.K - 1) * a.N + n);
+                else if (a.init)
+                    p = *(const f32x4*)(a.init + (size_t)b * a.N + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) base[e] = a.u0d * p[e] + a.u0o * (ps - p[e]) + bk[e];
             } else {
@@ -892,6 +897,8 @@ __global__ void __launch_bounds__(256) colreduce4_rows_kernel(const ColRedArgs a
                     f32x4 p = h0v;
                     if (a.seen[(size_t)t * a.Bp + b])
                         p = *(const f32x4*)(a.hall + (bt - 1) * KN + (size_t)(a.K - 1) * a.N + n);
+                    else if (a.init)
+                        p = *(const f32x4*)(a.init + (size_t)b * a.N + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) base[e] = a.u0d * p[e] + a.u0o * (ps - p[e]) + bk[e];
                 } else {
@@ -1019,11 +1026,12 @@ scalar_grads_kernel(const float* __restrict__ part, const float* __restrict__ bi
 
 __global__ void __launch_bounds__(256)
 dlogh0_kernel(const float* __restrict__ dh0_part, const float* __restrict__ log_h0,
-              float* __restrict__ d_log_h0, int N, int Np, int numM) {
+              float* __restrict__ d_log_h0, int N, int Np, int numM, int stateful) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const float s = ordered_sum<8>(dh0_part + n, (size_t)Np, numM);
-    d_log_h0[n] = s / (1.f + expf(-log_h0[n]));   // d softplus = sigmoid
+    // (stateful training: the sequences entered with a supplied state, a constant: log_h0 was not used)
+    d_log_h0[n] = stateful ? 0.f : s / (1.f + expf(-log_h0[n]));   // d softplus = sigmoid
 }
 
 // ---- KL / beta cell (ista_kl / ista_beta run recurrently, cell_forward.hip) ----------------------------
@@ -1083,7 +1091,7 @@ unpack_g_kernel(const float* __restrict__ x, const float* __restrict__ xhat, flo
 __global__ void __launch_bounds__(256)
 state_matrix_kernel(const float* __restrict__ hall, const unsigned char* __restrict__ seen,
                     const float* __restrict__ log_h0, float* __restrict__ P, int B, int T, int N,
-                    int K, int Bp) {
+                    int K, int Bp, const float* __restrict__ init) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * T * N) return;
     const int n = (int)(i % N);
@@ -1091,6 +1099,7 @@ state_matrix_kernel(const float* __restrict__ hall, const unsigned char* __restr
     const int t = (int)(bt % T), b = (int)(bt / T);
     float v;
     if (seen[(size_t)t * Bp + b]) v = hall[(bt - 1) * K * N + (size_t)(K - 1) * N + n];
+    else if (init) v = init[(size_t)b * N + n];
     else {
         const float z = log_h0[n];
         v = (z > 20.f) ? z : log1pf(expf(z));
@@ -1151,7 +1160,8 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
                                   size_t fwd_workspace_bytes, void* bwd_workspace,
                                   size_t bwd_workspace_bytes, float* d_log_D,
                                   float* d_log_alph, float* d_log_lam1, float* d_log_h0,
-                                  void* stream_, float* prof_ms, float beta = 0.f) {
+                                  void* stream_, float* prof_ms, float beta = 0.f,
+                                  const float* initial_state = nullptr) {
     if (!h) return DRNMF_ERR_INVALID_ARG;
     // (No implicit look at the handle's fault word here: a host-side read-and-clear at the entry of the
     // NEXT call races with the stream-ordered drnmf_status_take_device of a training step -- the host
@@ -1443,7 +1453,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
     }
     if (!persist) hipLaunchKernelGGL(bwd_edge_kernel, grid_a, dim3(256), 0, stream, ea);   // t = -1
     hipLaunchKernelGGL(dlogh0_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dh0_part,
-                       log_h0, d_log_h0, N, W.Np, numM);
+                       log_h0, d_log_h0, N, W.Np, numM, initial_state != nullptr ? 1 : 0);
     DRNMF_HIP(h, hipGetLastError());
     if (prof_ms) DRNMF_HIP(h, hipEventRecord(pev[1], stream));
 
@@ -1508,7 +1518,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
             float* Pst = (float*)(bw + L.off_pst);
             const size_t totp = (size_t)BT * N;
             hipLaunchKernelGGL(state_matrix_kernel, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0,
-                               stream, hall, seen, log_h0, Pst, B, T, N, K, W.Bp);
+                               stream, hall, seen, log_h0, Pst, B, T, N, K, W.Bp, initial_state);
             gemm_tn::Operands t2{dR_all, Pst, BT, Mg, N, W.Fp, N};
             DRNMF_HIP(h, gemm_tn::launch(t2, EpiP2{P, W.Np, pstr, perm_all}, nsplit, stream));
         }
@@ -1517,7 +1527,7 @@ static int32_t cell_backward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, 
         ca.drt = dRk_tail;
         ca.ldr = W.Fp;
         ca.hall = hall; ca.dz_all = dz_all; ca.bias = b_of(k); ca.psum_all = psum_all;
-        ca.seen = seen; ca.log_h0 = log_h0; ca.part = crp;
+        ca.seen = seen; ca.log_h0 = log_h0; ca.init = initial_state; ca.part = crp;
         ca.u0d = u0_diag; ca.u0o = u0_off; ca.uko = uk_off;
         ca.k = k; ca.B = B; ca.T = T; ca.N = N; ca.K = K; ca.Bp = W.Bp; ca.Np = W.Np;
         if (N % 4 == 0 && N / 4 <= 64)
@@ -1587,6 +1597,29 @@ extern "C" int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t
     return cell_backward_impl(h, d, x, params, log_h0, u0_diag, u0_off, uk_off, hall, d_out,
                               fwd_workspace, fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes,
                               d_log_D, d_log_alph, d_log_lam1, d_log_h0, stream_, nullptr);
+}
+
+// Stateful training (custom_layers.py:296-318; Keras Recurrent stateful=True under fit / train_on_batch):
+// the forward was drnmf_cell_forward_stateful with return_all_hidden = 1, every sequence entered with
+// initial_state[b] -- a CONSTANT of the gradient (Keras does not backpropagate into the previous batch).
+// Same BPTT; the state that enters a row's first valid frame is initial_state[b] instead of
+// softplus(log_h0) wherever the weight gradients need it, and d_log_h0 = 0.  initial_state NULL = drnmf_cell_backward.
+extern "C" int32_t drnmf_cell_backward_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                                const void* params, const float* log_h0, float u0_diag,
+                                                float u0_off, float uk_off, const float* initial_state,
+                                                const float* hall, const float* d_out,
+                                                const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                                void* bwd_workspace, size_t bwd_workspace_bytes,
+                                                float* d_log_D, float* d_log_alph, float* d_log_lam1,
+                                                float* d_log_h0, void* stream_) {
+    DRNMF_LOCK(h);
+    if (h && d && d->divergence != DRNMF_DIV_ED)
+        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "cell_backward_stateful is the reference's (Euclidean) cell");
+    if (h && initial_state && ((uintptr_t)initial_state & 15))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_backward_stateful: initial_state must be 16-byte aligned");
+    return cell_backward_impl(h, d, x, params, log_h0, u0_diag, u0_off, uk_off, hall, d_out,
+                              fwd_workspace, fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes,
+                              d_log_D, d_log_alph, d_log_lam1, d_log_h0, stream_, nullptr, 0.f, initial_state);
 }
 
 extern "C" int32_t drnmf_cell_backward_ista(drnmf_handle_t h, const drnmf_cell_desc_t* d,

@@ -599,15 +599,14 @@ class SimpleDeepRNN(_Layer):
         if self._train_blockers:
             raise NotImplementedError('training with %s is not implemented' %
                                       ', '.join(self._train_blockers))
-        if self.stateful:
-            # (Keras would enter each batch with the state the previous one left, as a constant of the
-            # gradient: custom_layers.py:296-318; enhance.py never trains a stateful layer.  The BPTT
-            # kernels start every sequence from softplus(log_h0), so refuse instead of ignoring the state)
-            raise NotImplementedError('training a stateful layer is not implemented')
         if not self.built:
             self.build(tuple(x.shape))
         if self._dense_now or getattr(self, '_train_dense', False) or self.dropout_U:
+            if self.stateful:
+                raise NotImplementedError('training a stateful layer on the dense-matrix path is not implemented')
             return self._forward_train_dense(x, mask_value)
+        if self.stateful and self.divergence != 'ed':
+            raise NotImplementedError('training a stateful KL / beta cell is not implemented')
         B, T, F = x.shape
         self.prepare(B, T)
         lab = self.maps_from_alt.labels_per_k
@@ -624,11 +623,24 @@ class SimpleDeepRNN(_Layer):
         if key not in self._ws:
             self._ws.clear()
             self._ws[key] = ops.cell_workspace(desc, x.device)
+        self._train_init = None
         if self.divergence != 'ed':
             # the KL / beta variant (an extension): ista_kl / ista_beta (enhance.py:421-456) run
             # recurrently; its BPTT is drnmf_cell_backward_ista
             hall = ops.cell_forward_ista(x, mask_value, self._params_block, desc, self.log_h0,
                                          beta=self.beta, workspace=self._ws[key])
+        elif self.stateful:
+            # Keras stateful RNN under fit / train_on_batch (custom_layers.py:296-318): the state the previous
+            # batch left enters this one as a CONSTANT of the gradient (zeros before the first batch /
+            # after reset_states); the state this batch leaves is kept for the next.  The entering state is
+            # copied: the BPTT needs it after the forward has overwritten `states`.
+            if getattr(self, 'states', None) is None or self.states[0] is None or \
+                    tuple(self.states[0].shape) != (B, self.output_dim):
+                self.states = [torch.zeros((B, self.output_dim), dtype=torch.float32, device=x.device)]
+            self._train_init = self.states[0].clone()
+            hall = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
+                                    workspace=self._ws[key], initial_state=self._train_init,
+                                    final_state=self.states[0])
         else:
             hall = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
                                     workspace=self._ws[key])
@@ -642,7 +654,8 @@ class SimpleDeepRNN(_Layer):
             return self._backward_dense(x, hall, d_out)
         desc, key, _ = self._train_ctx
         return ops.cell_backward(x, self._params_block, desc, self.log_h0, self._u, hall, d_out,
-                                 self._ws[key], grads=grads, profile=profile, beta=self.beta)
+                                 self._ws[key], grads=grads, profile=profile, beta=self.beta,
+                                 initial_state=getattr(self, '_train_init', None))
 
     # -- training on the dense-matrix path ---------------------------------------------------
     # Whatever maps_from_alt produce (build_alt's maps with a trainable log_U1 / log_Uk, a caller's

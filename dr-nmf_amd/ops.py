@@ -439,13 +439,15 @@ def snmf_cost_head_backward(x_raw, hidden, kernel_clean, kernel_noise, A, Bn, w,
 
 
 def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=None, profile=None,
-                  beta=None):
+                  beta=None, initial_state=None):
     """BPTT through the cell (forward must have been run with return_all_hidden=True on the same
     workspace).  A KL / beta descriptor (desc.divergence) goes to drnmf_cell_backward_ista with
     `beta` (u is ignored: that cell has no U term).  Returns dict(d_log_D [n_D,F,N], d_log_alph [n_alph,alph_len], d_log_lam1 [n_lam],
     d_log_h0 [N]); `grads` may supply preallocated output tensors.  `profile` (a dict, bench.py
     only) switches to drnmf_cell_backward_profile, which synchronises and fills chain_ms /
-    batched_ms / chain_launches."""
+    batched_ms / chain_launches.  initial_state [B,N]: stateful training -- the forward was
+    cell_forward(..., initial_state=...), the supplied state is a constant of the gradient
+    (drnmf_cell_backward_stateful; d_log_h0 comes back zero)."""
     L = _capi.lib()
     h = _capi.handle(_dev_index(x))
     x, hall, d_out = _f32c(x, "x"), _f32c(hall, "hall"), _f32c(d_out, "d_out")
@@ -473,7 +475,15 @@ def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=
             fwd_workspace.numel(), _capi.ptr(bws), nbytes,
             _capi.ptr(out["d_log_D"]), _capi.ptr(out["d_log_alph"]),
             _capi.ptr(out["d_log_lam1"]), _capi.ptr(out["d_log_h0"]), _stream())
-    if desc.divergence != _capi.DIV_ED:
+    if initial_state is not None:
+        if desc.divergence != _capi.DIV_ED or profile is not None:
+            raise NotImplementedError("stateful BPTT: the Euclidean cell, unprofiled")
+        if tuple(initial_state.shape) != (desc.B, desc.N) or initial_state.dtype != torch.float32 \
+                or not initial_state.is_contiguous():
+            raise ValueError("initial_state must be a contiguous float32 (B,N) tensor")
+        rc = L.drnmf_cell_backward_stateful(*(args[:8] + (_capi.ptr(initial_state),) + args[8:]))
+        _capi.check(rc, h, "drnmf_cell_backward_stateful")
+    elif desc.divergence != _capi.DIV_ED:
         rc = L.drnmf_cell_backward_ista(
             h, C.byref(desc), _capi.ptr(x), _capi.ptr(params), _capi.ptr(log_h0),
             float(1.5 if beta is None else beta), _capi.ptr(hall), _capi.ptr(d_out),

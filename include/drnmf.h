@@ -325,6 +325,19 @@ int32_t drnmf_cell_backward(drnmf_handle_t h, const drnmf_cell_desc_t* d, const 
                             void* bwd_workspace, size_t bwd_workspace_bytes, float* d_log_D,
                             float* d_log_alph, float* d_log_lam1, float* d_log_h0, void* stream);
 
+/* Stateful training: the BPTT of a forward run by drnmf_cell_forward_stateful (return_all_hidden = 1) whose
+ * sequences entered with initial_state [B][N] -- the state the previous batch left, a CONSTANT of the
+ * gradient as in Keras (Recurrent stateful=True; SimpleDeepRNN.reset_states custom_layers.py:296-318).
+ * Arguments as drnmf_cell_backward; d_log_h0 comes back zero (log_h0 was not used).  initial_state NULL =
+ * drnmf_cell_backward.  Euclidean cell only. */
+int32_t drnmf_cell_backward_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                     const void* params, const float* log_h0, float u0_diag,
+                                     float u0_off, float uk_off, const float* initial_state,
+                                     const float* hall, const float* d_out, const void* fwd_workspace,
+                                     size_t fwd_workspace_bytes, void* bwd_workspace,
+                                     size_t bwd_workspace_bytes, float* d_log_D, float* d_log_alph,
+                                     float* d_log_lam1, float* d_log_h0, void* stream);
+
 /* BPTT of the KL / beta variant of the cell (drnmf_cell_forward_ista run with return_all_hidden = 1 on
  * the same x / params / workspace; the iteration differentiated is ista_kl / ista_beta,
  * enhance.py:421-456): same inputs and outputs as drnmf_cell_backward, `beta` as in the forward.

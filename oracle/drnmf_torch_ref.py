@@ -13,7 +13,7 @@ def unit_cols(logD):
 
 
 def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, square=False,
-               normalise=True, snmf_cost_l1_weight=None, divergence='ed', beta=1.5):
+               normalise=True, snmf_cost_l1_weight=None, divergence='ed', beta=1.5, initial_state=None):
     """x, y: (B,T,F) float64 tensors; w: (B,T) sample weights (= validity mask in the reference).
     alt: dict name -> tensor (requires_grad where wanted).  Returns (loss, mask, h).
     divergence 'kl' | 'beta': the KL / beta variant of the cell (oracle.cell_forward_ista_warm: every
@@ -28,7 +28,9 @@ def model_loss(x, y, w, alt, labels_per_k, K, log_h0, kc, kn, mask_value=-1.0, s
     Uk = torch.exp(alt['log_Uk'])
     u0d, u0o, uko = U1[0, 0], (U1[0, 1] if N > 1 else U1[0, 0] * 0), Uk[0, 0]
     h0 = torch.nn.functional.softplus(log_h0)
-    state = h0[None, :].expand(B, N)
+    # initial_state (B,N): a stateful layer's entering state (Keras Recurrent stateful=True,
+    # custom_layers.py:296-318) -- a constant: no gradient reaches it, and log_h0 is then unused
+    state = h0[None, :].expand(B, N) if initial_state is None else initial_state.detach()
     out_prev = torch.zeros(B, N, dtype=x.dtype)
     outs = []
     # the maps from the log-domain parameters are evaluated once per graph execution, outside the

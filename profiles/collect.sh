@@ -98,7 +98,9 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_r100" -o p -- python3 "$ROOT/tools/train_profile.py" 32 500 257 100 5 3 \
     > /dev/null 2> "$OUT/pmc_r100.err"
 python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_r100_summary.json" "$OUT/pmc_r100"
-# keep the merge-back small: the raw per-dispatch CSVs are large
+# keep the merge-back small (gpurun copies back at most 64 MiB): the raw per-dispatch directories go once they are summarised
+find "$OUT" -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
+find "$OUT" -maxdepth 1 -type d -name 'step_api_*' -exec rm -rf {} +
 find "$OUT" -name '*counter_collection.csv' -size +8M -delete
 find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
 find "$OUT" -name "*.db" -delete

@@ -99,8 +99,12 @@ def test_simple_deep_rnn_config_surface():
     st = layers.SimpleDeepRNN(N, **dict(ok, stateful=True))      # stateful mode is supported
     with pytest.raises(ValueError):
         st.reset_states()                                        # batch size not known yet
-    with pytest.raises(NotImplementedError):                     # ... forward only: the BPTT starts every
-        st.forward_train(None)                                   # sequence from softplus(log_h0)
+    # (training a stateful layer: the fused Euclidean path since round 5, tests/test_gpu_train.py; the KL / beta
+    # cell and the dense-matrix path still refuse)
+    stk = layers.SimpleDeepRNN(N, **dict(ok, stateful=True, divergence="kl"))
+    stk.built = True
+    with pytest.raises(NotImplementedError):
+        stk.forward_train(None)
     # configurations outside build_unfolded_snmf's are accepted (general dense-matrix kernel,
     # forward only) ...
     for generic in (dict(activation="tanh"), dict(flag_nonnegative=False),
