@@ -913,8 +913,9 @@ def main():
                         dp.comm_destroy()
                     except Exception:        # noqa: BLE001 -- nothing to destroy on the rank that failed
                         pass
-                    collective = ("torch.distributed all-reduce over RCCL -- FALLBACK: drnmf_comm_init failed "
-                                  "(%s)" % why[:200])
+                    collective = ("torch.distributed all-reduce (backend %s%s) -- FALLBACK: drnmf_comm_init "
+                                  "failed (%s)" % (dist.get_backend(),
+                                                   " = RCCL" if dist.get_backend() == "nccl" else "", why[:200]))
                 else:
                     collective = "drnmf_allreduce_grads (RCCL communicator owned by the library handle)"
                     comm_seen = dp.comm_info(dev)          # (rank, world) as RCCL's communicator has them
