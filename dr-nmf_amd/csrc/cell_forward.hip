@@ -82,6 +82,7 @@ struct CellAArgs {
                              // pulled into the L2s by this launch's fifth wave; NULL: no prefetch
     int pf_tiles;            // MFMA bin tiles of that cell_b launch (its workgroup (x, y) reads tile 8 y + x % 8)
     int pf_sleep;            // the prefetching wave starts 8 * 64 * pf_sleep cycles into the launch
+    const f16* x16;          // fp16 mode, first layer: the packed input as fp16, Rp16 order [T][Bp][Fp] (pack_input_kernel)
 };
 
 // G = operand slots (16-bin chunks in flight per wave, prefetch distance G-1).  RB = 16-row blocks per
@@ -150,6 +151,19 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // A separate prefetch kernel on a side stream, paced by a progress counter, LOST: 8.78 -> 9.05-12.7 us per
     // launch (profiles/r05_prefetch_side_stream_negative.txt).
     if (HALF && w == NW_A) {
+        if (IS_FIRST && !IS_LAST) {
+            // first layer: republish x_t (fp32) at a frame-independent address -- cell_b subtracts x^ from it
+            // without a dependent frame-index load.  One 1-KB block per workgroup of the row group (the working
+            // waves read the fp16 copy of x_t, pack_input_kernel; they used to read these fp32 blocks, convert
+            // and republish them: 160 VGPRs instead of 125)
+            const int t5 = *a.t_rd;
+            const size_t g0 = (size_t)mb0 * (Fp / 16) * 256 + l * 4;
+            const float* src = a.rsrc + (size_t)t5 * pstride + g0;
+            float* dst = a.xcur + g0;
+            const int nblk = RB * (Fp / 16);           // (the row blocks of a group are contiguous)
+            for (int b = ab_raw; b < nblk; b += 8 * (int)gridDim.y)
+                *(f32x4*)(dst + (size_t)b * 256) = *(const f32x4*)(src + (size_t)b * 256);
+        }
         for (int i = 0; i < a.pf_sleep; ++i) __builtin_amdgcn_s_sleep(8);      // (see make_a; DRNMF_PF_SLEEP)
         if (!IS_LAST && a.Dn_pf != nullptr) {
             const int x = blockIdx.x & 7;
@@ -198,8 +212,9 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     const f16* brow16 = (const f16*)a.Dn + (size_t)ab * 512 + l * 8;
     const size_t bstep = HALF ? (size_t)NAC * 512 : (size_t)NAC * 256;             // per chunk c
     const size_t bstep_blk = (size_t)NAC * 256;                                     // fp16: block 2c -> 2c+1
-    // fp16 residual Rp16 (cell_shared.h): block (mb, c) of 512 halves
-    const f16* arow16 = (const f16*)rsrc + (size_t)mb0 * (Fp / 32) * 512 + l * 8;
+    // fp16 residual Rp16 (cell_shared.h): block (mb, c) of 512 halves; first layer: x_t in the same order
+    const f16* arow16 = (IS_FIRST ? a.x16 + (size_t)t * pstride : (const f16*)rsrc) +
+                        (size_t)mb0 * (Fp / 32) * 512 + l * 8;
     const size_t astep16 = (size_t)(Fp / 32) * 512;
 
     // training: the summed residual of this row tile also goes out row-major for the BPTT's weight
@@ -233,10 +248,10 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     // (fp16 mode: a.nchunks counts 32-bin chunks)
     const int per_wave = (a.nchunks - w + NW_A - 1) / NW_A;   // chunks owned by this wave (>= 0)
     const int clast = a.nchunks - 1;
-    // fp32: KS residual partials per chunk (x_t: one).  fp16: the first layer reads the two fp32
-    // input blocks of its 32-bin chunk, the others one fp16 block (ah)
-    constexpr int NP = HALF ? (IS_FIRST ? 2 : 1) : (IS_FIRST ? 1 : KS);
-    constexpr bool A16 = HALF && !IS_FIRST;
+    // fp32: KS residual partials per chunk (x_t: one).  fp16: one fp16 block per 32-bin chunk (ah) -- the
+    // residual, or for the first layer the fp16 copy of x_t
+    constexpr int NP = HALF ? 1 : (IS_FIRST ? 1 : KS);
+    constexpr bool A16 = HALF;
 
     f32x4 av[A16 ? 1 : G][RB][NP];
     f32x4 bv[HALF ? 1 : G][2];      // {s = 2i: atoms a0 a1, s = 2i+1: a0 a1} for i = 0, 1
@@ -250,12 +265,6 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             const int ca = (a.ablate & 2) ? 0 : c;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
-        } else if (HALF) {          // first layer: fp32 blocks 2c, 2c+1 of the packed input
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb)
-                    av[g][rb][hb] = *(const f32x4*)(arow + rb * astep + 256 * (2 * c + hb));
         } else {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -340,8 +349,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             // layer, added in block order by 16 lanes + a fixed shuffle tree (deterministic)
             const float* rp = a.rs_part + (size_t)(t & 1) * a.numA * a.Bp + rg;
             float s = 0.f;
-            // (eight loads in flight, added in index order: the plain loop is one dependent L2 round trip
-            // per term -- 16 of them at N = 8000, where this first-layer launch took 19 us against 8)
+            // (eight loads in flight, added in index order: a plain loop is one dependent L2 round trip per term)
             for (int b0 = (tid & 15); b0 < a.numA; b0 += 128) {
                 float v8[8];
 #pragma unroll
@@ -425,21 +433,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             transpose_chunk(g);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                f16x8 a8;
-                if (A16) {
-                    a8 = ah[g][rb];
-                } else {
-                    const f32x4 lo = av[g][rb][0], hi = av[g][rb][1];
-                    if (ab_raw == 0 && ok) {
-                        // republish this row tile's x_t chunk at a frame-independent address
-                        const int c = w + NW_A * (base + g);
-                        float* xc = a.xcur + (size_t)(mb0 + rb) * nft * 256 + 512 * c + l * 4;
-                        *(f32x4*)xc = lo;
-                        *(f32x4*)(xc + 256) = hi;
-                    }
-                    a8 = f16x8{(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3],
-                               (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
-                }
+                f16x8 a8 = ah[g][rb];
                 if (!ok) a8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 acc[rb][0] = mfma32h(a8, bt0, acc[rb][0]);
                 acc[rb][1] = mfma32h(a8, bt1, acc[rb][1]);
@@ -1269,7 +1263,8 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     {
         const size_t rows = (size_t)d->T * W.Bp;
         hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                           stream, x, xp, valid, mask_value, d->B, d->T, d->F, W.Bp, W.Fp);
+                           stream, x, xp, valid, mask_value, d->B, d->T, d->F, W.Bp, W.Fp,
+                           half ? (f16*)(ws + W.off_xp16) : (f16*)nullptr);
         hipLaunchKernelGGL(seen_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream, valid,
                            (unsigned char*)(ws + W.off_seen), d->T, W.Bp);
         if (initial_state)
@@ -1386,6 +1381,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         // latency-critical part.  Delay in units of 512 cycles, us per launch at the config-5 shape:
         // 0 8.58-8.62, 2 8.58, 4 8.55, 8 8.47, 12 8.42, 16 8.54, 24 9.28, 32 10.2; no prefetch 8.82)
         a.pf_sleep = tune_env("DRNMF_PF_SLEEP") ? atoi(tune_env("DRNMF_PF_SLEEP")) : 10;
+        a.x16 = half ? (const f16*)(ws + W.off_xp16) : nullptr;
         if (pf_on && k + 1 < K) a.Dn_pf = DnB_of(k + 1);
         return a;
     };

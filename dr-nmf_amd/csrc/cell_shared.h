@@ -321,10 +321,14 @@ __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
 
 // Masking + relayout: x [B][T][F] -> xp [T][Bp][Fp] (masked frames and all padding zero) and
 // valid [T][Bp].  One wave per (t, row).  [K2.0.4-memory: keras.layers.Masking]
+// xp16 (fp16 operand mode, or NULL): the same frames once more as fp16 in Rp16 order (cell_b_kernel), the
+// first layer's MFMA operand -- it then reads half the bytes and runs the same operand path as the other layers
+// (reading the fp32 blocks, converting and republishing them in the kernel: 160 VGPRs against 125; the
+// first-layer launch at F = 1025, N = 8000: 20.4 -> 17.2 us).
 __global__ void __launch_bounds__(256)
 pack_input_kernel(const float* __restrict__ x, float* __restrict__ xp,
                   unsigned char* __restrict__ valid, float mask_value, int B, int T, int F, int Bp,
-                  int Fp) {
+                  int Fp, f16* __restrict__ xp16 = nullptr) {
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const size_t rowid = (size_t)blockIdx.x * 4 + wv;   // = t*Bp + b
     if (rowid >= (size_t)T * Bp) return;
@@ -332,17 +336,23 @@ pack_input_kernel(const float* __restrict__ x, float* __restrict__ xp,
     const int nft = Fp / 16;
     // tile-packed destination: Rp[t][b/16][f/16][rp_pos(b%16, f%16)]
     float* dst = xp + (size_t)t * Bp * Fp + (size_t)(b >> 4) * nft * 256;
+    // Rp16[m][f/32][q = f%4][row][e = 4 ((f/16)%2) + (f%16)/4]   (Fp % 32 == 0 in that mode)
+    f16* dst16 = xp16 ? xp16 + (size_t)t * Bp * Fp + (size_t)(b >> 4) * (Fp / 32) * 512 + (b & 15) * 8 : nullptr;
+    auto pos16 = [](int f) { return (size_t)(f >> 5) * 512 + (f & 3) * 128 + ((f >> 4) & 1) * 4 + ((f & 15) >> 2); };
     bool any = false;
     if (b < B) {
         const float* src = x + ((size_t)b * T + t) * F;
         for (int f = l; f < F; f += 64) any |= (src[f] != mask_value);
         any = __any(any);
         for (int f = l; f < Fp; f += 64) {
-            dst[(size_t)(f >> 4) * 256 + rp_pos(b & 15, f & 15)] = (any && f < F) ? src[f] : 0.f;
+            const float v = (any && f < F) ? src[f] : 0.f;
+            dst[(size_t)(f >> 4) * 256 + rp_pos(b & 15, f & 15)] = v;
+            if (dst16) dst16[pos16(f)] = (f16)v;
         }
     } else {
         for (int f = l; f < Fp; f += 64) {
             dst[(size_t)(f >> 4) * 256 + rp_pos(b & 15, f & 15)] = 0.f;
+            if (dst16) dst16[pos16(f)] = (f16)0.f;
         }
     }
     if (l == 0) valid[rowid] = any ? 1 : 0;
@@ -384,6 +394,7 @@ struct Workspace {
     int nft_main, ntail;   // forward: bins 16*nft_main .. F-1 (at most MAX_TAIL) are handled outside the MFMA tiles
     size_t off_qpart, off_xtail, off_xcur, off_qsum;
     size_t off_h16_0, off_h16_1, off_r16;   // fp16 operand mode: Hp16 ping-pong, Rp16 (cell_b_kernel)
+    size_t off_xp16;                         // ... and the packed input once more as fp16 (pack_input_kernel)
     bool half;
     // Gram form (cell_gram.h): packed c, ring of 2 x GRAM_TB frames [.][K][Bp][Np]; one block of x
     // padded row-major [B][GRAM_TB][Fp]; q ping-pong
@@ -496,6 +507,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     W.off_h16_0 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_h16_1 = take(W.half ? (size_t)W.Bp * W.Np * 2 : 0);
     W.off_r16 = take(W.half ? (size_t)W.Bp * W.Fp * 2 : 0);
+    W.off_xp16 = take(W.half ? (size_t)d->T * W.Bp * W.Fp * 2 : 0);
     W.cp_full = W.gram && W.numO <= 32 && W.Bp / ROWS <= 16 && d->T > 2 * GRAM_TB &&
                 (size_t)d->T * d->K * W.Bp * W.Np * 4 <= ((size_t)1 << 30);
     if (const char* e = tune_env("DRNMF_CP_FULL"))      // tuning aid: 0 keeps the ring of two blocks
