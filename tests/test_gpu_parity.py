@@ -662,6 +662,8 @@ def test_c_abi_status_codes_and_messages(dev):
                                                       # the last 32-bin chunk straddles the tail tile
     dict(B=4, T=3, F=34, r=40, K=3),                  # two odd bins
     dict(B=16, T=2, F=1025, r=4000, K=50, alph=1600.0),              # BASELINE config 5 at its depth
+    dict(B=3, T=4, F=21, r=6, K=1),                   # a single layer: first and last at once (no cell_b, no prefetch)
+    dict(B=70, T=3, F=65, r=150, K=3, ragged=True),   # 10 atom blocks, 3 row groups: the spare waves' shares wrap
 ])
 def test_cell_forward_fp16_operands(dev, cfg):
     """BASELINE config 5: fp16 MFMA operands, fp32 accumulate.  Against the oracle's emulation of
