@@ -1029,6 +1029,10 @@ class UnfoldedSNMFModel(object):
         return self.load_weights_tree(tree)
 
     def forward(self, x, want_hidden=False):
+        """Device tensors in, device tensors out, nothing waited for: a fault on the device (a persistent
+        small-shape chain that timed out) is NOT raised here -- call ops.check_status(device) once you have
+        synchronised, as predict_on_batch does after its copy; a later training / test step drops such a stale
+        word instead of charging it to itself (_drop_stale_fault)."""
         h = self.cell.call(x, mask_value=self.mask_value)
         mask = ops.head_forward(h, self.clean.kernel, self.noise.kernel, square=self.square,
                                 h_off=h.shape[-1] - self.cell.output_dim)
