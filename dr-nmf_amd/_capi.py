@@ -76,6 +76,8 @@ SIGNATURES = {
                                             _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "drnmf_cell_backward_ista": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _sz, _vp, _sz,
                                         _vp, _vp, _vp, _vp, _vp]),
+    "drnmf_cell_backward_ista_stateful": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
+                                                 _vp, _vp, _vp, _vp, _vp]),
     "drnmf_cell_backward_profile": (_i32, [_vp, _DP, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp,
                                            _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp,
                                            C.POINTER(C.c_float)]),

@@ -1639,6 +1639,27 @@ extern "C" int32_t drnmf_cell_backward_ista(drnmf_handle_t h, const drnmf_cell_d
                               d_log_alph, d_log_lam1, d_log_h0, stream_, nullptr, beta);
 }
 
+// ... and of a stateful KL / beta cell (drnmf_cell_forward_ista with an initial state, return_all_hidden = 1)
+extern "C" int32_t drnmf_cell_backward_ista_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d,
+                                                     const float* x, const void* params, const float* log_h0,
+                                                     float beta, const float* initial_state, const float* hall,
+                                                     const float* d_out, const void* fwd_workspace,
+                                                     size_t fwd_workspace_bytes, void* bwd_workspace,
+                                                     size_t bwd_workspace_bytes, float* d_log_D,
+                                                     float* d_log_alph, float* d_log_lam1, float* d_log_h0,
+                                                     void* stream_) {
+    DRNMF_LOCK(h);
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (!d || (d->divergence != DRNMF_DIV_KL && d->divergence != DRNMF_DIV_BETA))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG,
+                   "cell_backward_ista_stateful: d->divergence must be DRNMF_DIV_KL or DRNMF_DIV_BETA");
+    if (initial_state && ((uintptr_t)initial_state & 15))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "cell_backward_ista_stateful: initial_state must be 16-byte aligned");
+    return cell_backward_impl(h, d, x, params, log_h0, 1.f, 0.f, 0.f, hall, d_out, fwd_workspace,
+                              fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes, d_log_D,
+                              d_log_alph, d_log_lam1, d_log_h0, stream_, nullptr, beta, initial_state);
+}
+
 extern "C" int32_t drnmf_cell_backward_profile(
     drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x, const void* params,
     const float* log_h0, float u0_diag, float u0_off, float uk_off, const float* hall,

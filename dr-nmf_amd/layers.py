@@ -605,8 +605,6 @@ class SimpleDeepRNN(_Layer):
             if self.stateful:
                 raise NotImplementedError('training a stateful layer on the dense-matrix path is not implemented')
             return self._forward_train_dense(x, mask_value)
-        if self.stateful and self.divergence != 'ed':
-            raise NotImplementedError('training a stateful KL / beta cell is not implemented')
         B, T, F = x.shape
         self.prepare(B, T)
         lab = self.maps_from_alt.labels_per_k
@@ -624,20 +622,23 @@ class SimpleDeepRNN(_Layer):
             self._ws.clear()
             self._ws[key] = ops.cell_workspace(desc, x.device)
         self._train_init = None
+        if self.stateful:
+            if getattr(self, 'states', None) is None or self.states[0] is None or \
+                    tuple(self.states[0].shape) != (B, self.output_dim):
+                self.states = [torch.zeros((B, self.output_dim), dtype=torch.float32, device=x.device)]
+            self._train_init = self.states[0].clone()
         if self.divergence != 'ed':
             # the KL / beta variant (an extension): ista_kl / ista_beta (enhance.py:421-456) run
-            # recurrently; its BPTT is drnmf_cell_backward_ista
+            # recurrently; its BPTT is drnmf_cell_backward_ista (stateful: ..._ista_stateful, as below)
             hall = ops.cell_forward_ista(x, mask_value, self._params_block, desc, self.log_h0,
-                                         beta=self.beta, workspace=self._ws[key])
+                                         beta=self.beta, workspace=self._ws[key],
+                                         initial_state=self._train_init,
+                                         final_state=self.states[0] if self.stateful else None)
         elif self.stateful:
             # Keras stateful RNN under fit / train_on_batch (custom_layers.py:296-318): the state the previous
             # batch left enters this one as a CONSTANT of the gradient (zeros before the first batch /
             # after reset_states); the state this batch leaves is kept for the next.  The entering state is
             # copied: the BPTT needs it after the forward has overwritten `states`.
-            if getattr(self, 'states', None) is None or self.states[0] is None or \
-                    tuple(self.states[0].shape) != (B, self.output_dim):
-                self.states = [torch.zeros((B, self.output_dim), dtype=torch.float32, device=x.device)]
-            self._train_init = self.states[0].clone()
             hall = ops.cell_forward(x, mask_value, self._params_block, desc, self.log_h0, self._u,
                                     workspace=self._ws[key], initial_state=self._train_init,
                                     final_state=self.states[0])

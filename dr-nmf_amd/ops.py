@@ -476,13 +476,22 @@ def cell_backward(x, params, desc, log_h0, u, hall, d_out, fwd_workspace, grads=
             _capi.ptr(out["d_log_D"]), _capi.ptr(out["d_log_alph"]),
             _capi.ptr(out["d_log_lam1"]), _capi.ptr(out["d_log_h0"]), _stream())
     if initial_state is not None:
-        if desc.divergence != _capi.DIV_ED or profile is not None:
-            raise NotImplementedError("stateful BPTT: the Euclidean cell, unprofiled")
+        if profile is not None:
+            raise NotImplementedError("stateful BPTT: unprofiled")
         if tuple(initial_state.shape) != (desc.B, desc.N) or initial_state.dtype != torch.float32 \
                 or not initial_state.is_contiguous():
             raise ValueError("initial_state must be a contiguous float32 (B,N) tensor")
-        rc = L.drnmf_cell_backward_stateful(*(args[:8] + (_capi.ptr(initial_state),) + args[8:]))
-        _capi.check(rc, h, "drnmf_cell_backward_stateful")
+        if desc.divergence != _capi.DIV_ED:
+            rc = L.drnmf_cell_backward_ista_stateful(
+                h, C.byref(desc), _capi.ptr(x), _capi.ptr(params), _capi.ptr(log_h0),
+                float(1.5 if beta is None else beta), _capi.ptr(initial_state), _capi.ptr(hall),
+                _capi.ptr(d_out), _capi.ptr(fwd_workspace), fwd_workspace.numel(), _capi.ptr(bws), nbytes,
+                _capi.ptr(out["d_log_D"]), _capi.ptr(out["d_log_alph"]), _capi.ptr(out["d_log_lam1"]),
+                _capi.ptr(out["d_log_h0"]), _stream())
+            _capi.check(rc, h, "drnmf_cell_backward_ista_stateful")
+        else:
+            rc = L.drnmf_cell_backward_stateful(*(args[:8] + (_capi.ptr(initial_state),) + args[8:]))
+            _capi.check(rc, h, "drnmf_cell_backward_stateful")
     elif desc.divergence != _capi.DIV_ED:
         rc = L.drnmf_cell_backward_ista(
             h, C.byref(desc), _capi.ptr(x), _capi.ptr(params), _capi.ptr(log_h0),

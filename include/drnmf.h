@@ -349,6 +349,13 @@ int32_t drnmf_cell_backward_ista(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                                  size_t fwd_workspace_bytes, void* bwd_workspace,
                                  size_t bwd_workspace_bytes, float* d_log_D, float* d_log_alph,
                                  float* d_log_lam1, float* d_log_h0, void* stream);
+/* The same for a stateful KL / beta cell: initial_state [B][N] as in drnmf_cell_backward_stateful. */
+int32_t drnmf_cell_backward_ista_stateful(drnmf_handle_t h, const drnmf_cell_desc_t* d, const float* x,
+                                          const void* params, const float* log_h0, float beta,
+                                          const float* initial_state, const float* hall, const float* d_out,
+                                          const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                          void* bwd_workspace, size_t bwd_workspace_bytes, float* d_log_D,
+                                          float* d_log_alph, float* d_log_lam1, float* d_log_h0, void* stream);
 
 /* Measurement aid (bench.py only; no reference counterpart): the same backward with HIP events at
  * its phase boundaries; SYNCHRONISES the stream and returns

@@ -99,9 +99,9 @@ def test_simple_deep_rnn_config_surface():
     st = layers.SimpleDeepRNN(N, **dict(ok, stateful=True))      # stateful mode is supported
     with pytest.raises(ValueError):
         st.reset_states()                                        # batch size not known yet
-    # (training a stateful layer: the fused Euclidean path since round 5, tests/test_gpu_train.py; the KL / beta
-    # cell and the dense-matrix path still refuse)
-    stk = layers.SimpleDeepRNN(N, **dict(ok, stateful=True, divergence="kl"))
+    # (training a stateful layer: the fused paths since round 5, tests/test_gpu_train.py; the dense-matrix path
+    # still refuses)
+    stk = layers.SimpleDeepRNN(N, **dict(ok, stateful=True, activation="tanh"))
     stk.built = True
     with pytest.raises(NotImplementedError):
         stk.forward_train(None)
