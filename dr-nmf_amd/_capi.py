@@ -59,6 +59,8 @@ SIGNATURES = {
     "drnmf_dense_cell_backward": (_i32, [_vp, _DDP, _vp, _f32] + [_vp] * 13 + [_sz, _vp]),
     "drnmf_dense_cell_forward_dropout": (_i32, [_vp, _DDP, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drnmf_dense_cell_backward_dropout": (_i32, [_vp, _DDP, _vp, _f32] + [_vp] * 14 + [_sz, _vp]),
+    "drnmf_dense_cell_forward_dropout_stateful": (_i32, [_vp, _DDP, _vp, _f32] + [_vp] * 7 + [_sz, _vp]),
+    "drnmf_dense_cell_backward_stateful": (_i32, [_vp, _DDP, _vp, _f32] + [_vp] * 13 + [_sz, _vp]),
     "drnmf_padded_f": (_i32, [_i32]),
     "drnmf_head_forward": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp,
                                   _vp, _vp, _vp, _vp]),

@@ -203,6 +203,22 @@ dense_store_state_kernel(const float* __restrict__ state, float* __restrict__ ou
     out[i] = state[((size_t)(b >> 4) * (Np / 16) + (n >> 4)) * 256 + rp_pos(b & 15, n & 15)];
 }
 
+// With a recurrent dropout mask the state buffer holds prev_output * B_U; what a stateful layer carries to
+// its next batch is the output itself: a row's last frame repeats the output of its last valid one, a row
+// with no valid frame keeps the state it entered with.  (out may be init: same element, same thread.)
+__global__ void __launch_bounds__(256)
+dense_store_state_unmasked_kernel(const float* __restrict__ h_out, const float* init,
+                                  const float* __restrict__ h0, const unsigned char* __restrict__ valid,
+                                  float* out, int T, int N, int Bp, int out_width, int out_off) {
+    const int b = blockIdx.x;
+    int any = 0;
+    for (int t = threadIdx.x; t < T; t += 256) any |= valid[(size_t)t * Bp + b];
+    any = __syncthreads_or(any);
+    const float* last = h_out + ((size_t)b * T + (T - 1)) * out_width + out_off;
+    for (int n = threadIdx.x; n < N; n += 256)
+        out[(size_t)b * N + n] = any ? last[n] : (init ? init[(size_t)b * N + n] : h0[n]);
+}
+
 // Stacked matrix [U; S; W] of one layer -> cell_a operand packing.  Row i of the stack is
 // contraction index i: [0, Np) = p (U rows), then Np rows of h (S rows) when nS, then Fp rows of x
 // (W rows) when nW; padded rows / columns are zero.
@@ -339,9 +355,6 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
     if (rc) return rc;
     if (!x || !params || !h_out || !workspace || (!h0 && !initial_state))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_forward: NULL pointer argument");
-    if (drop_u && final_state)
-        DRNMF_FAIL(h, DRNMF_ERR_UNSUPPORTED, "dense_cell_forward: the state kept under recurrent dropout "
-                   "is the MASKED previous output; final_state is not available (training phase only)");
     const DenseLayout D = dense_layout(d);
     if (workspace_bytes < D.ws_total)
         DRNMF_FAIL(h, DRNMF_ERR_WORKSPACE, "dense_cell_forward: workspace %zu < required %zu",
@@ -484,7 +497,13 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
             for (; t < d->T; ++t) DRNMF_HIP(h, hipGraphLaunch(ex, stream));
         }
     }
-    if (final_state) {
+    if (final_state && drop_u) {
+        hipLaunchKernelGGL(dense_store_state_unmasked_kernel, dim3(d->B), dim3(256), 0, stream, h_out,
+                           initial_state, h0, valid, final_state, d->T, d->N, D.Bp,
+                           d->return_all_hidden ? d->N * K : d->N,
+                           d->return_all_hidden ? (K - 1) * d->N : 0);
+        DRNMF_HIP(h, hipGetLastError());
+    } else if (final_state) {
         const size_t tot = (size_t)d->B * d->N;
         hipLaunchKernelGGL(dense_store_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256),
                            0, stream, state + (size_t)(d->T & 1) * D.Bp * D.Np, final_state, d->B,
@@ -516,4 +535,18 @@ extern "C" int32_t drnmf_dense_cell_forward_dropout(drnmf_handle_t h, const drnm
     if (h && !drop_u) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_forward_dropout: NULL mask");
     return dense_forward_impl(h, d, x, mask_value, params, h0, nullptr, nullptr, h_out, workspace,
                               workspace_bytes, stream_, drop_u);
+}
+
+// The same for a STATEFUL layer in its training phase (Keras stateful=True under fit, custom_layers.py:
+// 296-318 with 377-384): the carried state enters as in drnmf_dense_cell_forward (B_U multiplies it where the
+// U_k products read it; what final_state receives is the unmasked output of each row's last valid frame).
+extern "C" int32_t drnmf_dense_cell_forward_dropout_stateful(
+    drnmf_handle_t h, const drnmf_dense_desc_t* d, const float* x, float mask_value, const void* params,
+    const float* h0, const float* initial_state, float* final_state, const float* drop_u, float* h_out,
+    void* workspace, size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
+    if (h && !drop_u)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_forward_dropout_stateful: NULL mask");
+    return dense_forward_impl(h, d, x, mask_value, params, h0, initial_state, final_state, h_out,
+                              workspace, workspace_bytes, stream_, drop_u);
 }

@@ -135,16 +135,19 @@ struct EpiDenseBwd {
     }
 };
 
-// P_all[bt] = state entering frame t = previous output once a valid frame was seen, else h0
+// P_all[bt] = state entering frame t = previous output once a valid frame was seen, else h0 (stateful:
+// the state init[b] the row entered the batch with)
 __global__ void __launch_bounds__(256)
 dense_gather_p_kernel(const float* __restrict__ hall, const float* __restrict__ h0,
                       const unsigned char* __restrict__ seen, float* __restrict__ P, int64_t BT,
-                      int N, int K, int T, const float* __restrict__ drop) {
+                      int N, int K, int T, const float* __restrict__ drop,
+                      const float* __restrict__ init) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)BT * N) return;
     const int64_t bt = (int64_t)(i / N);
     const int n = (int)(i % N);
-    const float v = seen[bt] ? hall[(size_t)(bt - 1) * K * N + (size_t)(K - 1) * N + n] : h0[n];
+    const float v = seen[bt] ? hall[(size_t)(bt - 1) * K * N + (size_t)(K - 1) * N + n]
+                             : (init ? init[(size_t)(bt / T) * N + n] : h0[n]);
     P[i] = drop ? v * drop[(size_t)(bt / T) * N + n] : v;      // (what U_k multiplied: the masked state)
 }
 
@@ -231,7 +234,8 @@ static int32_t dense_backward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d
                                              const float* d_out, float* dU, float* dS, float* dW,
                                              float* db, float* dh0, void* workspace,
                                              size_t workspace_bytes, void* stream_,
-                                             const float* drop_u) {
+                                             const float* drop_u,
+                                             const float* initial_state = nullptr) {
     (void)b;
     if (!h) return DRNMF_ERR_INVALID_ARG;
     if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->N <= 0 || d->K <= 0)
@@ -240,7 +244,8 @@ static int32_t dense_backward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_backward: unknown activation %d",
                    d->activation);
     const int B = d->B, T = d->T, F = d->F, N = d->N, K = d->K;
-    if (!x || !U || !h0 || !hall || !d_out || !dU || !db || !dh0 || !workspace ||
+    if (!x || !U || (!h0 && !initial_state) || !hall || !d_out || !dU || !db ||
+        (!dh0 && !initial_state) || !workspace ||
         (K > 1 && (!S || !dS)) || (d->connect_input && (!W || !dW)))
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_backward: NULL pointer argument");
     if (workspace_bytes < drnmf_dense_backward_workspace_bytes(d))
@@ -291,14 +296,17 @@ static int32_t dense_backward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d
             DRNMF_HIP(h, gemm::launch(g, e, stream));
         }
     }
-    hipLaunchKernelGGL(dense_rowsum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, G_st, dh0,
-                       B, N, drop_u);
+    if (dh0) {
+        if (initial_state) DRNMF_HIP(h, hipMemsetAsync(dh0, 0, (size_t)N * 4, stream));
+        else hipLaunchKernelGGL(dense_rowsum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, G_st,
+                                dh0, B, N, drop_u);
+    }
 
     // ---- time-batched weight gradients -----------------------------------------------------------
     {
         const size_t tot = (size_t)BT * N;
         hipLaunchKernelGGL(dense_gather_p_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                           stream, hall, h0, seen, P_all, BT, N, K, T, drop_u);
+                           stream, hall, h0, seen, P_all, BT, N, K, T, drop_u, initial_state);
     }
     int splits = DB_SPLITS;
     while (splits > 1 && BT / splits < 64) splits >>= 1;
@@ -351,4 +359,20 @@ extern "C" int32_t drnmf_dense_cell_backward_dropout(
     if (h && !drop_u) DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_backward_dropout: NULL mask");
     return dense_backward_impl(h, d, x, mask_value, U, S, W, b, h0, hall, d_out, dU, dS, dW, db, dh0,
                                workspace, workspace_bytes, stream_, drop_u);
+}
+
+// BPTT of a STATEFUL layer's batch (Keras stateful=True, custom_layers.py:296-318): initial_state [B][N] is
+// the state the forward entered with (drnmf_dense_cell_forward / _forward_dropout_stateful), a constant of
+// the gradient -- it takes h0's place wherever dU_k contracts the state a row's first valid frame saw, and
+// there is no d h0.  drop_u may be NULL (no recurrent dropout).
+extern "C" int32_t drnmf_dense_cell_backward_stateful(
+    drnmf_handle_t h, const drnmf_dense_desc_t* d, const float* x, float mask_value, const float* U,
+    const float* S, const float* W, const float* b, const float* initial_state, const float* drop_u,
+    const float* hall, const float* d_out, float* dU, float* dS, float* dW, float* db,
+    void* workspace, size_t workspace_bytes, void* stream_) {
+    DRNMF_LOCK(h);
+    if (h && !initial_state)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "dense_cell_backward_stateful: NULL initial_state");
+    return dense_backward_impl(h, d, x, mask_value, U, S, W, b, nullptr, hall, d_out, dU, dS, dW, db,
+                               nullptr, workspace, workspace_bytes, stream_, drop_u, initial_state);
 }

@@ -602,8 +602,6 @@ class SimpleDeepRNN(_Layer):
         if not self.built:
             self.build(tuple(x.shape))
         if self._dense_now or getattr(self, '_train_dense', False) or self.dropout_U:
-            if self.stateful:
-                raise NotImplementedError('training a stateful layer on the dense-matrix path is not implemented')
             return self._forward_train_dense(x, mask_value)
         B, T, F = x.shape
         self.prepare(B, T)
@@ -723,8 +721,17 @@ class SimpleDeepRNN(_Layer):
                                                   device=x.device)) / keep
             else:
                 drop = torch.as_tensor(drop, dtype=torch.float32, device=x.device).contiguous()
+        self._train_init = None
+        if self.stateful:
+            # the carried state enters as a constant of the gradient (custom_layers.py:296-318), as on
+            # the fused path (forward_train)
+            if getattr(self, 'states', None) is None or self.states[0] is None or \
+                    tuple(self.states[0].shape) != (B, self.output_dim):
+                self.states = [torch.zeros((B, self.output_dim), dtype=torch.float32, device=x.device)]
+            self._train_init = self.states[0].clone()
         hall = ops.dense_cell_forward(x, mask_value, block, desc, c(h0), workspace=self._ws[key],
-                                      drop_u=drop)
+                                      drop_u=drop, initial_state=self._train_init,
+                                      final_state=self.states[0] if self.stateful else None)
         self._train_ctx = ('dense', leaves, (U, S, W, b, h0), mask_value, drop)
         return hall
 
@@ -737,7 +744,8 @@ class SimpleDeepRNN(_Layer):
                                    self.activation, all_hidden)
         c = lambda v: None if v is None else v.detach().contiguous()
         g = ops.dense_cell_backward(x, mask_value, desc, c(U), c(S), c(W), c(b), c(h0), hall, d_out,
-                                    workspace=getattr(self, '_dense_bwd_ws', None), drop_u=drop)
+                                    workspace=getattr(self, '_dense_bwd_ws', None), drop_u=drop,
+                                    initial_state=getattr(self, '_train_init', None))
         self._dense_bwd_ws = g['workspace']
         outs, grads = [], []
         for t, gt in ((U, g['dU']), (S, g['dS']), (W, g['dW']), (b, g['db']), (h0, g['dh0'])):

@@ -220,9 +220,16 @@ def dense_cell_forward(x, mask_value, params, desc, h0, out=None, workspace=None
                                or not st.is_contiguous()):
             raise ValueError("states must be contiguous float32 (B,N) tensors")
     mv = float("nan") if mask_value is None else float(mask_value)
+    if drop_u is not None and (initial_state is not None or final_state is not None):
+        # a stateful layer in its training phase (custom_layers.py:296-318 with 377-384)
+        drop_u = _check_drop_u(drop_u, desc)
+        rc = L.drnmf_dense_cell_forward_dropout_stateful(
+            h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params), _capi.ptr(h0),
+            _capi.ptr(initial_state), _capi.ptr(final_state), _capi.ptr(drop_u), _capi.ptr(out),
+            _capi.ptr(workspace), workspace.numel(), _stream())
+        _capi.check(rc, h, "drnmf_dense_cell_forward_dropout_stateful")
+        return out
     if drop_u is not None:
-        if initial_state is not None or final_state is not None:
-            raise ValueError("recurrent dropout belongs to the training phase: no stateful pointers")
         drop_u = _check_drop_u(drop_u, desc)
         rc = L.drnmf_dense_cell_forward_dropout(h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(params),
                                                 _capi.ptr(h0), _capi.ptr(drop_u), _capi.ptr(out),
@@ -238,11 +245,12 @@ def dense_cell_forward(x, mask_value, params, desc, h0, out=None, workspace=None
 
 
 def dense_cell_backward(x, mask_value, desc, U, S, W, b, h0, hall, d_out, workspace=None,
-                        drop_u=None):
+                        drop_u=None, initial_state=None):
     """BPTT of the dense step (drnmf_dense_cell_backward): hall [B,T,K*N] is the forward's
     all-hidden output, d_out the gradient w.r.t. the returned output ([B,T,N], or [B,T,K*N] when
     desc.return_all_hidden).  Returns dict(dU [K,N,N], dS [K-1,N,N] | None, dW [K,F,N] | None,
-    db [K,N], dh0 [N])."""
+    db [K,N], dh0 [N]).  initial_state [B,N]: the state a stateful layer's batch entered with
+    (drnmf_dense_cell_backward_stateful: a constant of the gradient, dh0 = 0)."""
     L = _capi.lib()
     h = _capi.handle(_dev_index(x))
     B, T, F, N, K = desc.B, desc.T, desc.F, desc.N, desc.K
@@ -267,6 +275,21 @@ def dense_cell_backward(x, mask_value, desc, U, S, W, b, h0, hall, d_out, worksp
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     mv = float("nan") if mask_value is None else float(mask_value)
+    if initial_state is not None:
+        if tuple(initial_state.shape) != (B, N) or initial_state.dtype != torch.float32 or \
+                not initial_state.is_contiguous():
+            raise ValueError("initial_state must be a contiguous float32 (B,N) tensor")
+        if drop_u is not None:
+            drop_u = _check_drop_u(drop_u, desc)
+        rc = L.drnmf_dense_cell_backward_stateful(
+            h, C.byref(desc), _capi.ptr(x), mv, _capi.ptr(U), _capi.ptr(S), _capi.ptr(W), _capi.ptr(b),
+            _capi.ptr(initial_state), _capi.ptr(drop_u), _capi.ptr(hall), _capi.ptr(d_out),
+            _capi.ptr(g["dU"]), _capi.ptr(g["dS"]), _capi.ptr(g["dW"]), _capi.ptr(g["db"]),
+            _capi.ptr(workspace), workspace.numel(), _stream())
+        _capi.check(rc, h, "drnmf_dense_cell_backward_stateful")
+        g["dh0"].zero_()
+        g["workspace"] = workspace
+        return g
     if drop_u is not None:
         drop_u = _check_drop_u(drop_u, desc)
         rc = L.drnmf_dense_cell_backward_dropout(

@@ -263,6 +263,24 @@ int32_t drnmf_dense_cell_backward_dropout(drnmf_handle_t h, const drnmf_dense_de
                                           const float* d_out, float* dU, float* dS, float* dW,
                                           float* db, float* dh0, void* workspace,
                                           size_t workspace_bytes, void* stream);
+/* Keras stateful=True in the training phase (custom_layers.py:296-318): the state the previous batch left
+ * enters this one as a CONSTANT of the gradient.  The forward without dropout is drnmf_dense_cell_forward
+ * with its stateful pointers; _forward_dropout_stateful adds them to the dropout form (final_state receives
+ * the output of each row's last valid frame, not its masked copy; it may be initial_state).  The BPTT takes
+ * the entering state [B][N] in h0's place and has no d h0; drop_u may be NULL there. */
+int32_t drnmf_dense_cell_forward_dropout_stateful(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                                  const float* x, float mask_value, const void* params,
+                                                  const float* h0, const float* initial_state,
+                                                  float* final_state, const float* drop_u,
+                                                  float* h_out, void* workspace,
+                                                  size_t workspace_bytes, void* stream);
+int32_t drnmf_dense_cell_backward_stateful(drnmf_handle_t h, const drnmf_dense_desc_t* d,
+                                           const float* x, float mask_value, const float* U,
+                                           const float* S, const float* W, const float* b,
+                                           const float* initial_state, const float* drop_u,
+                                           const float* hall, const float* d_out, float* dU,
+                                           float* dS, float* dW, float* db, void* workspace,
+                                           size_t workspace_bytes, void* stream);
 
 /* ---- mask head: replaces the H_clean/H_noise slices, TimeDistributed(DenseNonNegW) x2
  * (custom_layers.py:23-29; enhance.py:277-292), the optional 'square' transform

@@ -94,18 +94,21 @@ _ACT = {
 
 
 def dense_cell(x, Uk, Sk, Wk, bk, h0, mask_value=-1.0, return_all_hidden=False,
-               connect_input=True, activation='relu', drop_u=None):
+               connect_input=True, activation='relu', drop_u=None, initial_state=None,
+               return_state=False):
     """torch twin of oracle.cell_forward_dense (custom_layers.py:343-375 under K.rnn's masked scan),
     for reference gradients w.r.t. the step's matrices.  Uk [K,N,N], Sk [K-1,N,N], Wk [K,F,N],
     bk [K,N], h0 [N] = the initial state itself.  drop_u [B,N]: the recurrent dropout mask B_U of
-    the training phase, multiplying prev_output in every U_k product (custom_layers.py:361, 377-384)."""
+    the training phase, multiplying prev_output in every U_k product (custom_layers.py:361, 377-384).
+    initial_state [B,N]: the state a stateful layer's batch enters with (custom_layers.py:296-318; a
+    constant: pass it detached); return_state: also return the state the batch leaves."""
     B, T, F = x.shape
     K, N = Uk.shape[0], Uk.shape[1]
     act = _ACT[activation]
     valid = (x != mask_value).any(-1)
     xm = x * valid[..., None].to(x.dtype)
     width = K * N if return_all_hidden else N
-    state = h0[None, :].expand(B, N)
+    state = h0[None, :].expand(B, N) if initial_state is None else initial_state
     out_prev = torch.zeros(B, width, dtype=x.dtype)
     outs = []
     for t in range(T):
@@ -123,4 +126,6 @@ def dense_cell(x, Uk, Sk, Wk, bk, h0, mask_value=-1.0, return_all_hidden=False,
         out_prev = torch.where(v, out, out_prev)
         state = torch.where(v, hidden[-1], state)
         outs.append(out_prev)
+    if return_state:
+        return torch.stack(outs, 1), state
     return torch.stack(outs, 1)

@@ -29,6 +29,7 @@ fn_t drnmf_all_exports[] = {
     REF(drnmf_comm_destroy), REF(drnmf_comm_info), REF(drnmf_allreduce_grads),
     REF(drnmf_broadcast_params), REF(drnmf_cell_launches_per_frame),
     REF(drnmf_dense_cell_forward_dropout), REF(drnmf_dense_cell_backward_dropout),
+    REF(drnmf_dense_cell_forward_dropout_stateful), REF(drnmf_dense_cell_backward_stateful),
 };
 
 /* Layout of the one struct that crosses the ABI in DEVICE memory, built by the host language

@@ -581,3 +581,61 @@ def test_recurrent_dropout_trains_on_the_dense_path(dev):
     assert np.all(np.isfinite(model.predict_on_batch(P["X"])))
     with pytest.raises(ValueError):
         layers.SimpleDeepRNN(N, dropout_U=1.5, device=dev)
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_stateful_layer_trains_on_the_dense_path(dev, dropout):
+    """Keras stateful=True under fit on the dense-matrix path (custom_layers.py:296-318; with dropout_U
+    377-384): every batch enters with the state the previous one left -- zeros before the first --
+    as a constant of the gradient.  Two consecutive batches: outputs, carried states and every gradient
+    against torch fp64 autograd of the oracle's op graph started from the same entering state; a row
+    without a valid frame keeps its state; with a dropout mask the state carried on is the output, not
+    its masked copy."""
+    from drnmf_amd import layers
+    from oracle import drnmf_torch_ref as R
+    B, T, F, N, K = 5, 6, 12, 16, 3
+    rng = np.random.default_rng(19)
+    A = (0.2 * rng.standard_normal((F, N))).astype(np.float32)
+    c = (0.1 * rng.standard_normal((N,))).astype(np.float32)
+    maps = {"W": lambda a: a["A"], "b": lambda a: a["c"]}
+    np.random.seed(4)
+    cell = layers.SimpleDeepRNN(N, activation="tanh", K_layers=K, alt_params={"A": A, "c": c},
+                                keys_trainable=["A", "c"], maps_from_alt=maps,
+                                dropout_U=0.4 if dropout else 0.0, flag_connect_input_to_layers=True,
+                                flag_nonnegative=False, return_sequences=True, stateful=True, device=dev)
+    X1, X2 = _ragged_x(rng, B, T, F), _ragged_x(rng, B, T, F)
+    X2[2] = -1.0                                        # a row with no valid frame in the second batch
+    cell.build((B, T, F))
+    names = [n[len(cell.name) + 1:] for n in cell.weight_names]
+    w = dict(zip(names, cell.get_weights()))
+    mask = ((rng.random((B, N)) < 0.6) / 0.6).astype(np.float32) if dropout else None
+    Rw = rng.standard_normal((B, T, N)).astype(np.float32)
+    td = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    state = torch.zeros((B, N), dtype=torch.float64)
+    kept = []
+    for X in (X1, X2):
+        x = torch.from_numpy(X).to(dev)
+        cell._drop_u_mask = mask
+        hall = cell.forward_train(x, mask_value=-1.)
+        g = cell.backward(x, hall, torch.from_numpy(Rw).to(dev))["by_name"]
+        torch.cuda.synchronize()
+        L = {n: td(w[n]) for n in names}
+        out, new_state = R.dense_cell(
+            torch.tensor(X.astype(np.float64)), torch.stack([L["U_%d" % k] for k in range(K)]),
+            torch.stack([L["S_%dto%d" % (k - 1, k)] for k in range(1, K)]), torch.stack([L["A"]] * K),
+            torch.stack([L["c"]] * K), L["h0"], activation="tanh",
+            drop_u=None if mask is None else torch.tensor(mask.astype(np.float64)),
+            initial_state=state, return_state=True)
+        _check(hall[..., (K - 1) * N:].cpu().numpy(), out.detach().numpy())
+        _check(cell.states[0].cpu().numpy(), new_state.detach().numpy())
+        (out * torch.tensor(Rw.astype(np.float64))).sum().backward()
+        for n, gv in g.items():
+            want = L[n].grad.numpy() if L[n].grad is not None else np.zeros_like(w[n])
+            err = np.max(np.abs(gv.cpu().numpy() - want)) / max(np.max(np.abs(want)), 1e-30)
+            if n == "h0":                                   # the entering state replaces it: no gradient
+                assert not np.any(gv.cpu().numpy()) and not np.any(want)
+            else:
+                assert err <= G_TOL, "%s: max|dg|/max|g| = %.3e" % (n, err)
+        state = new_state.detach()
+        kept.append(cell.states[0].cpu().numpy()[2].copy())
+    assert np.array_equal(kept[0], kept[1]) and np.any(kept[0] != 0)

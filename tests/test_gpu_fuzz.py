@@ -50,6 +50,34 @@ def test_fuzz_cell_forward(dev):
             (dict(B=B, T=T, F=F, r=r, K=K, untied=untied, ua=ua, ragged=ragged, ah=ah, it=it), err)
 
 
+def test_fuzz_cell_forward_fp16_operands(dev):
+    """The fp16-operand kernels (one packing, transposed LDS reads in cell_a, the spare waves' prefetch of
+    the next dictionary and republished x_t) on both sides of every tile boundary, against the oracle's
+    emulation of the same rounding points; tied dictionaries take the path without the prefetch."""
+    rng = np.random.default_rng(516)
+    for it in range(48):
+        B = int(rng.choice([1, 3, 15, 16, 17, 33, 48, 65, 80]))
+        T = int(rng.integers(1, 6))
+        F = int(rng.choice([5, 16, 17, 18, 31, 33, 34, 47, 49, 64, 65, 66, 97, 129, 257]))
+        r = int(rng.choice([2, 5, 8, 15, 16, 17, 31, 33, 50, 64, 100, 144]))
+        K = int(rng.integers(1, 7))
+        untied = [(), ("log_D",), ("log_D", "log_alph"),
+                  ("log_D", "log_alph", "log_lam1")][int(rng.integers(0, 4))]
+        ragged, ah = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        P, alt, labels, N = TP._problem(B, T, F, r, K, untied=untied, ragged=ragged, seed=100 + it)
+        h, _, _ = TP._run_cell(dev, P, alt, labels, N, K, return_all_hidden=ah, operand_f16=True)
+        lay, u = O.maps_factored(alt, labels, K), O.u_scalars(alt)
+        emu = O.cell_forward_factored(P["X"], lay, u, P["log_h0"], operand_dtype=np.float16,
+                                      return_all_hidden=ah)
+        scale = np.max(np.abs(emu))
+        if scale < 1e-3:
+            continue
+        cfg = dict(B=B, T=T, F=F, r=r, K=K, untied=untied, ragged=ragged, ah=ah, it=it)
+        assert np.all(np.isfinite(h)), cfg
+        assert np.max(np.abs(h - emu)) / scale <= 2e-3, (cfg, np.max(np.abs(h - emu)) / scale)
+        assert np.sqrt(np.mean((h - emu) ** 2)) / scale <= 1e-4, cfg
+
+
 def test_fuzz_gradients(dev):
     rng = np.random.default_rng(7)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)

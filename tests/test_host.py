@@ -99,12 +99,7 @@ def test_simple_deep_rnn_config_surface():
     st = layers.SimpleDeepRNN(N, **dict(ok, stateful=True))      # stateful mode is supported
     with pytest.raises(ValueError):
         st.reset_states()                                        # batch size not known yet
-    # (training a stateful layer: the fused paths since round 5, tests/test_gpu_train.py; the dense-matrix path
-    # still refuses)
-    stk = layers.SimpleDeepRNN(N, **dict(ok, stateful=True, activation="tanh"))
-    stk.built = True
-    with pytest.raises(NotImplementedError):
-        stk.forward_train(None)
+    # (training a stateful layer: tests/test_gpu_train.py and tests/test_gpu_dense.py)
     # configurations outside build_unfolded_snmf's are accepted (general dense-matrix kernel,
     # forward only) ...
     for generic in (dict(activation="tanh"), dict(flag_nonnegative=False),
