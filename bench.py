@@ -233,7 +233,7 @@ def train_bench(torch, dev, steps=20, warmup=5, shape=(32, 500, 257, 1000, 5), r
             "loss_first": float(losses[0]), "loss_last": float(losses[-1])}
 
 
-def slab_bench(torch, dev, F, r, K, T, slab=250):
+def slab_bench(torch, dev, F, r, K, T, slab=250, host_slabs=0):
     """The reference predicts in slabs of 250 utterances (enhance.py:1189-1193): the same forward
     (cell + mask head) on one slab, where the row-blocked kernels apply."""
     from drnmf_amd import layers, ops
@@ -260,6 +260,27 @@ def slab_bench(torch, dev, F, r, K, T, slab=250):
     tf = slab * T * 4.0 * F * N * K / sec / 1e12
     out = {"utterances": slab, "frames_per_s": slab * T / sec, "ms_per_slab": sec * 1e3,
            "tflops": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS}
+    if host_slabs:
+        # host arrays in, host arrays out (never `value`): the reference's loop of predict_on_batch calls
+        # (enhance.py:1189-1193) against model.predict, whose copies ride two side streams
+        import time
+        import numpy as np
+        xh = np.concatenate([X.cpu().numpy()] * host_slabs)
+        model.predict(xh[:slab + 1], batch_size=slab)              # both sets of staging buffers, pinned pages
+        t0 = time.perf_counter()
+        kept = [model.predict_on_batch(xh[s0:s0 + slab]) for s0 in range(0, xh.shape[0], slab)]
+        t_loop = time.perf_counter() - t0
+        del kept                                                   # (unmapping GBs of results is not timed)
+        t0 = time.perf_counter()
+        kept = model.predict(xh, batch_size=slab)
+        t_pipe = time.perf_counter() - t0
+        del kept
+        out["host_arrays_in_and_out"] = {
+            "slabs": host_slabs, "frames_per_s_predict_on_batch_loop": xh.shape[0] * T / t_loop,
+            "frames_per_s_predict": xh.shape[0] * T / t_pipe,
+            "note": "PCIe-inclusive, wall clock, pageable numpy in and out, result allocation included; "
+                    "both stage through pinned buffers, predict also sends slab s+1 while slab s computes"}
+        del xh
     del model, X, h_buf, m_buf
     torch.cuda.empty_cache()
     return out
@@ -1093,7 +1114,7 @@ def main():
             extra["dictionary_training"] = safe(snmf_train_bench, torch, dev, F, r)
         extra["config1_single_utterance"] = safe(config1_bench, torch, dev)
         if not a.no_slab:
-            extra["inference_slab_250"] = safe(slab_bench, torch, dev, F, r, K, T)
+            extra["inference_slab_250"] = safe(slab_bench, torch, dev, F, r, K, T, host_slabs=3)
             # the same forward (cell + mask head) over batch sizes: from 128 rows on the batch runs as
             # independent sub-batches on side streams (csrc/cell_shared.h Workspace::split)
             sweep = []

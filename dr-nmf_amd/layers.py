@@ -1048,9 +1048,79 @@ class UnfoldedSNMFModel(object):
         return (mask, h) if want_hidden else mask
 
     def predict_on_batch(self, x):
-        xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.cell.device)
-        out = self.forward(xt).cpu().numpy()
-        ops.check_status(self.cell.device)      # (the copy synchronised: a chain that timed out raises HERE)
+        # (one slab of `predict`: pinned staging both ways -- a pageable device-to-host copy runs at a sixth
+        # of the link rate; a chain that timed out raises after the copy has synchronised)
+        return self.predict(x, batch_size=max(1, len(x)))
+
+    def predict(self, x, batch_size=250, verbose=0):
+        """keras Model.predict(x, batch_size): enhance.py's inference loop (1185-1193 validation, 1215-1223
+        test: `predict_on_batch` over slabs of 250 utterances) as ONE call.  x [n,T,F] numpy -> masks
+        [n,T,F] numpy, equal bit for bit to that loop.  Slab s+1 goes up and slab s-1's masks come down
+        on two copy streams, through pinned staging buffers the model keeps, while slab s computes: the
+        PCIe time of a slab hides behind the chain of the next."""
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim != 3:
+            raise ValueError('predict: x must be (n, T, F), got shape %s' % (x.shape,))
+        n, T, F = x.shape
+        bs = int(batch_size)
+        if bs <= 0:
+            raise ValueError('predict: batch_size must be positive')
+        dev = self.cell.device
+        Fo = int(self.clean.kernel.shape[1])
+        out = np.empty((n, T, Fo), dtype=np.float32)
+        if n == 0:
+            return out
+        bs = min(bs, n)
+        nbuf = 1 if n <= bs else 2
+        pipe = getattr(self, '_predict_pipe', None)
+        if pipe is None or pipe['shape'][:4] != (bs, T, F, Fo) or pipe['shape'][4] < nbuf:
+            pin = lambda w: [torch.empty((bs, T, w), dtype=torch.float32, pin_memory=True) for _ in range(nbuf)]
+            self._predict_pipe = None                # (the old buffers go before the new ones come)
+            pipe = dict(shape=(bs, T, F, Fo, nbuf), stage=pin(F), back=pin(Fo),
+                        xd=[torch.empty((bs, T, F), dtype=torch.float32, device=dev) for _ in range(nbuf)],
+                        up=torch.cuda.Stream(dev), down=torch.cuda.Stream(dev))
+            self._predict_pipe = pipe
+        main = torch.cuda.current_stream(dev)
+        ev = lambda: [torch.cuda.Event(), torch.cuda.Event()]
+        ev_up, ev_comp, ev_down = ev(), ev(), ev()
+        xs, res = torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(out)
+        slabs = [(lo, min(lo + bs, n)) for lo in range(0, n, bs)]
+
+        def collect(s):                              # slab s: pinned staging -> the caller's array
+            lo, hi = slabs[s]
+            ev_down[s & 1].synchronize()
+            res[lo:hi].copy_(pipe['back'][s & 1][:hi - lo])
+
+        def send(s):                                 # slab s: the caller's array -> pinned staging -> device
+            lo, hi = slabs[s]
+            j, b = s & 1, hi - lo
+            if s >= 2:
+                ev_up[j].synchronize()               # slab s-2 has left this staging buffer
+            pipe['stage'][j][:b].copy_(xs[lo:hi])
+            with torch.cuda.stream(pipe['up']):
+                if s >= 2:
+                    pipe['up'].wait_event(ev_comp[j])    # ... and its chain has read xd[j]
+                pipe['xd'][j][:b].copy_(pipe['stage'][j][:b], non_blocking=True)
+                ev_up[j].record(pipe['up'])
+        send(0)
+        for s, (lo, hi) in enumerate(slabs):
+            j, b = s & 1, hi - lo
+            if s + 1 < len(slabs):
+                send(s + 1)      # one slab ahead: enqueueing a slab's launches keeps this thread busy for
+                                 # about as long as the device needs to run them
+            main.wait_event(ev_up[j])
+            mask = self.forward(pipe['xd'][j][:b])
+            ev_comp[j].record(main)
+            with torch.cuda.stream(pipe['down']):
+                pipe['down'].wait_event(ev_comp[j])
+                pipe['back'][j][:b].copy_(mask, non_blocking=True)
+                ev_down[j].record(pipe['down'])
+            mask.record_stream(pipe['down'])
+            if s >= 1:
+                collect(s - 1)
+        collect(len(slabs) - 1)
+        main.synchronize()
+        ops.check_status(dev)
         return out
 
     __call__ = forward
@@ -1621,6 +1691,12 @@ class SNMFCostPretrainModel(UnfoldedSNMFModel):
         out = [o.cpu().numpy() for o in self.forward(xt)]
         ops.check_status(self.cell.device)      # (the copies synchronised: a chain that timed out raises HERE)
         return out
+
+    def predict(self, x, batch_size=250, verbose=0):
+        """Two outputs per slab (pretraining only: the plain loop, no copy streams)."""
+        bs = max(1, int(batch_size))
+        parts = [self.predict_on_batch(x[s:s + bs]) for s in range(0, max(len(x), 1), bs)]
+        return [np.concatenate([p[i] for p in parts]) for i in range(2)]
 
     def loss_and_grads(self, x, y, sample_weight, live=True):
         cell = self.cell

@@ -231,6 +231,15 @@ def test_model_predict_on_batch_matches_oracle(dev, square):
     assert irm.shape == (B, T, F)
     mse = np.mean((irm - ref) ** 2)
     assert mse <= MASK_MSE_TOL, "mask MSE %.3e" % mse
+    # keras Model.predict = the slab loop of enhance.py:1189-1193 in one call (copies on their own
+    # streams): the same bits as that loop, for a slab size that divides n, one that does not, one >= n
+    for bs in (2, 4, 250):
+        loop = np.concatenate([model.forward(torch.from_numpy(P["X"][s:s + bs]).to(dev)).cpu().numpy()
+                               for s in range(0, B, bs)])
+        assert np.array_equal(model.predict(P["X"], batch_size=bs), loop), bs
+        assert np.array_equal(np.concatenate([model.predict_on_batch(P["X"][s:s + bs])
+                                              for s in range(0, B, bs)]), loop), bs
+    assert model.predict(P["X"][:0]).shape == (0, T, F)
     # layer indices enhance.py:311-315 relies on
     assert model.layers[-5 if square else -3].name == "clean_est"
     assert model.layers[-4 if square else -2].name == "noise_est"
