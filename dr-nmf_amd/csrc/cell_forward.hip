@@ -805,9 +805,7 @@ template <int KS, int RB, bool AH, bool HALF>
 void* a_func_g(int per_wave, bool first, bool last, bool qred = false) {
     // G operand slots; operand registers G * (4*KS*RB + 8)
     if (per_wave <= 2) return a_func<2, KS, RB, AH, HALF>(first, last, qred);
-    if (HALF && per_wave >= 8 && tune_env("DRNMF_G8"))   // tuning aid: 8 operand slots
-        return a_func<8, KS, RB, AH, HALF>(first, last, qred);
-    // (8 slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch)
+    // (8 operand slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch; not instantiated)
     // two groups per wave (F = 513), one row block, fp32: epilogue operand loads behind the first chunk
     bool late = RB == 1 && !HALF && per_wave > 4 && per_wave <= 8;
     if (const char* e = tune_env("DRNMF_LATE"))   // tuning aid: 0 = never, 2 = whenever instantiated

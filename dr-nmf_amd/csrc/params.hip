@@ -20,8 +20,8 @@ char g_create_err[512] = {0};
 namespace {
 const char* const kTuneNames[] = {
     "DRNMF_ABLATE", "DRNMF_ABLATE_A", "DRNMF_ABLATE_B", "DRNMF_CP_FULL", "DRNMF_DENSE_NW", "DRNMF_FPG",
-    "DRNMF_G8", "DRNMF_GRAM", "DRNMF_KS", "DRNMF_LATE", "DRNMF_NO_ALLB", "DRNMF_NO_GRAPH",
-    "DRNMF_PERSIST", "DRNMF_PERSIST_FAULT", "DRNMF_RB", "DRNMF_RBA", "DRNMF_BIG", "DRNMF_SPLIT",
+    "DRNMF_GRAM", "DRNMF_KS", "DRNMF_LATE", "DRNMF_NO_ALLB", "DRNMF_NO_GRAPH",
+    "DRNMF_PERSIST", "DRNMF_PERSIST_FAULT", "DRNMF_RB", "DRNMF_RBA", "DRNMF_SPLIT",
     "DRNMF_THIN", "DRNMF_PF", "DRNMF_PF_SLEEP"};
 std::mutex g_tune_mu;
 // (values are never erased or overwritten in place: a pointer handed out stays valid for the
