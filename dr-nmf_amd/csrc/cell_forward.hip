@@ -52,7 +52,7 @@ struct CellAArgs {
     float* h_out;            // [Bp][Np]  this layer's h (last layer: the state)
     f16* h16_out;            // fp16 mode: the same h as Hp16, cell_b's MFMA operand (cell_shared.h)
     float* state;            // [Bp][Np]
-    float* rs_part;          // [2][numA][Bp] row sums of the state per atom block, by frame parity
+    float* rs_part;          // [2][Bp][numA rounded up to 4] row sums of the state per atom block, by frame parity
     float* psum;             // [Bp]  sum(p) of the current frame
     float* psum_all;         // [T][Bp] the same, kept for the backward pass
     const unsigned char* valid;  // [T][Bp]
@@ -347,18 +347,23 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
         if (IS_FIRST) {
             // sum(p) = sum over atom blocks of the row sums left by the previous frame's last
             // layer, added in block order by 16 lanes + a fixed shuffle tree (deterministic)
-            const float* rp = a.rs_part + (size_t)(t & 1) * a.numA * a.Bp + rg;
+            // A row's partials are contiguous ([parity][row][atom block], padded to a multiple of four with
+            // zeros): 16-byte loads, 16 lanes cover 64 blocks.  (They used to lie [block][row]: one 4-byte load
+            // per block and 16 cache lines per load instruction -- at N = 8000, 250 blocks, that made this
+            // launch 17.3 us against the other layers' 8.9; N = 2000: 6.2 against 5.3.)
+            const int numAp = (a.numA + 3) & ~3;
+            const float* rp = a.rs_part + ((size_t)(t & 1) * a.Bp + rg) * numAp;
             float s = 0.f;
-            // (eight loads in flight, added in index order: a plain loop is one dependent L2 round trip per term)
-            for (int b0 = (tid & 15); b0 < a.numA; b0 += 128) {
-                float v8[8];
+            for (int b0 = (tid & 15) * 4; b0 < numAp; b0 += 256) {
+                f32x4 v4[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int b2 = b0 + 16 * u;
-                    v8[u] = rp[(size_t)(b2 < a.numA ? b2 : b0) * a.Bp];
+                for (int u = 0; u < 4; ++u) {
+                    const int b2 = b0 + 64 * u;
+                    v4[u] = *(const f32x4*)(rp + (b2 < numAp ? b2 : b0));
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s += (b0 + 16 * u < a.numA) ? v8[u] : 0.f;
+                for (int u = 0; u < 4; ++u)
+                    s += (b0 + 64 * u < numAp) ? (v4[u][0] + v4[u][1]) + (v4[u][2] + v4[u][3]) : 0.f;
             }
             s = row16_sum(s);
             ps[rb] = s;
@@ -639,7 +644,7 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
             float s = st[0] + st[1];
             s = row16_sum(s);
             if ((tid & 15) == 0)
-                a.rs_part[((size_t)((t + 1) & 1) * a.numA + ab) * a.Bp + rg] = s;
+                a.rs_part[((size_t)((t + 1) & 1) * a.Bp + rg) * ((a.numA + 3) & ~3) + ab] = s;
         } else {
             st_xchg(a.h_out + hoff, hn);
             if (HALF)   // Hp16 block (mb, ab): slot q = ec/8, e = ec%8 (cell_shared.h)
@@ -690,7 +695,8 @@ __global__ void noop_kernel() {}
 // block 0 of parity 0 (sum(p) adds the blocks).
 __global__ void __launch_bounds__(256)
 load_state_kernel(const float* __restrict__ init, float* __restrict__ state,
-                  float* __restrict__ rs_part, int* tptr, int B, int N, int Np, int Bp, int numA) {
+                  float* __restrict__ rs_part, int* tptr, int B, int N, int Np, int Bp, int numA,
+                  int by_row = 0) {
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wv;
     if (blockIdx.x == 0 && threadIdx.x == 0) { tptr[0] = 0; tptr[16] = 0; }
@@ -703,7 +709,10 @@ load_state_kernel(const float* __restrict__ init, float* __restrict__ state,
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (l == 0) {
-        for (int a = 0; a < 2 * numA; ++a) rs_part[(size_t)a * Bp + b] = (a == 0) ? s : 0.f;
+        // rs_part [2][numA][Bp], or by_row: [2][Bp][numA] (the factored cell_a; numA padded by the caller)
+        for (int a = 0; a < 2 * numA; ++a)
+            rs_part[by_row ? ((size_t)(a / numA) * Bp + b) * numA + a % numA : (size_t)a * Bp + b] =
+                (a == 0) ? s : 0.f;
     }
 }
 
@@ -739,7 +748,8 @@ seen_kernel(const unsigned char* __restrict__ valid, unsigned char* __restrict__
 // initial state go to atom block 0 of parity 0; frame counter = 0.
 __global__ void __launch_bounds__(256)
 init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
-                  float* __restrict__ rs_part, int* tptr, int N, int Np, int Bp, int numA) {
+                  float* __restrict__ rs_part, int* tptr, int N, int Np, int Bp, int numA,
+                  int by_row = 0) {
     __shared__ float wsum[4];
     const int tid = threadIdx.x;
     float s = 0.f;
@@ -757,7 +767,10 @@ init_state_kernel(const float* __restrict__ log_h0, float* __restrict__ state,
     if ((tid & 63) == 0) wsum[tid >> 6] = s;
     __syncthreads();
     const float tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-    for (int i = tid; i < 2 * numA * Bp; i += 256) rs_part[i] = (i < Bp) ? tot : 0.f;
+    // (block 0 of parity 0 of every row; by_row: [2][Bp][numA], see load_state_kernel)
+    const int rs_stride = by_row ? numA : 1;
+    for (int i = tid; i < 2 * numA * Bp; i += 256)
+        rs_part[i] = (i < Bp * rs_stride && i % rs_stride == 0) ? tot : 0.f;
     if (tid == 0) { tptr[0] = 0; tptr[16] = 0; }
 }
 
@@ -1267,10 +1280,10 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
                            (unsigned char*)(ws + W.off_seen), d->T, W.Bp);
         if (initial_state)
             hipLaunchKernelGGL(load_state_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream,
-                               initial_state, state, rs_part, tA, d->B, d->N, W.Np, W.Bp, W.numA);
+                               initial_state, state, rs_part, tA, d->B, d->N, W.Np, W.Bp, round_up(W.numA, 4), 1);
         else
             hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
-                               rs_part, tA, d->N, W.Np, W.Bp, W.numA);
+                               rs_part, tA, d->N, W.Np, W.Bp, round_up(W.numA, 4), 1);
         DRNMF_HIP(h, hipGetLastError());
         // fp16 mode: cell_b writes the MFMA bin tiles of Rp16 only; the padding of the last 32-bin
         // chunk (and the odd-bin tile) must be finite: it meets zero dictionary slots
@@ -1629,10 +1642,10 @@ extern "C" int32_t drnmf_cell_forward_ista(drnmf_handle_t h, const drnmf_cell_de
                            stream, x, xp, valid, mask_value, d->B, d->T, d->F, W.Bp, W.Fp);
         if (initial_state)
             hipLaunchKernelGGL(load_state_kernel, dim3((W.Bp + 3) / 4), dim3(256), 0, stream,
-                               initial_state, state, rs_part, tA, d->B, d->N, W.Np, W.Bp, W.numA);
+                               initial_state, state, rs_part, tA, d->B, d->N, W.Np, W.Bp, round_up(W.numA, 4), 1);
         else
             hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, stream, log_h0, state,
-                               rs_part, tA, d->N, W.Np, W.Bp, W.numA);
+                               rs_part, tA, d->N, W.Np, W.Bp, round_up(W.numA, 4), 1);
         DRNMF_HIP(h, hipMemsetAsync(psum, 0, (size_t)W.Bp * 4, stream));   // read (times 0) by cell_a
         if (d->return_all_hidden) {      // the BPTT reads these (times 0) as the reference cell's does
             DRNMF_HIP(h, hipMemsetAsync(ws + W.off_psum_all, 0, (size_t)d->T * W.Bp * 4, stream));

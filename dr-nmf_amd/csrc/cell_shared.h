@@ -498,7 +498,7 @@ Workspace workspace_layout(const drnmf_cell_desc_t* d, bool allow_split = true) 
     W.off_h1 = take((size_t)W.Bp * W.Np * 4);
     W.off_state = take((size_t)W.Bp * W.Np * 4);
     W.numO = W.Np / 16;
-    W.off_rs = take((size_t)2 * (W.gram ? W.numO : W.numA) * W.Bp * 4);
+    W.off_rs = take((size_t)2 * (W.gram ? W.numO : round_up(W.numA, 4)) * W.Bp * 4);
     W.off_psum = take((size_t)W.Bp * 4);
     W.off_qpart = take((size_t)2 * W.numA * MAX_TAIL * W.Bp * 4);
     W.off_xtail = take((size_t)MAX_TAIL * W.Bp * 4);
