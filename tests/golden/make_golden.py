@@ -25,7 +25,7 @@ REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def extract(pyfile, names):
+def extract(pyfile, names, extra_ns=None):
     tmp = tempfile.mkdtemp(prefix='golden_')
     dst = os.path.join(tmp, os.path.basename(pyfile))
     shutil.copy(pyfile, dst)
@@ -34,10 +34,32 @@ def extract(pyfile, names):
     src = open(dst).read()
     tree = ast.parse(src)
     ns = {'np': np, 'numpy': np}
+    ns.update(extra_ns or {})
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in names:
             mod = ast.Module(body=[node], type_ignores=[])
             exec(compile(mod, dst, 'exec'), ns)
+    shutil.rmtree(tmp)
+    missing = [n for n in names if n not in ns]
+    assert not missing, missing
+    return ns
+
+
+def extract_methods(pyfile, cls, names, extra_ns=None):
+    """Methods of a class as plain functions f(self, ...) (the class itself subclasses Keras' Recurrent)."""
+    tmp = tempfile.mkdtemp(prefix='golden_')
+    dst = os.path.join(tmp, os.path.basename(pyfile))
+    shutil.copy(pyfile, dst)
+    subprocess.run([sys.executable, '-m', 'lib2to3', '-w', '-n', dst], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    tree = ast.parse(open(dst).read())
+    ns = {'np': np, 'numpy': np}
+    ns.update(extra_ns or {})
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name in names:
+                    exec(compile(ast.Module(body=[sub], type_ignores=[]), dst, 'exec'), ns)
     shutil.rmtree(tmp)
     missing = [n for n in names if n not in ns]
     assert not missing, missing
@@ -134,6 +156,111 @@ def main():
         {'transform_x': 'none', 'transform_y': 'logmag'},
         {'transform_x': 'logmag', 'transform_y': 'none'},
         {'transform_x': 'none', 'transform_y': 'none'})], dtype=np.float64)
+
+    # ---- build_alt (enhance.py:139-206): the log-domain parameters and the maps to U / S / W / b ----
+    # The function's only backend calls are K.exp / K.sqrt / K.sum(axis, keepdims) / K.square / K.dot /
+    # K.ones and the tensors' own .transpose(): bound here to their numpy namesakes (same signatures), so
+    # the reference's own expressions are what is evaluated.  Own generator: the vectors above keep their
+    # values.  The per-layer copies are perturbed IN the dict build_alt returned (its S maps close over
+    # that dict, enhance.py:177-178, as after Keras' build() has replaced its entries).
+    class _K(object):
+        exp, sqrt, sum, square, dot, ones = (staticmethod(f) for f in
+                                             (np.exp, np.sqrt, np.sum, np.square, np.dot, np.ones))
+    balt = extract(os.path.join(REF, 'enhance.py'), ['build_alt'], {'K': _K})['build_alt']
+    rng2 = np.random.Generator(np.random.PCG64(20172))
+    cases = {'tied': (9, 6, 3, [], False), 'untied_da': (9, 6, 3, ['log_D', 'log_alph'], True),
+             'untied_all': (7, 4, 2, ['log_D', 'log_alph', 'log_lam1'], False)}
+    for tag, (F, N, K_layers, untied, vec_alph) in cases.items():
+        W = rng2.random((F, N)).astype(np.float32) ** 2
+        alph = np.float32(N / 4.0) * (np.ones((N,), np.float32) if vec_alph else np.float32(1.0))
+        params = {'W': W, 'U1': np.eye(N, dtype=np.float32), 'Uk': np.zeros((N, N), np.float32),
+                  'alph': alph, 'lam1': np.float32(0.3)}
+        alt, maps = balt(N, K_layers, params, untied)
+        pre = 'alt_%s_' % tag
+        out[pre + 'W'], out[pre + 'alph'], out[pre + 'lam1'] = W, np.asarray(alph), params['lam1']
+        out[pre + 'K'], out[pre + 'untied'] = np.int64(K_layers), np.array(untied, dtype='U16')
+        out[pre + 'keys'] = np.array(sorted(alt.keys()), dtype='U16')
+        for k in sorted(alt.keys()):
+            out[pre + 'init_' + k] = np.asarray(alt[k])
+        for k in sorted(alt.keys()):                   # "trained" values: every entry moves
+            alt[k] = (np.asarray(alt[k]) +
+                      (0.1 * rng2.standard_normal(np.shape(alt[k]))).astype(np.float32)).astype(np.float32)
+            out[pre + 'val_' + k] = alt[k]
+        for kind in ('U', 'S', 'W', 'b'):
+            for i, m in enumerate(maps[kind]):
+                out[pre + '%s_%d' % (kind, i)] = np.asarray(m(alt))
+
+    # ---- SimpleDeepRNN.step / get_initial_state (custom_layers.py:336-375) run as written over short, fully
+    # valid sequences: K.rnn without a mask is `output, states = step(x_t, states + constants)` per frame
+    # [K2.0.4-memory], so this is the reference's recurrence itself; the masked scan is NOT covered (Keras is
+    # absent).  K.dot / K.concatenate / K.expand_dims / K.tile are numpy's; `self` is a plain namespace holding
+    # what build() would have put there (the matrices the maps above produce, or free ones); the activations are
+    # Keras' by definition (relu = max(x, 0), tanh, sigmoid).
+    import types
+
+    class _K2(object):
+        dot, concatenate, expand_dims, tile = (staticmethod(f) for f in
+                                               (np.dot, np.concatenate, np.expand_dims, np.tile))
+    cl = extract_methods(os.path.join(REF, 'custom_layers.py'), 'SimpleDeepRNN',
+                         ['step', 'get_initial_state'], {'K': _K2})
+    acts = {'relu': lambda v: np.maximum(v, 0), 'tanh': np.tanh,
+            'sigmoid': lambda v: 1.0 / (1.0 + np.exp(-v))}
+    rng3 = np.random.Generator(np.random.PCG64(20173))
+    F, N, K_layers, B, T = 9, 6, 3, 4, 5
+    pre = 'alt_untied_da_'
+    fused_alt = {k[len(pre) + 4:]: out[k] for k in out if k.startswith(pre + 'val_')}
+    for k in ('log_U1', 'log_Uk'):                    # U as initialised: the form the fused kernels take
+        fused_alt[k] = out[pre + 'init_' + k]
+    W0 = out[pre + 'W']
+    params = {'W': W0, 'U1': np.eye(N, dtype=np.float32), 'Uk': np.zeros((N, N), np.float32),
+              'alph': out[pre + 'alph'], 'lam1': out[pre + 'lam1']}
+    alt_f, maps_f = balt(N, K_layers, params, ['log_D', 'log_alph'])
+    for k in alt_f:
+        alt_f[k] = fused_alt[k]
+    dense_alt = dict(alt_f)
+    for k in ('log_U1', 'log_Uk'):
+        dense_alt[k] = out[pre + 'val_' + k]
+
+    def mats(maps, a):
+        return {kind: [np.asarray(m(a), np.float32) for m in maps[kind]] for kind in ('U', 'S', 'W', 'b')}
+    free = {'U': [(0.3 * rng3.standard_normal((N, N))).astype(np.float32) for _ in range(K_layers)],
+            'S': [(0.3 * rng3.standard_normal((N, N))).astype(np.float32) for _ in range(K_layers - 1)],
+            'W': [(0.3 * rng3.standard_normal((F, N))).astype(np.float32) for _ in range(K_layers)],
+            'b': [(0.1 * rng3.standard_normal((N,))).astype(np.float32) for _ in range(K_layers)]}
+    # the S maps close over the dict build_alt returned (enhance.py:177-178): evaluate them with THAT dict
+    # holding the values, as after build()
+    m_fused = mats(maps_f, alt_f)
+    alt_f.update(dense_alt)
+    m_dense = mats(maps_f, alt_f)
+    seqs = {'seq_fused': (m_fused, 'relu', True, False, False),
+            'seq_dense_allhidden': (m_dense, 'relu', True, True, False),
+            'seq_free_tanh_dropout': (free, 'tanh', True, False, True),
+            'seq_free_sigmoid_noconnect': (free, 'sigmoid', False, True, False)}
+    for tag, (m, act, connect, all_hidden, drop) in seqs.items():
+        x = (rng3.random((B, T, F)) ** 2).astype(np.float32)
+        log_h0 = rng3.uniform(-0.05, 0.05, N).astype(np.float32)
+        h0 = np.log1p(np.exp(log_h0)).astype(np.float32)     # softplus (custom_layers.py:203-206)
+        B_U = ((rng3.random((B, N)) < 0.6) / 0.6).astype(np.float32) if drop else np.float32(1.)
+        me = types.SimpleNamespace(K_layers=K_layers, output_dim=N, Uk=m['U'], Sk=m['S'], Wk=m['W'],
+                                   bk=m['b'], activation=acts[act], h0=h0,
+                                   flag_connect_input_to_layers=connect,
+                                   flag_return_all_hidden=all_hidden)
+        states = cl['get_initial_state'](me, x)
+        assert len(states) == 1 and states[0].shape == (B, N)
+        hs = []
+        for t in range(T):
+            o, states = cl['step'](me, x[:, t], list(states) + [B_U, np.float32(1.)])
+            hs.append(o)
+        p2 = 'step_%s_' % tag
+        out[p2 + 'x'], out[p2 + 'log_h0'], out[p2 + 'h0'] = x, log_h0, h0
+        out[p2 + 'h'] = np.stack(hs, 1).astype(np.float32)
+        out[p2 + 'act'], out[p2 + 'connect'] = np.array(act), np.int64(connect)
+        out[p2 + 'all_hidden'], out[p2 + 'B_U'] = np.int64(all_hidden), np.asarray(B_U)
+        for kind in ('U', 'S', 'W', 'b'):
+            for i, v in enumerate(m[kind]):
+                out[p2 + '%s_%d' % (kind, i)] = v
+    for k, v in fused_alt.items():
+        out['step_seq_fused_alt_' + k] = v
 
     np.savez_compressed(os.path.join(HERE, 'reference_numpy_golden.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_numpy_golden.npz'), len(out), 'arrays')

@@ -639,3 +639,29 @@ def test_stateful_layer_trains_on_the_dense_path(dev, dropout):
         state = new_state.detach()
         kept.append(cell.states[0].cpu().numpy()[2].copy())
     assert np.array_equal(kept[0], kept[1]) and np.any(kept[0] != 0)
+
+
+@pytest.mark.parametrize("tag", ["seq_fused", "seq_dense_allhidden", "seq_free_tanh_dropout",
+                                 "seq_free_sigmoid_noconnect"])
+def test_dense_kernels_match_reference_step_golden(dev, golden, tag):
+    """The HIP kernels against the REFERENCE ITSELF: SimpleDeepRNN.step / get_initial_state (custom_layers.py:
+    336-375) executed as written over 5-frame sequences (tests/golden/make_golden.py) with build_alt's own
+    matrices or free ones, relu / tanh / sigmoid, all-hidden output, no input connection, a recurrent dropout
+    mask.  Same tolerance as against the oracle."""
+    from drnmf_amd import ops
+    pre = "step_%s_" % tag
+    g = golden
+    K = sum(1 for k in g.files if k.startswith(pre + "U_"))
+    U, W, b = (np.stack([g[pre + "%s_%d" % (kind, i)] for i in range(K)]) for kind in "UWb")
+    S = np.stack([g[pre + "S_%d" % i] for i in range(K - 1)])
+    X, ref, B_U = g[pre + "x"], g[pre + "h"], g[pre + "B_U"]
+    act, connect, ah = str(g[pre + "act"]), bool(g[pre + "connect"]), bool(g[pre + "all_hidden"])
+    if B_U.ndim == 0:
+        _check(_run(dev, X, U, S, W, b, g[pre + "h0"], activation=act, connect=connect, all_hidden=ah), ref)
+        return
+    Bn, T, F = X.shape
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    desc = ops.make_dense_desc(Bn, T, F, U.shape[1], K, connect, act, ah)
+    params = ops.dense_prepare_params(desc, t(U), t(S), t(W) if connect else None, t(b))
+    h = ops.dense_cell_forward(t(X), -1.0, params, desc, t(g[pre + "h0"]), drop_u=t(B_U))
+    _check(h.cpu().numpy(), ref)

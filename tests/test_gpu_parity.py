@@ -708,6 +708,36 @@ def test_cell_forward_fp16_operands(dev, cfg):
         assert np.max(np.abs(hall - emu_all)) / scale <= 2e-3
 
 
+def test_fused_cell_matches_reference_step_golden(dev, golden):
+    """The fused factored kernels against the REFERENCE ITSELF: build_alt's maps (enhance.py:139-206) and
+    SimpleDeepRNN.step / get_initial_state (custom_layers.py:336-375) executed as written over a 5-frame
+    sequence (tests/golden/make_golden.py, case seq_fused: untied log_D / log_alph at 'trained' values, U as
+    initialised) -- through the C ABI directly and through the Keras-surface layer, which must pick the
+    fused path by itself."""
+    from drnmf_amd import layers
+    g, pre = golden, "step_seq_fused_"
+    alt = {k[len(pre + "alt_"):]: g[k] for k in g.files if k.startswith(pre + "alt_")}
+    X, ref = g[pre + "x"], g[pre + "h"]
+    B, T, F = X.shape
+    N, K = ref.shape[-1], sum(1 for k in g.files if k.startswith(pre + "U_"))
+    labels = {n: (["%s_%d" % (n, k) for k in range(K)] if n + "_0" in alt else [n] * K)
+              for n in ("log_D", "log_alph", "log_lam1")}
+    h, _, _ = _run_cell(dev, dict(X=X, log_h0=g[pre + "log_h0"]), alt, labels, N, K)
+    _check_h(h, ref)
+    W = g["alt_untied_da_W"]
+    params = dict(W=W, U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=g["alt_untied_da_alph"], lam1=g["alt_untied_da_lam1"])
+    alt0, maps = layers.build_alt(N, K, params, ["log_D", "log_alph"])
+    cell = layers.SimpleDeepRNN(N, activation="relu", K_layers=K, alt_params=alt0, maps_from_alt=maps,
+                                keys_trainable=["log_D_0"], flag_connect_input_to_layers=True,
+                                flag_nonnegative=True, return_sequences=True, device=dev)
+    cell.build((B, T, F))
+    names = [n[len(cell.name) + 1:] for n in cell.weight_names]
+    cell.set_weights([g[pre + "log_h0"] if n == "log_h0" else alt[n] for n in names])
+    assert not cell._dense_now
+    _check_h(cell.call(torch.from_numpy(X).to(dev), mask_value=-1.).cpu().numpy(), ref)
+
+
 def test_end_to_end_enhancement_pipeline(dev):
     """enhance.py's inference flow end to end on the device -- wav -> STFT stacks ->
     reshape_and_pad_stacks -> predict_on_batch in slabs -> crop -> masked iSTFT -> SNR / SDR

@@ -80,6 +80,33 @@ def test_build_alt_matches_oracle():
             np.testing.assert_allclose(maps["S"][k](alt), Sk[k], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["tied", "untied_da", "untied_all"])
+def test_build_alt_matches_reference_golden(golden, tag):
+    """The PRODUCT's build_alt (the host code enhance.py would call) against the reference's own, executed
+    as written (tests/golden/make_golden.py): names, clones and values of the log-domain parameters, and the
+    matrices the maps produce at 'trained' values -- on numpy arrays and on torch tensors."""
+    import torch
+    from drnmf_amd import layers
+    g, pre = golden, "alt_%s_" % tag
+    K, untied = int(g[pre + "K"]), [str(u) for u in g[pre + "untied"]]
+    W = g[pre + "W"]
+    N = W.shape[1]
+    params = dict(W=W, U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=g[pre + "alph"], lam1=g[pre + "lam1"])
+    alt, maps = layers.build_alt(N, K, params, params_untied=untied)
+    assert sorted(alt.keys()) == [str(k) for k in g[pre + "keys"]]
+    for k in alt:
+        np.testing.assert_array_equal(alt[k], g[pre + "init_" + k])
+    val = {k: g[pre + "val_" + k] for k in alt}
+    tval = {k: torch.from_numpy(np.array(v)) for k, v in val.items()}
+    for a, get in ((val, np.asarray), (tval, lambda m: m.numpy())):
+        for kind, n in (("U", K), ("W", K), ("b", K), ("S", K - 1)):
+            assert len(maps[kind]) == n
+            for k in range(n):
+                np.testing.assert_allclose(get(maps[kind][k](a)), g[pre + "%s_%d" % (kind, k)],
+                                           rtol=2e-6, atol=1e-6 if kind == "S" else 2e-7)
+
+
 def test_simple_deep_rnn_config_surface():
     from drnmf_amd import layers
     P = O.synth_problem(2, 3, 21, 6, seed=5)

@@ -34,6 +34,89 @@ def test_divergences_match_reference_golden(golden):
                                       g["div_beta_%s" % str(b).replace(".", "p")])
 
 
+@pytest.mark.parametrize("tag", ["tied", "untied_da", "untied_all"])
+def test_build_alt_and_its_maps_match_reference_golden(golden, tag):
+    """enhance.py:139-206 executed as written (its K.* calls bound to numpy, tests/golden/make_golden.py): the
+    log-domain parameters build_alt returns -- names, per-layer clones, values -- and, at 'trained' values
+    of every entry, the matrices its maps produce (U_k, S_k, W_k, b_k; scalar and per-atom alph, tied and
+    untied layers).  The oracle's restatement (build_alt, maps_dense, maps_factored, u_scalars) against them."""
+    g, pre = golden, "alt_%s_" % tag
+    K, untied = int(g[pre + "K"]), [str(u) for u in g[pre + "untied"]]
+    W = g[pre + "W"]
+    N = W.shape[1]
+    params = dict(W=W, U1=np.eye(N, dtype=np.float32), Uk=np.zeros((N, N), np.float32),
+                  alph=g[pre + "alph"], lam1=g[pre + "lam1"])
+    alt, labels = O.build_alt(N, K, params, untied)
+    assert sorted(alt.keys()) == [str(k) for k in g[pre + "keys"]]
+    for k in alt:
+        assert alt[k].dtype == np.float32
+        np.testing.assert_array_equal(alt[k], g[pre + "init_" + k])
+    # the rank-structured initial U is what the fused kernels assume (eye -> exp(log(1e-7 + .)))
+    u0d, u0o, uko = O.u_scalars(alt)
+    assert abs(u0d - 1.0) < 1e-6 and abs(u0o - 1e-7) < 1e-12 and abs(uko - 1e-7) < 1e-12
+    val = {k: g[pre + "val_" + k] for k in alt}
+    Wk, Uk, bk, Sk = O.maps_dense(val, labels, K, N, dtype=np.float64)
+    tol = dict(rtol=2e-6, atol=2e-7)          # the reference evaluates in float32
+    for k in range(K):
+        np.testing.assert_allclose(Uk[k], g[pre + "U_%d" % k], **tol)
+        np.testing.assert_allclose(Wk[k], g[pre + "W_%d" % k], **tol)
+        np.testing.assert_allclose(bk[k], g[pre + "b_%d" % k], **tol)
+        if k >= 1:
+            np.testing.assert_allclose(Sk[k - 1], g[pre + "S_%d" % (k - 1)], rtol=2e-6, atol=1e-6)
+    assert pre + "S_%d" % (K - 1) not in g.files and pre + "U_%d" % K not in g.files     # K-1 / K maps
+    # the factored form the kernels run: W_k = Dn diag(1/alpha), S_k = I - Dn^T Dn diag(1/alpha), b_k
+    for k, (Dn, ia, b) in enumerate(O.maps_factored(val, labels, K)):
+        np.testing.assert_allclose(Dn * ia[None, :], g[pre + "W_%d" % k], **tol)
+        np.testing.assert_allclose(b, g[pre + "b_%d" % k], **tol)
+        if k >= 1:
+            np.testing.assert_allclose(np.eye(N) - (Dn.T @ Dn) * ia[None, :], g[pre + "S_%d" % (k - 1)],
+                                       rtol=2e-6, atol=1e-6)
+
+
+STEP_SEQS = ["seq_fused", "seq_dense_allhidden", "seq_free_tanh_dropout", "seq_free_sigmoid_noconnect"]
+
+
+def _step_case(g, tag):
+    pre = "step_%s_" % tag
+    K = sum(1 for k in g.files if k.startswith(pre + "U_"))
+    m = {kind: [g[pre + "%s_%d" % (kind, i)] for i in range(K - (kind == "S"))] for kind in "USWb"}
+    return dict(x=g[pre + "x"], h=g[pre + "h"], h0=g[pre + "h0"], log_h0=g[pre + "log_h0"],
+                act=str(g[pre + "act"]), connect=bool(g[pre + "connect"]),
+                all_hidden=bool(g[pre + "all_hidden"]), B_U=g[pre + "B_U"], K=K, **m)
+
+
+@pytest.mark.parametrize("tag", STEP_SEQS)
+def test_cell_recurrence_matches_reference_step_golden(golden, tag):
+    """SimpleDeepRNN.step (custom_layers.py:343-375) and get_initial_state (336-341) executed as written over
+    5-frame sequences (tests/golden/make_golden.py): the oracle's restatements of the recurrence -- the dense op
+    graph, its torch twin (the one carrying the recurrent dropout mask), and for build_alt's maps with the
+    initial U the FACTORED form the kernels implement -- against the reference's own outputs."""
+    import torch
+    from oracle import drnmf_torch_ref as R
+    c = _step_case(golden, tag)
+    tol = dict(rtol=2e-5, atol=2e-6)                    # the reference ran in float32
+    if c["B_U"].ndim == 0:
+        h = O.cell_forward_dense(c["x"], c["W"], c["U"], c["b"], c["S"], None, h0=c["h0"],
+                                 return_all_hidden=c["all_hidden"], connect_input=c["connect"],
+                                 activation=c["act"])
+        np.testing.assert_allclose(h, c["h"], **tol)
+    td = lambda a: torch.tensor(np.asarray(a, np.float64))
+    ht = R.dense_cell(td(c["x"]), torch.stack([td(u) for u in c["U"]]), torch.stack([td(u) for u in c["S"]]),
+                      torch.stack([td(u) for u in c["W"]]), torch.stack([td(u) for u in c["b"]]), td(c["h0"]),
+                      return_all_hidden=c["all_hidden"], connect_input=c["connect"], activation=c["act"],
+                      drop_u=None if c["B_U"].ndim == 0 else td(c["B_U"]))
+    np.testing.assert_allclose(ht.numpy(), c["h"], **tol)
+    if tag == "seq_fused":
+        alt = {k[len("step_seq_fused_alt_"):]: golden[k] for k in golden.files
+               if k.startswith("step_seq_fused_alt_")}
+        labels = {n: (["%s_%d" % (n, k) for k in range(c["K"])] if n + "_0" in alt else [n] * c["K"])
+                  for n in ("log_D", "log_alph", "log_lam1")}
+        hf = O.cell_forward_factored(c["x"], O.maps_factored(alt, labels, c["K"]), O.u_scalars(alt),
+                                     c["log_h0"])
+        np.testing.assert_allclose(hf, c["h"], **tol)
+        assert np.count_nonzero(c["h"]) > 0.2 * c["h"].size      # (not thresholded away)
+
+
 def test_layout_helpers_match_reference_golden(golden):
     g = golden
     np.testing.assert_array_equal(O.masked_seqs_to_frames(g["m2f_x"], g["m2f_mask"]), g["m2f_out"])
