@@ -243,7 +243,8 @@ class _Attrs(object):
             ptr = C.cast(buf, C.c_void_p)
         else:
             arr = np.ascontiguousarray(arr, dtype={"f": np.float32 if arr.dtype.itemsize <= 4
-                                                   else np.float64}.get(arr.dtype.kind, np.int64))
+                                                   else np.float64}.get(arr.dtype.kind, np.int64)
+                                       ).reshape(arr.shape)      # (ascontiguousarray makes 0-d arrays (1,))
             tid = L.H5Tcopy(_T[{np.dtype(np.float32): "f32", np.dtype(np.float64): "f64",
                                 np.dtype(np.int64): "i64"}[arr.dtype]])
             shape = arr.shape
@@ -327,11 +328,13 @@ class Group(object):
     def create_dataset(self, name, data):
         L = lib()
         arr = np.asarray(data)
+        # (0-d arrays -- Keras' scalar weights, build_alt's log_alph / log_lam1 -- keep a scalar dataspace as
+        # h5py writes them: np.ascontiguousarray alone returns shape (1,))
         if arr.dtype.kind == "f":
-            arr = np.ascontiguousarray(arr, np.float32 if arr.dtype.itemsize <= 4 else np.float64)
+            arr = np.ascontiguousarray(arr, np.float32 if arr.dtype.itemsize <= 4 else np.float64).reshape(arr.shape)
             key = "f32" if arr.dtype == np.float32 else "f64"
         elif arr.dtype.kind in "iub":
-            arr = np.ascontiguousarray(arr, np.int64)
+            arr = np.ascontiguousarray(arr, np.int64).reshape(arr.shape)
             key = "i64"
         else:
             raise TypeError("create_dataset: unsupported dtype %s" % arr.dtype)

@@ -141,10 +141,12 @@ class _Layer(object):
                              (self.name, len(ws), len(weights)))
         for w, v in zip(ws, weights):
             v = np.asarray(v, dtype=np.float32)
+            if v.size == 1 and w.numel() == 1:       # () and (1,) name the same scalar
+                v = v.reshape(tuple(w.shape))
             if tuple(v.shape) != tuple(w.shape):
                 raise ValueError('Layer %s weight shape %s != provided %s' %
                                  (self.name, tuple(w.shape), tuple(v.shape)))
-            w.copy_(torch.from_numpy(np.ascontiguousarray(v)))
+            w.copy_(torch.from_numpy(np.ascontiguousarray(v)).reshape(tuple(w.shape)))
         self._weights_changed()
 
     def _weights_changed(self):
@@ -363,7 +365,9 @@ class SimpleDeepRNN(_Layer):
         self._alt = OrderedDict()
         for key in self.alt_params:                                       # custom_layers.py:216-228
             v = np.array(self.alt_params[key], dtype=np.float32, copy=True)   # never alias the caller's
-            self._alt[key] = torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
+            # (scalars -- log_alph, log_lam1 of build_alt -- keep Keras' shape (): K.variable of a 0-d array;
+            # np.ascontiguousarray alone would make them (1,))
+            self._alt[key] = torch.from_numpy(np.ascontiguousarray(v)).reshape(v.shape).to(self.device)
         self.trainable_keys = [k for k in self._alt if k in self.keys_trainable]
         # matrices without a map are free weights of the layer (custom_layers.py:241-281)
         self._free = OrderedDict()

@@ -10,11 +10,16 @@ Parity pin status
 * ista_ed / ista_kl / ista_beta / kl_div / beta_div / masked_seqs_to_frames /
   pad_axis_toN_with_constant / reshape_and_pad_stacks: PINNED against outputs of the reference's
   own functions, executed in the build container (tests/golden/make_golden.py -> *.npz).
-* cell_forward_* layers 1..K-1: pinned indirectly -- with the U-term zeroed and T=1 they are
-  `ista_ed` with K-1 iterations (tests/test_oracle.py), and the Gram form (reference op graph)
-  and the factored form agree to fp64 round-off.
+* build_alt / maps_dense / maps_factored / u_scalars and the recurrence of cell_forward_dense /
+  cell_forward_factored (and drnmf_torch_ref.dense_cell) over fully valid sequences: PINNED against
+  enhance.py:139-206 and custom_layers.py:336-375 (build_alt, SimpleDeepRNN.step, get_initial_state)
+  executed as written, their K.* calls bound to numpy (make_golden.py; tests/test_oracle.py
+  test_build_alt_and_its_maps_match_reference_golden, test_cell_recurrence_matches_reference_step_golden).
+* cell_forward_* also indirectly -- with the U-term zeroed and T=1 layers 1..K-1 are `ista_ed` with
+  K-1 iterations (tests/test_oracle.py), and the Gram form (reference op graph) and the factored form
+  agree to fp64 round-off.
 * Keras 2.0.4 / Theano 0.9 / librosa 0.5.1 / Matlab semantics the reference relies on but does
-  not contain (Masking, K.rnn masking, 'uniform' initializer, weighted loss normalisation,
+  not contain (Masking, the MASKED K.rnn scan, 'uniform' initializer, weighted loss normalisation,
   librosa.stft framing, Matlab legacy rand) are restated from memory and marked
   [K2.0.4-memory] / [librosa-memory]: "parity unpinned" at those boundaries.
 """

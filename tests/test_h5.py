@@ -99,6 +99,16 @@ def test_model_weights_hdf5_round_trip(h5, tmp_path):
     m.load_weights(path)
     for a, b in zip(w0, m.get_weights()):
         np.testing.assert_array_equal(a, b)
+        assert a.shape == b.shape
+    # build_alt's scalar parameters (log_alph, log_lam1: np.log of a float32, enhance.py:147) are 0-d arrays;
+    # K.variable keeps that shape and h5py writes a scalar dataspace: the layer, the tree and the file agree
+    names = [str(n) for n in m.weights_tree()[m.cell.name + "/weight_names"]]
+    scalars = [w for n, w in zip(names, m.cell.get_weights()) if n.endswith(("log_alph", "log_lam1"))]
+    assert len(scalars) == 2 and all(w.shape == () for w in scalars)
+    with h5.File(path, "r") as f:
+        for n in names:
+            if n.endswith(("log_alph", "log_lam1")):
+                assert tuple(f[m.cell.name][n].shape) == ()
     tool = _h5dump()
     if tool:
         txt = subprocess.run([tool, "-A", path], capture_output=True, text=True, check=True).stdout
@@ -125,7 +135,9 @@ def test_reference_style_file_is_loaded(h5, tmp_path):
         names = ["simple_deep_rnn_7" + n[len(cn):] for n in reversed(wn)]
         g.attrs["weight_names"] = [n.encode() for n in names]
         for n, src in zip(names, reversed(wn)):
-            g.create_dataset(n, data=tree[cn + "/" + src] * 3)
+            v = tree[cn + "/" + src] * 3
+            # (a scalar weight written as (1,) by some other tool is the same scalar)
+            g.create_dataset(n, data=v.reshape(1) if v.ndim == 0 and n.endswith("log_lam1") else v)
         for dst, src in (("time_distributed_1", "clean_est"), ("time_distributed_2", "noise_est")):
             gg = g0.create_group(dst)
             gg.attrs["weight_names"] = [b"kernel"]
