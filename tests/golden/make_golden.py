@@ -262,6 +262,26 @@ def main():
     for k, v in fused_alt.items():
         out['step_seq_fused_alt_' + k] = v
 
+    # ---- mask head: DenseNonNegW.call (custom_layers.py:23-29) and DivideAbyAplusB._merge_function (41-45)
+    # as written (K.dot / K.exp / K.log = numpy's), wired as enhance.py:269-306 wires them: H_clean / H_noise =
+    # the first / last r atoms, kernels log(1e-7 + W[:, :r]).T / log(1e-7 + W[:, r:]).T, optional square
+    class _K3(object):
+        dot, exp, log = staticmethod(np.dot), staticmethod(np.exp), staticmethod(np.log)
+    dn = extract_methods(os.path.join(REF, 'custom_layers.py'), 'DenseNonNegW', ['call'], {'K': _K3})['call']
+    mf = extract_methods(os.path.join(REF, 'custom_layers.py'), 'DivideAbyAplusB', ['_merge_function'],
+                         {'K': _K3})['_merge_function']
+    rng4 = np.random.Generator(np.random.PCG64(20174))
+    Fh, rh = 7, 4
+    Wh = (rng4.random((Fh, 2 * rh)) ** 2).astype(np.float32)
+    hh = ((rng4.random((3, 4, 2 * rh)) < 0.5) * rng4.random((3, 4, 2 * rh)) * 2).astype(np.float32)
+    kc, kn = np.log(np.float32(1e-7) + Wh[:, :rh]).T, np.log(np.float32(1e-7) + Wh[:, rh:]).T
+    dense = lambda kern: types.SimpleNamespace(kernel=kern, use_bias=False, activation=None)
+    A, Bn = dn(dense(kc), hh[:, :, :rh]), dn(dense(kn), hh[:, :, rh:])
+    out['head_h'], out['head_W'], out['head_kc'], out['head_kn'] = hh, Wh, kc, kn
+    out['head_A'], out['head_B'] = A, Bn
+    out['head_mask'] = mf(None, [A, Bn])
+    out['head_mask_square'] = mf(None, [np.square(A), np.square(Bn)])
+
     np.savez_compressed(os.path.join(HERE, 'reference_numpy_golden.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_numpy_golden.npz'), len(out), 'arrays')
 

@@ -708,6 +708,26 @@ def test_cell_forward_fp16_operands(dev, cfg):
         assert np.max(np.abs(hall - emu_all)) / scale <= 2e-3
 
 
+@pytest.mark.parametrize("square", [False, True])
+def test_mask_head_matches_reference_golden(dev, golden, square):
+    """The head kernels against the REFERENCE ITSELF (DenseNonNegW.call, DivideAbyAplusB._merge_function run as
+    written, tests/golden/make_golden.py): through the C ABI and through the Keras-surface layers."""
+    from drnmf_amd import layers, ops
+    g = golden
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    h, kc, kn = t(g["head_h"]), t(g["head_kc"]), t(g["head_kn"])
+    want = g["head_mask_square" if square else "head_mask"]
+    m, A, Bn = ops.head_forward(h, kc, kn, square=square, want_ab=True)
+    np.testing.assert_allclose(m.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    if not square:
+        np.testing.assert_allclose(A.cpu().numpy(), g["head_A"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(Bn.cpu().numpy(), g["head_B"], rtol=2e-5, atol=1e-6)
+        r, F = g["head_kc"].shape
+        dn = layers.DenseNonNegW(F, use_bias=False, weights=[g["head_kc"]], device=dev)
+        np.testing.assert_allclose(dn(h[..., :r].contiguous()).cpu().numpy(), g["head_A"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(layers.divide_A_by_AplusB([A, Bn]).cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+
+
 def test_fused_cell_matches_reference_step_golden(dev, golden):
     """The fused factored kernels against the REFERENCE ITSELF: build_alt's maps (enhance.py:139-206) and
     SimpleDeepRNN.step / get_initial_state (custom_layers.py:336-375) executed as written over a 5-frame

@@ -117,6 +117,22 @@ def test_cell_recurrence_matches_reference_step_golden(golden, tag):
         assert np.count_nonzero(c["h"]) > 0.2 * c["h"].size      # (not thresholded away)
 
 
+def test_mask_head_matches_reference_golden(golden):
+    """DenseNonNegW.call (custom_layers.py:23-29) and DivideAbyAplusB._merge_function (41-45) executed as written
+    and wired as enhance.py:269-306 wires them (tests/golden/make_golden.py): reconstructions and ratio mask,
+    plain and with transform_before_irm='square'."""
+    g = golden
+    for square, want in ((False, g["head_mask"]), (True, g["head_mask_square"])):
+        m, A, Bn = O.head_forward(g["head_h"], g["head_kc"], g["head_kn"], square=square)
+        np.testing.assert_allclose(m, want, rtol=3e-6, atol=1e-7)
+        if not square:
+            np.testing.assert_allclose(A, g["head_A"], rtol=3e-6, atol=1e-7)
+            np.testing.assert_allclose(Bn, g["head_B"], rtol=3e-6, atol=1e-7)
+    # the kernels build_unfolded_snmf starts from (enhance.py:282, 290)
+    r = g["head_kc"].shape[0]
+    np.testing.assert_array_equal(np.log(np.float32(1e-7) + g["head_W"][:, :r]).T, g["head_kc"])
+
+
 def test_layout_helpers_match_reference_golden(golden):
     g = golden
     np.testing.assert_array_equal(O.masked_seqs_to_frames(g["m2f_x"], g["m2f_mask"]), g["m2f_out"])
