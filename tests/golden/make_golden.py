@@ -282,6 +282,48 @@ def main():
     out['head_mask'] = mf(None, [A, Bn])
     out['head_mask_square'] = mf(None, [np.square(A), np.square(Bn)])
 
+    # ---- reconstruction: util.istft_noDiv (util.py:48-169) and util.istft_mc (203-226) as written, the way
+    # audio_dataset.reconstruct_x calls them (267-278: flag_noDiv=1, center=False, the sqrt-Hann window vector of
+    # audio_dataset.py:194).  scipy / six are installed; of librosa only util.pad_center is touched, with a window
+    # already n_fft long, where it returns its argument -- bound to exactly that (anything else asserts).
+    import scipy
+    import scipy.fftpack
+    import scipy.signal
+    import six
+
+    def _pad_center_identity(w, n):
+        assert len(w) == n
+        return w
+    uns = {'scipy': scipy, 'six': six, 'fft': scipy.fftpack,
+           'util': types.SimpleNamespace(pad_center=_pad_center_identity)}
+    ut = extract(os.path.join(REF, 'util.py'), ['istft_noDiv', 'istft_mc', 'wavread', 'wavwrite'], uns)
+    rng5 = np.random.Generator(np.random.PCG64(20175))
+    Nf, hop, nfr = 32, 8, 12
+    win = np.sqrt(scipy.signal.hann(Nf, sym=False)) if hasattr(scipy.signal, 'hann') else \
+        np.sqrt(scipy.signal.get_window('hann', Nf, fftbins=True))
+    S = (rng5.standard_normal((Nf // 2 + 1, nfr)) + 1j * rng5.standard_normal((Nf // 2 + 1, nfr))).astype(np.complex64)
+    S[0].imag = 0
+    S[-1].imag = 0
+    msk = rng5.random((Nf // 2 + 1, nfr)).astype(np.float32)
+    out['istft_S_re'], out['istft_S_im'], out['istft_window'] = S.real.copy(), S.imag.copy(), win
+    out['istft_hop'], out['istft_mask'] = np.int64(hop), msk
+    out['istft_noDiv_y'] = ut['istft_noDiv'](S, hop_length=hop, center=False, window=win, dtype=np.float32)
+    xr, Nret = ut['istft_mc'](S[:, :, None], hop, flag_noDiv=1, window=win)
+    assert Nret == Nf
+    out['istft_mc_x'] = xr
+    out['istft_mc_x_nsampl50'] = ut['istft_mc']((msk * S)[:, :, None], hop, nsampl=50, flag_noDiv=1, window=win)[0]
+    # ---- wav files: util.wavwrite / util.wavread as written (util.py:29-45) through scipy.io.wavfile ----
+    tmpd = tempfile.mkdtemp(prefix='golden_wav_')
+    for tag, scale in (('quiet', 0.4), ('loud', 2.5)):
+        sig = (scale * rng5.standard_normal((1, 400)) / 3).astype(np.float32)     # nch x nsampl, as wavread returns
+        path = os.path.join(tmpd, tag + '.wav')
+        ut['wavwrite'](path, 16000, sig)
+        import scipy.io.wavfile
+        out['wav_%s_float' % tag] = sig
+        out['wav_%s_int16' % tag] = scipy.io.wavfile.read(path)[1]
+        out['wav_%s_read' % tag] = ut['wavread'](path)
+    shutil.rmtree(tmpd)
+
     np.savez_compressed(os.path.join(HERE, 'reference_numpy_golden.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_numpy_golden.npz'), len(out), 'arrays')
 

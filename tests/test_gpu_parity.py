@@ -549,6 +549,30 @@ def test_stft_istft_reconstruction_and_snr(dev, N, hop, nsampl):
     assert q.dtype == torch.int16 and int(q.abs().max()) <= 32767
 
 
+def test_reconstruction_kernels_match_reference_golden(dev, golden):
+    """The iSTFT and wav-quantisation kernels against the REFERENCE ITSELF: util.istft_mc(flag_noDiv=1) as
+    audio_dataset.reconstruct_x calls it and util.wavwrite's int16 conversion, executed as written
+    (tests/golden/make_golden.py)."""
+    from drnmf_amd import ops
+    g = golden
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    re, im = t(g["istft_S_re"].T[None]), t(g["istft_S_im"].T[None])          # [n_sig, n_frames, F]
+    hop = int(g["istft_hop"])
+    N = 2 * (re.shape[-1] - 1)
+    full = g["istft_mc_x"][0]
+    y = ops.istft_masked(re, im, None, full.shape[0], N, hop).cpu().numpy()[0]
+    assert np.max(np.abs(y - full)) <= 1e-4 * np.max(np.abs(full))
+    want = g["istft_mc_x_nsampl50"][0]
+    ym = ops.istft_masked(re, im, t(g["istft_mask"].T[None]), 50, N, hop).cpu().numpy()[0]
+    assert np.max(np.abs(ym - want)) <= 1e-4 * np.max(np.abs(want))
+    for tag in ("quiet", "loud"):
+        q = ops.to_int16_wav(t(g["wav_%s_float" % tag][0])).cpu().numpy()
+        # (x / max|x| * 32767 in float32 on the device, float64 in numpy: a value on an integer boundary may
+        # truncate to the neighbour)
+        assert np.max(np.abs(q.astype(int) - g["wav_%s_int16" % tag].astype(int))) <= 1
+        assert np.mean(q == g["wav_%s_int16" % tag]) > 0.99
+
+
 def test_stateful_cell_carries_state_across_batches(dev):
     """stateful=True (custom_layers.py:296-318): two consecutive half-length calls equal one
     full-length run started from the zero state; reset_states() zeroes it again."""

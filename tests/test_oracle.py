@@ -133,6 +133,29 @@ def test_mask_head_matches_reference_golden(golden):
     np.testing.assert_array_equal(np.log(np.float32(1e-7) + g["head_W"][:, :r]).T, g["head_kc"])
 
 
+def test_reconstruction_and_wav_helpers_match_reference_golden(golden):
+    """util.istft_noDiv / util.istft_mc (util.py:48-169, 203-226) called as audio_dataset.reconstruct_x calls them
+    (flag_noDiv=1, center=False, the sqrt-Hann window vector), and util.wavwrite / util.wavread (29-45), executed as
+    written (tests/golden/make_golden.py)."""
+    g = golden
+    S = g["istft_S_re"] + 1j * g["istft_S_im"]
+    hop, win = int(g["istft_hop"]), g["istft_window"]
+    N = 2 * (S.shape[0] - 1)
+    np.testing.assert_allclose(O.sqrt_hann(N), win, rtol=0, atol=1e-7)      # (the oracle's is float32)
+    tol = dict(rtol=0, atol=2e-6 * float(np.max(np.abs(g["istft_noDiv_y"]))))     # the reference sums in float32
+    np.testing.assert_allclose(O.istft_noDiv(S, hop, win), g["istft_noDiv_y"], **tol)
+    np.testing.assert_allclose(O.reconstruct(g["istft_S_re"], g["istft_S_im"], None, hop, win),
+                               g["istft_mc_x"][0], **tol)
+    np.testing.assert_allclose(O.reconstruct(g["istft_S_re"], g["istft_S_im"], g["istft_mask"], hop, win, nsampl=50),
+                               g["istft_mc_x_nsampl50"][0], **tol)
+    for tag in ("quiet", "loud"):
+        x, q = g["wav_%s_float" % tag][0], g["wav_%s_int16" % tag]
+        np.testing.assert_array_equal(O.wav_int16_to_float(q), g["wav_%s_read" % tag])
+        mx = np.max(np.abs(x))
+        np.testing.assert_array_equal(np.int16((x / mx if mx > 1 else x) * 32767.0), q)   # util.py:39-44
+    assert np.max(np.abs(g["wav_loud_float"])) > 1 > np.max(np.abs(g["wav_quiet_float"]))
+
+
 def test_layout_helpers_match_reference_golden(golden):
     g = golden
     np.testing.assert_array_equal(O.masked_seqs_to_frames(g["m2f_x"], g["m2f_mask"]), g["m2f_out"])
