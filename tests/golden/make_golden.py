@@ -298,7 +298,7 @@ def main():
            'util': types.SimpleNamespace(pad_center=_pad_center_identity)}
     ut = extract(os.path.join(REF, 'util.py'), ['istft_noDiv', 'istft_mc', 'wavread', 'wavwrite'], uns)
     rng5 = np.random.Generator(np.random.PCG64(20175))
-    Nf, hop, nfr = 32, 8, 12
+    Nf, hop, nfr = 64, 16, 12
     win = np.sqrt(scipy.signal.hann(Nf, sym=False)) if hasattr(scipy.signal, 'hann') else \
         np.sqrt(scipy.signal.get_window('hann', Nf, fftbins=True))
     S = (rng5.standard_normal((Nf // 2 + 1, nfr)) + 1j * rng5.standard_normal((Nf // 2 + 1, nfr))).astype(np.complex64)
@@ -311,7 +311,7 @@ def main():
     xr, Nret = ut['istft_mc'](S[:, :, None], hop, flag_noDiv=1, window=win)
     assert Nret == Nf
     out['istft_mc_x'] = xr
-    out['istft_mc_x_nsampl50'] = ut['istft_mc']((msk * S)[:, :, None], hop, nsampl=50, flag_noDiv=1, window=win)[0]
+    out['istft_mc_x_nsampl100'] = ut['istft_mc']((msk * S)[:, :, None], hop, nsampl=100, flag_noDiv=1, window=win)[0]
     # ---- wav files: util.wavwrite / util.wavread as written (util.py:29-45) through scipy.io.wavfile ----
     tmpd = tempfile.mkdtemp(prefix='golden_wav_')
     for tag, scale in (('quiet', 0.4), ('loud', 2.5)):

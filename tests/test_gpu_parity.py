@@ -562,8 +562,8 @@ def test_reconstruction_kernels_match_reference_golden(dev, golden):
     full = g["istft_mc_x"][0]
     y = ops.istft_masked(re, im, None, full.shape[0], N, hop).cpu().numpy()[0]
     assert np.max(np.abs(y - full)) <= 1e-4 * np.max(np.abs(full))
-    want = g["istft_mc_x_nsampl50"][0]
-    ym = ops.istft_masked(re, im, t(g["istft_mask"].T[None]), 50, N, hop).cpu().numpy()[0]
+    want = g["istft_mc_x_nsampl100"][0]
+    ym = ops.istft_masked(re, im, t(g["istft_mask"].T[None]), 100, N, hop).cpu().numpy()[0]
     assert np.max(np.abs(ym - want)) <= 1e-4 * np.max(np.abs(want))
     for tag in ("quiet", "loud"):
         q = ops.to_int16_wav(t(g["wav_%s_float" % tag][0])).cpu().numpy()

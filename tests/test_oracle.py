@@ -146,8 +146,8 @@ def test_reconstruction_and_wav_helpers_match_reference_golden(golden):
     np.testing.assert_allclose(O.istft_noDiv(S, hop, win), g["istft_noDiv_y"], **tol)
     np.testing.assert_allclose(O.reconstruct(g["istft_S_re"], g["istft_S_im"], None, hop, win),
                                g["istft_mc_x"][0], **tol)
-    np.testing.assert_allclose(O.reconstruct(g["istft_S_re"], g["istft_S_im"], g["istft_mask"], hop, win, nsampl=50),
-                               g["istft_mc_x_nsampl50"][0], **tol)
+    np.testing.assert_allclose(O.reconstruct(g["istft_S_re"], g["istft_S_im"], g["istft_mask"], hop, win, nsampl=100),
+                               g["istft_mc_x_nsampl100"][0], **tol)
     for tag in ("quiet", "loud"):
         x, q = g["wav_%s_float" % tag][0], g["wav_%s_int16" % tag]
         np.testing.assert_array_equal(O.wav_int16_to_float(q), g["wav_%s_read" % tag])
