@@ -15,6 +15,8 @@ Parity pin status
   enhance.py:139-206 and custom_layers.py:336-375 (build_alt, SimpleDeepRNN.step, get_initial_state)
   executed as written, their K.* calls bound to numpy (make_golden.py; tests/test_oracle.py
   test_build_alt_and_its_maps_match_reference_golden, test_cell_recurrence_matches_reference_step_golden).
+* head_forward (dense_nonneg, divide_a_by_aplusb), istft_noDiv / reconstruct, wav_int16_to_float: PINNED
+  against custom_layers.py:23-45 and util.py:29-45, 48-169, 203-226 executed as written (same script).
 * cell_forward_* also indirectly -- with the U-term zeroed and T=1 layers 1..K-1 are `ista_ed` with
   K-1 iterations (tests/test_oracle.py), and the Gram form (reference op graph) and the factored form
   agree to fp64 round-off.
