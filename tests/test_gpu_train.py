@@ -323,6 +323,8 @@ def test_snmf_cost_pretraining_gradients_and_fit(dev, cfg):
         assert err <= G_TOL, "%s: rel err %.3e (max ref %.3e)" % (n, err, scale)
     # value of the objective vs the numpy oracle on the device outputs
     xr, h = pre.predict_on_batch(P["X"])
+    xr2, h2 = pre.predict(P["X"], batch_size=2)           # (keras Model.predict: two outputs, slab by slab)
+    assert np.array_equal(xr2, xr) and np.array_equal(h2, h)
     want = O.loss_snmf_cost(P["X"], xr, np.zeros_like(xr), h, wmask, lam1)
     got = pre.test_on_batch(P["X"], [P["X"], P["X"]], [wmask, wmask])
     assert abs(got - want) <= 1e-5 * abs(want)
