@@ -485,10 +485,24 @@ def dense_graph_bench(torch, dev, F, r, K, B, frames=40):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3
     fl = 2.0 * B * frames * N * (K * (N + F) + (K - 1) * N)
+    bytes_ls = ((K * (N + F) + (K - 1) * N) * N / K) * 4.0      # matrix bytes streamed per layer-step (mean)
     res = {"frames": frames, "frames_per_s": B * frames / sec,
            "us_per_layer_step": sec / (frames * K) * 1e6, "tflops_executed": fl / sec / 1e12,
-           "tflops_algorithmic": B * frames * 4.0 * F * N * K / sec / 1e12}
-    del U, S, W, P, ws, out, X
+           "tflops_algorithmic": B * frames * 4.0 * F * N * K / sec / 1e12,
+           "matrix_stream_GBps": bytes_ls / (sec / (frames * K)) / 1e9}
+    # the same with fp16-stored matrices (drnmf_dense_desc_t.operand_f16: half the stream)
+    d16 = ops.make_dense_desc(B, frames, F, N, K, operand_f16=True)
+    P16 = ops.dense_prepare_params(d16, U, S if K > 1 else None, W, b)
+    ops.dense_cell_forward(X, None, P16, d16, h0, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    e0.record()
+    ops.dense_cell_forward(X, None, P16, d16, h0, out=out, workspace=ws)
+    e1.record()
+    torch.cuda.synchronize()
+    s16 = e0.elapsed_time(e1) * 1e-3
+    res["f16_operands"] = {"frames_per_s": B * frames / s16, "us_per_layer_step": s16 / (frames * K) * 1e6,
+                           "matrix_stream_GBps": 0.5 * bytes_ls / (s16 / (frames * K)) / 1e9}
+    del U, S, W, P, P16, ws, out, X
     torch.cuda.empty_cache()
     return res
 

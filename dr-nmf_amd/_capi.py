@@ -22,7 +22,8 @@ class CellDesc(C.Structure):
 
 class DenseDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("B", "T", "F", "N", "K", "connect_input", "activation", "return_all_hidden")]
+                ("B", "T", "F", "N", "K", "connect_input", "activation", "return_all_hidden",
+                 "operand_f16")]
 
 
 ACTIVATIONS = {"linear": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "softplus": 4, "hard_sigmoid": 5}

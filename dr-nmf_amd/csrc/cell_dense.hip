@@ -23,6 +23,7 @@ namespace {
 
 struct DenseArgs {
     const float* M;          // stacked matrix of this layer, cell_a packing: block (c, ab) of 512 floats
+                             // (HALF: fp16, blocks (c32, ab) of 2 x 512 halves, pack_dense16_kernel)
     const float* bias;       // [Np]
     const float* xp;         // [T][Bp][Fp] packed input (pack_input_kernel)
     const float* h_in;       // [Bp][Np] packed h of layer k-1 (unused for layer 0)
@@ -55,7 +56,12 @@ __device__ __forceinline__ float activate(float v, int act) {
 // G operand slots per wave, prefetch distance G-1 (same rotation as cell_a_kernel); NW waves split
 // the contraction (the stacked matrices do not fit the Infinity Cache at the large shapes -- 36 MB
 // per layer at F=513, N=2000 -- so the operand stream comes from HBM and needs many loads in flight)
-template <int G, int NW, bool IS_LAST, bool WRITE_OUT>
+// HALF (drnmf_dense_desc_t.operand_f16): the matrices are stored as fp16 in the B-operand order of
+// v_mfma_f32_16x16x32_f16 for 32-row chunks of the contraction; the activations stay in their fp32 blocks
+// (they are a few % of the bytes) and are rounded to fp16 in registers: a 32-row chunk is two 16-row blocks,
+// lane (q, j) holds k = 16 b + 4 s + q (b = 0, 1; s = 0..3) of row j -- the matrix packing puts the same
+// eight rows, in that order, into lane (q, atom) (nP / nH / nX then count 32-row chunks).
+template <int G, int NW, bool IS_LAST, bool WRITE_OUT, bool HALF = false>
 __global__ void __launch_bounds__(64 * NW) dense_step_kernel(const DenseArgs a) {
     __shared__ __attribute__((aligned(16))) float red[NW * ROWS * ATOMS];
     const int mb = blockIdx.x >> 3;                           // grid layout: see cell_a_kernel
@@ -76,24 +82,43 @@ __global__ void __launch_bounds__(64 * NW) dense_step_kernel(const DenseArgs a) 
     const float* xseg = a.xp + (size_t)t * a.Bp * Fp + (size_t)mb * (Fp / 16) * 256 + l * 4;
     const float* brow = a.M + (size_t)ab * 512 + l * 4;
     const size_t bstep = (size_t)a.numA * 512;
+    const f16* brow16 = (const f16*)a.M + (size_t)ab * 1024 + l * 8;      // HALF: (c32, ab) = 2 x 512 halves
+    const size_t bstep16 = (size_t)a.numA * 1024;
     const int nPH = a.nP + a.nH, nch = nPH + a.nX;
     const int per_wave = (nch - w + NW - 1) / NW, clast = nch - 1;
+    const int xlast16 = Fp / 16 - 1;                 // HALF: the last 16-row block of x (Fp / 16 may be odd)
 
-    f32x4 av[G], bv[G][2];
+    f32x4 av[G][HALF ? 2 : 1], bv[HALF ? 1 : G][2];
+    f16x8 bh[HALF ? G : 1][2];
     auto load_chunk = [&](int i, int g) {
         int c = w + NW * i;
         c = c > clast ? clast : c;
-        const float* ap = c < a.nP ? pseg + 256 * c
-                                   : (c < nPH ? hseg + 256 * (c - a.nP) : xseg + 256 * (c - nPH));
-        av[g] = *(const f32x4*)ap;
-        bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
-        bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
+        if (HALF) {
+            const float *ap0, *ap1;
+            if (c < a.nP) { ap0 = pseg + 512 * c; ap1 = ap0 + 256; }
+            else if (c < nPH) { ap0 = hseg + 512 * (c - a.nP); ap1 = ap0 + 256; }
+            else {      // (an odd block count: the partner of the last block re-reads it against zero matrix rows)
+                const int b0 = 2 * (c - nPH), b1 = b0 + 1 > xlast16 ? xlast16 : b0 + 1;
+                ap0 = xseg + 256 * b0; ap1 = xseg + 256 * b1;
+            }
+            av[g][0] = *(const f32x4*)ap0;
+            av[g][HALF ? 1 : 0] = *(const f32x4*)ap1;
+            bh[g][0] = *(const f16x8*)(brow16 + (size_t)c * bstep16);
+            bh[g][1] = *(const f16x8*)(brow16 + (size_t)c * bstep16 + 512);
+        } else {
+            const float* ap = c < a.nP ? pseg + 256 * c
+                                       : (c < nPH ? hseg + 256 * (c - a.nP) : xseg + 256 * (c - nPH));
+            av[g][0] = *(const f32x4*)ap;
+            bv[g][0] = *(const f32x4*)(brow + (size_t)c * bstep);
+            bv[g][1] = *(const f32x4*)(brow + (size_t)c * bstep + 256);
+        }
     };
     constexpr int PF = G - 1;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        av[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bv[g][0] = bv[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        av[g][0] = av[g][HALF ? 1 : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (HALF) bh[g][0] = bh[g][1] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        else bv[g][0] = bv[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int g = 0; g < PF; ++g) load_chunk(g, g);
@@ -114,11 +139,20 @@ __global__ void __launch_bounds__(64 * NW) dense_step_kernel(const DenseArgs a) 
             load_chunk(base + g + PF, (g + PF) % G);
             __builtin_amdgcn_sched_barrier(0);
             const bool ok = base + g < per_wave;
+            if (HALF) {
+                const f32x4 a0 = av[g][0], a1 = av[g][HALF ? 1 : 0];
+                f16x8 a8 = {(f16)a0[0], (f16)a0[1], (f16)a0[2], (f16)a0[3],
+                            (f16)a1[0], (f16)a1[1], (f16)a1[2], (f16)a1[3]};
+                if (!ok) a8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                acc0 = mfma32h(a8, bh[g][0], acc0);
+                acc1 = mfma32h(a8, bh[g][1], acc1);
+            } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float r = ok ? av[g][s] : 0.f;
-                acc0 = mfma16(r, bv[g][s >> 1][(s & 1) * 2], acc0);
-                acc1 = mfma16(r, bv[g][s >> 1][(s & 1) * 2 + 1], acc1);
+                for (int s = 0; s < 4; ++s) {
+                    const float r = ok ? av[g][0][s] : 0.f;
+                    acc0 = mfma16(r, bv[g][s >> 1][(s & 1) * 2], acc0);
+                    acc1 = mfma16(r, bv[g][s >> 1][(s & 1) * 2 + 1], acc1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -245,6 +279,33 @@ pack_dense_kernel(const float* __restrict__ U, const float* __restrict__ S,
       ((fi >> 2) & 1) * 2 + (n32 & 1)] = v;
 }
 
+// The same stack as fp16 in the B-operand order of v_mfma_f32_16x16x32_f16 (dense_step_kernel<.., HALF>): block
+// (c, ab) = rows 32c..32c+31 x atoms 32ab..32ab+31 as two 512-half halves (even atoms, odd atoms); lane
+// (q, j) of a half holds rows 32c + 16b + 4s + q at e = 4b + s.  The x segment is padded to a multiple of 32
+// rows (Xp); padded rows / columns are zero.
+__global__ void __launch_bounds__(256)
+pack_dense16_kernel(const float* __restrict__ U, const float* __restrict__ S,
+                    const float* __restrict__ W, f16* __restrict__ M, int N, int F, int Np, int Xp,
+                    int L) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)L * Np) return;
+    const int i = (int)(idx / Np), n = (int)(idx % Np);
+    float v = 0.f;
+    if (n < N) {
+        if (i < Np) {
+            if (i < N) v = U[(size_t)i * N + n];
+        } else if (S && i < 2 * Np) {
+            if (i - Np < N) v = S[(size_t)(i - Np) * N + n];
+        } else if (W) {
+            const int f = i - (S ? 2 * Np : Np);
+            if (f < F) v = W[(size_t)f * N + n];
+        }
+    }
+    const int c = i >> 5, r = i & 31, b = r >> 4, s = (r & 15) >> 2, q = r & 3;
+    const int ab = n >> 5, j = (n & 31) >> 1, hsel = n & 1;
+    M[(((size_t)c * (Np / 32) + ab) * 2 + hsel) * 512 + (q * 16 + j) * 8 + 4 * b + s] = (f16)v;
+}
+
 __global__ void __launch_bounds__(256)
 pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int N, int Np, int K) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -255,10 +316,13 @@ pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int N, in
 
 struct DenseLayout {
     int Bp, Fp, Np, numA, nX;
+    int half, Xp;            // operand_f16: fp16 matrices, the x rows padded to a multiple of 32 (Xp)
     size_t L0, L1;           // stacked rows of layer 0 / of layers k > 0
     size_t off_bias, params_total;
     size_t off_xp, off_valid, off_h0, off_h1, off_state, off_t, off_drop, ws_total;
-    size_t m_off(int k) const { return k == 0 ? 0 : (L0 + (size_t)(k - 1) * L1) * Np * 4; }
+    size_t m_off(int k) const {
+        return k == 0 ? 0 : (L0 + (size_t)(k - 1) * L1) * Np * (half ? 2 : 4);
+    }
 };
 
 DenseLayout dense_layout(const drnmf_dense_desc_t* d) {
@@ -267,8 +331,10 @@ DenseLayout dense_layout(const drnmf_dense_desc_t* d) {
     D.Fp = pad_f(d->F);
     D.Np = pad_n(d->N);
     D.numA = D.Np / ATOMS;
-    D.nX = d->connect_input ? D.Fp / 16 : 0;
-    D.L0 = (size_t)D.Np + (d->connect_input ? D.Fp : 0);
+    D.half = d->operand_f16 != 0;
+    D.Xp = D.half ? round_up(D.Fp, 32) : D.Fp;
+    D.nX = d->connect_input ? (D.half ? D.Xp / 32 : D.Fp / 16) : 0;
+    D.L0 = (size_t)D.Np + (d->connect_input ? D.Xp : 0);
     D.L1 = D.L0 + D.Np;
     D.off_bias = round_up_sz(D.m_off(d->K), 256);
     D.params_total = D.off_bias + round_up_sz((size_t)d->K * D.Np * 4, 256);
@@ -297,11 +363,11 @@ int validate_dense_desc(drnmf_handle_t h, const drnmf_dense_desc_t* d) {
     return DRNMF_OK;
 }
 
-template <int G, int NW>
+template <int G, int NW, bool HALF = false>
 void* dense_func(bool last, bool write_out) {
-    if (last) return (void*)&dense_step_kernel<G, NW, true, true>;
-    return write_out ? (void*)&dense_step_kernel<G, NW, false, true>
-                     : (void*)&dense_step_kernel<G, NW, false, false>;
+    if (last) return (void*)&dense_step_kernel<G, NW, true, true, HALF>;
+    return write_out ? (void*)&dense_step_kernel<G, NW, false, true, HALF>
+                     : (void*)&dense_step_kernel<G, NW, false, false, HALF>;
 }
 
 }  // namespace
@@ -334,10 +400,16 @@ extern "C" int32_t drnmf_dense_prepare_params(drnmf_handle_t h, const drnmf_dens
     for (int k = 0; k < d->K; ++k) {
         const int L = (int)(k == 0 ? D.L0 : D.L1);
         const size_t tot = (size_t)L * D.Np;
-        hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                           stream, U + (size_t)k * NN, k > 0 ? S + (size_t)(k - 1) * NN : nullptr,
-                           d->connect_input ? W + (size_t)k * FN : nullptr,
-                           (float*)(base + D.m_off(k)), d->N, d->F, D.Np, D.Fp, L);
+        if (D.half)
+            hipLaunchKernelGGL(pack_dense16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                               stream, U + (size_t)k * NN, k > 0 ? S + (size_t)(k - 1) * NN : nullptr,
+                               d->connect_input ? W + (size_t)k * FN : nullptr,
+                               (f16*)(base + D.m_off(k)), d->N, d->F, D.Np, D.Xp, L);
+        else
+            hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                               stream, U + (size_t)k * NN, k > 0 ? S + (size_t)(k - 1) * NN : nullptr,
+                               d->connect_input ? W + (size_t)k * FN : nullptr,
+                               (float*)(base + D.m_off(k)), d->N, d->F, D.Np, D.Fp, L);
     }
     hipLaunchKernelGGL(pack_bias_kernel, dim3((unsigned)((d->K * D.Np + 255) / 256)), dim3(256), 0,
                        stream, b, (float*)(base + D.off_bias), d->N, D.Np, d->K);
@@ -401,8 +473,8 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
         else { a.t_rd = tA; a.t_wr = nullptr; a.t_wr_add = 0; }
         a.B = d->B; a.T = d->T; a.N = d->N; a.Bp = D.Bp; a.Fp = D.Fp; a.Np = D.Np;
         a.numA = D.numA;
-        a.nP = D.Np / 16;
-        a.nH = k > 0 ? D.Np / 16 : 0;
+        a.nP = D.half ? D.Np / 32 : D.Np / 16;
+        a.nH = k > 0 ? a.nP : 0;
         a.nX = D.nX;
         a.act = d->activation;
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
@@ -413,13 +485,16 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
     // waves per workgroup by contraction length (16-wide chunks).  Measured on MI355X, us per
     // layer-step with 4 / 8 / 16 waves: F=513 N=2000 B=64: 17.6 / 17.2 / 19.3; F=257 N=2000 B=32:
     // 14.9 / 13.8 / 16.8; F=257 N=200 B=32: 4.8 / 5.2 / 6.0
-    int nw = (D.Np / 16) * 2 + D.nX >= 128 ? 8 : 4;
+    int nw = (D.Np / 16) * 2 + (d->connect_input ? D.Fp / 16 : 0) >= 128 ? 8 : 4;
     if (const char* e = tune_env("DRNMF_DENSE_NW")) {   // tuning aid
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16) nw = v;
     }
     auto func = [&](int k) {
         const bool last = k == K - 1, wo = d->return_all_hidden != 0;
+        if (D.half)
+            return nw == 16 ? dense_func<4, 16, true>(last, wo)
+                            : (nw == 8 ? dense_func<4, 8, true>(last, wo) : dense_func<4, 4, true>(last, wo));
         return nw == 16 ? dense_func<4, 16>(last, wo)
                         : (nw == 8 ? dense_func<4, 8>(last, wo) : dense_func<4, 4>(last, wo));
     };
@@ -443,7 +518,7 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
             std::vector<uint64_t> key = {
                 0xDE05Eull, (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N,
                 (uint64_t)d->K, (uint64_t)d->connect_input, (uint64_t)d->activation,
-                (uint64_t)d->return_all_hidden, (uint64_t)(uintptr_t)params,
+                (uint64_t)d->return_all_hidden + 2 * (uint64_t)(d->operand_f16 != 0), (uint64_t)(uintptr_t)params,
                 (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)frames, (uint64_t)nw};
             for (auto& g : h->graphs)
                 if (g.key == key) { g.last_stream = stream; *out = g.exec; return DRNMF_OK; }

@@ -319,9 +319,6 @@ class SimpleDeepRNN(_Layer):
         if divergence != 'ed' and (self._generic or operand_dtype != 'float32'):
             raise NotImplementedError("divergence='kl'|'beta' exists for the build_alt "
                                       "configuration with fp32 operands")
-        if self._generic and operand_dtype != 'float32':
-            raise NotImplementedError("operand_dtype='float16' exists for the fused build_alt "
-                                      "configuration only")
         # Dropout is the identity outside the training phase (K.in_train_phase,
         # custom_layers.py:377-395).  In training the reference applies ONLY dropout_U: the layer sets
         # consume_less = 'gpu' (custom_layers.py:169), so get_constants never builds the dropout_W
@@ -486,7 +483,8 @@ class SimpleDeepRNN(_Layer):
         B, T, F = x.shape
         desc = ops.make_dense_desc(B, T, F, self.output_dim, self.K_layers,
                                    self.flag_connect_input_to_layers, self.activation,
-                                   self.flag_return_all_hidden)
+                                   self.flag_return_all_hidden,
+                                   operand_f16=self.operand_dtype == 'float16')
         if not self._dense_block_valid:
             U, S, W, b = self.dense_matrices()
             dev = x.device
@@ -705,8 +703,11 @@ class SimpleDeepRNN(_Layer):
     def _forward_train_dense(self, x, mask_value):
         B, T, F = x.shape
         leaves, U, S, W, b, h0 = self._dense_matrices_torch()
+        # (operand_dtype='float16': the forward on fp16 matrix-core operands, the BPTT in fp32 from the stored
+        # hiddens -- mixed precision, as on the fused path)
         desc = ops.make_dense_desc(B, T, F, self.output_dim, self.K_layers,
-                                   self.flag_connect_input_to_layers, self.activation, True)
+                                   self.flag_connect_input_to_layers, self.activation, True,
+                                   operand_f16=self.operand_dtype == 'float16')
         c = lambda v: None if v is None else v.detach().contiguous()
         block = ops.dense_prepare_params(desc, c(U), c(S), c(W), c(b),
                                          out=getattr(self, '_dense_train_block', None))
@@ -1178,8 +1179,6 @@ class UnfoldedSNMFModel(object):
         if cell.dropout_U:
             cell._train_dense = True
         if cell._train_dense:
-            if cell.operand_dtype != 'float32':
-                raise NotImplementedError("operand_dtype='float16' trains on the fused path only")
             self._train_items = cell.trainable_weight_items()
         else:
             # flat-buffer order = the order of the BPTT's stacked outputs (d_log_D [n_D,F,N], d_log_h0,

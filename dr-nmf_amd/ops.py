@@ -145,12 +145,13 @@ def cell_forward(x, mask_value, params, desc, log_h0, u, out=None, workspace=Non
 
 
 def make_dense_desc(B, T, F, N, K, connect_input=True, activation="relu",
-                    return_all_hidden=False):
+                    return_all_hidden=False, operand_f16=False):
     if activation not in _capi.ACTIVATIONS:
         raise ValueError("activation %r is not one of %s" % (activation,
                                                              sorted(_capi.ACTIVATIONS)))
     return _capi.DenseDesc(int(B), int(T), int(F), int(N), int(K), int(bool(connect_input)),
-                           _capi.ACTIVATIONS[activation], int(bool(return_all_hidden)))
+                           _capi.ACTIVATIONS[activation], int(bool(return_all_hidden)),
+                           int(bool(operand_f16)))
 
 
 def dense_prepare_params(desc, U, S, W, b, out=None):

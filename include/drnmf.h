@@ -213,6 +213,11 @@ typedef struct drnmf_dense_desc {
                                 * layer 0 included (custom_layers.py:366-368)                   */
     int32_t activation;        /* DRNMF_ACT_*                                                   */
     int32_t return_all_hidden; /* flag_return_all_hidden                                        */
+    int32_t operand_f16;       /* extension, as in drnmf_cell_desc_t: the stacked matrices are STORED as
+                                * fp16 and the state / hidden / input rounded to fp16 where they enter the
+                                * products (v_mfma_f32_16x16x32_f16, fp32 accumulation, bias, activation,
+                                * state, output).  Forward only: drnmf_dense_cell_backward on such a
+                                * descriptor is the fp32 BPTT of that forward (mixed precision)          */
 } drnmf_dense_desc_t;
 /*   U [K][N][N], S [K-1][N][N] (NULL when K == 1), W [K][F][N] (NULL without connect_input),
  *   b [K][N]: the matrices Uk/Sk/Wk/bk of SimpleDeepRNN.build in the reference's orientation

@@ -151,7 +151,7 @@ ACTIVATIONS = {
 
 def cell_forward_dense(x, Wk, Uk, bk, Sk, log_h0, mask_value=-1.0, return_all_hidden=False,
                        connect_input=True, dtype=np.float64, activation='relu', h0=None,
-                       initial_state=None, return_state=False):
+                       initial_state=None, return_state=False, operand_dtype=None):
     """The reference's op graph: per frame, K layers of relu(p U_k + h^(k-1) S_k + x Wk_k + b_k)
     (custom_layers.py:361-369), scanned over time with Keras' masked-RNN rule
     [K2.0.4-memory: theano_backend.rnn] -- a masked step repeats the previous OUTPUT (zeros before
@@ -159,8 +159,17 @@ def cell_forward_dense(x, Wk, Uk, bk, Sk, log_h0, mask_value=-1.0, return_all_hi
     (custom_layers.py:203-206, 336-341).  Returns h:(B,T,N) (or (B,T,K*N) if return_all_hidden).
     General form of the step (custom_layers.py:343-375): `activation` by Keras name; h0 = the
     initial state itself when flag_nonnegative is off (the `h0` weight, custom_layers.py:208-211);
-    connect_input=False drops x from every layer; initial_state (B,N) = stateful mode."""
+    connect_input=False drops x from every layer; initial_state (B,N) = stateful mode.
+    operand_dtype=np.float16 emulates the device's fp16-operand mode of this path (an extension): the
+    matrices and, where they enter a product, the state, the previous layer's hidden and x_t are rounded
+    to fp16; sums, bias, activation, state and output stay in `dtype`."""
     x = np.asarray(x, dtype=dtype)
+    if operand_dtype is not None:
+        rnd = lambda a: np.asarray(a, dtype=dtype).astype(operand_dtype).astype(dtype)
+        Wk, Uk = [rnd(m) for m in Wk], [rnd(m) for m in Uk]
+        Sk = [rnd(m) for m in Sk]
+    else:
+        rnd = lambda a: a
     B, T, F = x.shape
     K = len(Uk)
     N = Uk[0].shape[1]
@@ -175,14 +184,14 @@ def cell_forward_dense(x, Wk, Uk, bk, Sk, log_h0, mask_value=-1.0, return_all_hi
     out_prev = np.zeros((B, width), dtype=dtype)
     hs = np.empty((B, T, width), dtype=dtype)
     for t in range(T):
-        p = state[:, -N:]
+        p = rnd(state[:, -N:])
         hidden = []
         for k in range(K):
             pre = p @ Uk[k]
             if k > 0:
-                pre = pre + hidden[k - 1] @ Sk[k - 1]
+                pre = pre + rnd(hidden[k - 1]) @ Sk[k - 1]
             if connect_input:
-                pre = pre + xm[:, t] @ Wk[k]
+                pre = pre + rnd(xm[:, t]) @ Wk[k]
             hidden.append(act(pre + bk[k]))
         out = np.concatenate(hidden, axis=1) if return_all_hidden else hidden[-1]
         v = valid[:, t][:, None]

@@ -68,6 +68,7 @@ static void size_queries(void) {
                         memset(&dd, 0, sizeof(dd));
                         dd.B = d.B; dd.T = d.T; dd.F = d.F; dd.N = d.N > 2000 ? 2000 : d.N; dd.K = d.K;
                         dd.connect_input = var & 1; dd.activation = var % 6; dd.return_all_hidden = var == 2;
+                        dd.operand_f16 = var == 3;
                         total += drnmf_dense_params_bytes(&dd) + drnmf_dense_workspace_bytes(&dd) +
                                  drnmf_dense_backward_workspace_bytes(&dd);
                     }

@@ -665,3 +665,92 @@ def test_dense_kernels_match_reference_step_golden(dev, golden, tag):
     params = ops.dense_prepare_params(desc, t(U), t(S), t(W) if connect else None, t(b))
     h = ops.dense_cell_forward(t(X), -1.0, params, desc, t(g[pre + "h0"]), drop_u=t(B_U))
     _check(h.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, T=5, F=21, N=12, K=1),                                  # Fp / 16 = 2: whole 32-row chunks of x
+    dict(B=5, T=6, F=33, N=40, K=3),                                  # Fp / 16 = 3: the odd block's partner
+    dict(B=17, T=4, F=65, N=70, K=2, activation="tanh"),              # two row tiles, Fp / 16 = 5
+    dict(B=4, T=5, F=20, N=16, K=3, all_hidden=True, activation="sigmoid"),
+    dict(B=2, T=4, F=16, N=24, K=2, connect=False),
+    dict(B=3, T=3, F=513, N=200, K=2),                                # STFT size 2^k + 1: 8 waves
+])
+def test_dense_cell_fp16_operands(dev, cfg):
+    """drnmf_dense_desc_t.operand_f16 (an extension, as BASELINE config 5's mode of the fused cell): matrices
+    stored as fp16, state / hidden / input rounded to fp16 where they enter the products, fp32 accumulation and
+    update.  Against the oracle's emulation of the same rounding points (tight) and against the exact op graph
+    (loose: the rounding itself); masked frames, stateful entry and exit, a recurrent dropout mask."""
+    from drnmf_amd import ops
+    B, T, F, N, K = cfg["B"], cfg["T"], cfg["F"], cfg["N"], cfg["K"]
+    act, connect, ah = cfg.get("activation", "relu"), cfg.get("connect", True), cfg.get("all_hidden", False)
+    rng = np.random.default_rng(300 + B + 7 * T + N)
+    U, S, W, b = _random_mats(rng, K, N, F)
+    h0 = np.abs(rng.standard_normal(N)).astype(np.float32) * 0.3
+    X = _ragged_x(rng, B, T, F)
+    init = np.abs(rng.standard_normal((B, N))).astype(np.float32) * 0.2
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    desc = ops.make_dense_desc(B, T, F, N, K, connect, act, ah, operand_f16=True)
+    params = ops.dense_prepare_params(desc, t(U), t(S) if K > 1 else None, t(W) if connect else None, t(b))
+    lst = lambda m: [m[i] for i in range(m.shape[0])]
+    for stateful in (False, True):
+        fin = torch.empty((B, N), dtype=torch.float32, device=dev) if stateful else None
+        h = ops.dense_cell_forward(t(X), -1.0, params, desc, t(h0), initial_state=t(init) if stateful else None,
+                                   final_state=fin).cpu().numpy()
+        kw = dict(h0=h0, return_all_hidden=ah, connect_input=connect, activation=act,
+                  initial_state=init if stateful else None, return_state=stateful)
+        emu = O.cell_forward_dense(X, lst(W), lst(U), lst(b), lst(S), None, operand_dtype=np.float16, **kw)
+        exact = O.cell_forward_dense(X, lst(W), lst(U), lst(b), lst(S), None, **kw)
+        if stateful:
+            (emu, emu_state), (exact, _) = emu, exact
+            assert np.max(np.abs(fin.cpu().numpy() - emu_state[:, -N:])) <= 2e-3 * max(np.max(np.abs(emu_state)), 1e-30)
+        scale = max(np.max(np.abs(emu)), 1e-30)
+        assert np.all(np.isfinite(h))
+        assert np.max(np.abs(h - emu)) / scale <= 2e-3, np.max(np.abs(h - emu)) / scale
+        assert np.sqrt(np.mean((h - emu) ** 2)) / scale <= 2e-4
+        assert np.max(np.abs(h - exact)) / scale <= 3e-2          # the fp16 rounding itself, K layers deep
+        assert np.max(np.abs(emu - exact)) > 0                    # (the emulation does round)
+    # the fp32 descriptor on the same inputs is the exact path (the flag is what switches)
+    d32 = ops.make_dense_desc(B, T, F, N, K, connect, act, ah)
+    p32 = ops.dense_prepare_params(d32, t(U), t(S) if K > 1 else None, t(W) if connect else None, t(b))
+    _check(ops.dense_cell_forward(t(X), -1.0, p32, d32, t(h0)).cpu().numpy(),
+           O.cell_forward_dense(X, lst(W), lst(U), lst(b), lst(S), None, h0=h0, return_all_hidden=ah,
+                                connect_input=connect, activation=act))
+
+
+def test_generic_layer_runs_and_trains_with_fp16_operands(dev):
+    """SimpleDeepRNN(operand_dtype='float16') outside build_unfolded_snmf's configuration (free weights, tanh): the
+    layer's forward is the fp16-operand dense kernel; under training the forward runs in that mode and the BPTT in
+    fp32 from the stored hiddens (mixed precision): gradients within the rounding of the fp64 autograd of the exact
+    op graph."""
+    from drnmf_amd import layers
+    from oracle import drnmf_torch_ref as R
+    B, T, F, N, K = 5, 6, 12, 16, 2
+    rng = np.random.default_rng(77)
+    np.random.seed(3)
+    cell = layers.SimpleDeepRNN(N, activation="tanh", K_layers=K, flag_connect_input_to_layers=True,
+                                flag_nonnegative=False, return_sequences=True, operand_dtype="float16", device=dev)
+    X = _ragged_x(rng, B, T, F)
+    x = torch.from_numpy(X).to(dev)
+    cell.build(tuple(x.shape))
+    names = [n[len(cell.name) + 1:] for n in cell.weight_names]
+    w = dict(zip(names, cell.get_weights()))
+    lst = lambda pre, n: [w["%s_%d" % (pre, k)] for k in range(n)]
+    Ws, Us, bs = lst("W", K), lst("U", K), lst("b", K)
+    Ss = [w["S_%dto%d" % (k - 1, k)] for k in range(1, K)]
+    emu = O.cell_forward_dense(X, Ws, Us, bs, Ss, None, h0=w["h0"], activation="tanh", operand_dtype=np.float16)
+    h = cell.call(x, mask_value=-1.).cpu().numpy()
+    assert np.max(np.abs(h - emu)) <= 2e-3 * np.max(np.abs(emu))
+    Rw = rng.standard_normal((B, T, N)).astype(np.float32)
+    hall = cell.forward_train(x, mask_value=-1.)
+    g = cell.backward(x, hall, torch.from_numpy(Rw).to(dev))["by_name"]
+    td = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    L = {n: td(w[n]) for n in names}
+    out = R.dense_cell(torch.tensor(X.astype(np.float64)), torch.stack([L["U_%d" % k] for k in range(K)]),
+                       torch.stack([L["S_%dto%d" % (k - 1, k)] for k in range(1, K)]),
+                       torch.stack([L["W_%d" % k] for k in range(K)]), torch.stack([L["b_%d" % k] for k in range(K)]),
+                       L["h0"], activation="tanh")
+    (out * torch.tensor(Rw.astype(np.float64))).sum().backward()
+    for n, gv in g.items():
+        want = L[n].grad.numpy()
+        err = np.max(np.abs(gv.cpu().numpy() - want)) / max(np.max(np.abs(want)), 1e-30)
+        assert err <= 2e-2, "%s: max|dg|/max|g| = %.3e" % (n, err)

@@ -139,8 +139,10 @@ def test_simple_deep_rnn_config_surface():
     # ... what has no meaning raises
     with pytest.raises(ValueError):
         layers.SimpleDeepRNN(N, **dict(ok, activation="swish"))
+    # (fp16 operands on the dense-matrix path: tests/test_gpu_dense.py; with the KL / beta cell they stay refused)
+    assert layers.SimpleDeepRNN(N, **dict(ok, activation="tanh", operand_dtype="float16"))._generic
     with pytest.raises(NotImplementedError):
-        layers.SimpleDeepRNN(N, **dict(ok, activation="tanh", operand_dtype="float16"))
+        layers.SimpleDeepRNN(N, **dict(ok, divergence="kl", operand_dtype="float16"))
 
 
 def test_build_unfolded_snmf_argument_errors():
