@@ -140,6 +140,37 @@ def test_fuzz_dense_cell(dev):
             (dict(B=B, T=T, F=F, N=N, K=K, act=act, connect=connect, ah=ah, masked=masked, st=st), e1, e2)
 
 
+def test_fuzz_dense_cell_fp16_operands(dev):
+    """drnmf_dense_desc_t.operand_f16 over random shapes (odd and even counts of 16-row blocks in every segment of
+    the contraction, 4 / 8 waves), activations, flags, stateful entry: against the oracle's emulation of the
+    rounding points."""
+    from drnmf_amd import ops
+    rng = np.random.default_rng(4242)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    acts = ["linear", "relu", "tanh", "sigmoid", "softplus", "hard_sigmoid"]
+    for it in range(60):
+        B = int(rng.choice([1, 2, 7, 16, 17, 33, 48]))
+        T = int(rng.integers(1, 7))
+        F = int(rng.choice([5, 15, 16, 17, 31, 32, 33, 47, 48, 49, 65, 129, 257]))
+        N = int(rng.choice([2, 6, 16, 17, 31, 32, 33, 64, 70, 100, 200]))
+        K = int(rng.integers(1, 5))
+        act = acts[int(rng.integers(0, 6))]
+        connect, ah, st = (bool(rng.integers(0, 2)) for _ in range(3))
+        U, S, W, b = TD._random_mats(rng, K, N, F)
+        h0 = np.abs(rng.standard_normal(N)).astype(np.float32) * 0.3
+        X = TD._ragged_x(rng, B, T, F)
+        init = np.abs(rng.standard_normal((B, N))).astype(np.float32) * 0.2 if st else None
+        desc = ops.make_dense_desc(B, T, F, N, K, connect, act, ah, operand_f16=True)
+        params = ops.dense_prepare_params(desc, t(U), t(S) if K > 1 else None, t(W) if connect else None, t(b))
+        h = ops.dense_cell_forward(t(X), -1.0, params, desc, t(h0), initial_state=t(init)).cpu().numpy()
+        emu = O.cell_forward_dense(X, list(W), list(U), list(b), list(S), None, h0=h0, return_all_hidden=ah,
+                                   connect_input=connect, activation=act, initial_state=init,
+                                   operand_dtype=np.float16)
+        err = np.max(np.abs(h - emu)) / max(np.max(np.abs(emu)), 1e-30)
+        assert np.all(np.isfinite(h)) and err <= 3e-3, \
+            (dict(B=B, T=T, F=F, N=N, K=K, act=act, connect=connect, ah=ah, st=st, it=it), err)
+
+
 def test_fuzz_ista_and_mu(dev):
     from drnmf_amd import ops
     rng = np.random.default_rng(5)
