@@ -75,7 +75,7 @@ def parse_trace(text):
     return np.array(rows)
 
 
-def main():
+def main(out_path=None):
     enh = extract(os.path.join(REF, 'enhance.py'),
                   ['kl_div', 'beta_div', 'ista_ed', 'ista_kl', 'ista_beta'])
     utl = extract(os.path.join(REF, 'util.py'),
@@ -324,8 +324,9 @@ def main():
         out['wav_%s_read' % tag] = ut['wavread'](path)
     shutil.rmtree(tmpd)
 
-    np.savez_compressed(os.path.join(HERE, 'reference_numpy_golden.npz'), **out)
-    print('wrote', os.path.join(HERE, 'reference_numpy_golden.npz'), len(out), 'arrays')
+    out_path = out_path or os.path.join(HERE, 'reference_numpy_golden.npz')
+    np.savez_compressed(out_path, **out)
+    print('wrote', out_path, len(out), 'arrays')
 
 
 if __name__ == '__main__':

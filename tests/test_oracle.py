@@ -1,5 +1,7 @@
 """Pin the CPU oracle: against golden vectors produced by the reference's own numpy functions
 (tests/golden/make_golden.py) and through the algebraic identities of SURVEY.md section 4."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,25 @@ from oracle import drnmf_oracle as O
 
 
 # ------------------------------------------------------------------ golden vectors (reference)
+@pytest.mark.filterwarnings("ignore::DeprecationWarning", "ignore::SyntaxWarning")   # (the reference's py2 string escapes)
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference lives in the build container only")
+def test_golden_file_is_what_the_reference_produces_today(golden, tmp_path):
+    """Where the reference is present: run the committed generator again and compare every array with the
+    committed fixture, bit for bit (the fixture is data produced by the reference's own code, nothing else)."""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")
+    spec = importlib.util.spec_from_file_location("make_golden", here)
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    out = str(tmp_path / "again.npz")
+    mg.main(out)
+    again = np.load(out)
+    assert sorted(again.files) == sorted(golden.files)
+    for k in golden.files:
+        assert again[k].dtype == golden[k].dtype and np.array_equal(again[k], golden[k]), k
+
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 @pytest.mark.parametrize("name", ["ed", "kl", "beta"])
 def test_ista_matches_reference_golden(golden, tag, name):
