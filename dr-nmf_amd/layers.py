@@ -1128,6 +1128,11 @@ class UnfoldedSNMFModel(object):
         ops.check_status(dev)
         return out
 
+    def free_predict_buffers(self):
+        """Drop the pinned staging buffers, device slabs and copy streams `predict` / `predict_on_batch` keep
+        between calls (they are re-made on the next call)."""
+        self._predict_pipe = None
+
     __call__ = forward
 
     # -- training: loss 'mse_of_masked' + Adam (enhance.py:1040-1073, 1152) -----------------
