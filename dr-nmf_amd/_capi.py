@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libdrnmf.so")
 OK = 0
 COMM_ID_BYTES = 128          # DRNMF_COMM_ID_BYTES
 DIV_ED, DIV_KL, DIV_BETA = 0, 1, 2
+MATRIX_F32, MATRIX_BF16X3 = 0, 1     # DRNMF_MATRIX_*
 
 
 class CellDesc(C.Structure):
@@ -91,6 +92,8 @@ SIGNATURES = {
     "drnmf_check_status": (_i32, [_vp]),
     "drnmf_status_take_device": (_i32, [_vp, _vp, _vp]),
     "drnmf_reload_env": (_i32, []),
+    "drnmf_set_matrix_mode": (_i32, [_vp, _i32]),
+    "drnmf_get_matrix_mode": (_i32, [_vp]),
     "drnmf_persist_admitted": (_i32, [_vp]),
     "drnmf_persist_admit_reason": (C.c_char_p, [_vp]),
     "drnmf_host_report_ring": (_i32, [_vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(_i32)]),

@@ -151,6 +151,14 @@ struct drnmf_handle_s {
     // handles are independent of each other.  Recursive: drnmf_destroy -> drnmf_comm_destroy.
     std::recursive_mutex mu;
     int device = 0;
+    int matrix_mode = DRNMF_MATRIX_F32;  // drnmf_set_matrix_mode: how the frame-parallel products contract
+    // DRNMF_MATRIX_BF16X3 only: device scratch for the Bt operand of a frame-parallel product, split into
+    // its bf16 planes by a pre-pass (gemm_nt_x3.h) -- one buffer per stream that ran such a product, grown
+    // on demand; outgrown buffers are parked (work already enqueued may still read them) and freed by
+    // drnmf_destroy.  The one device allocation the library makes on its own (include/drnmf.h).
+    struct X3Scratch { hipStream_t stream; void* ptr; size_t bytes; };
+    std::vector<X3Scratch> x3_scratch;
+    std::vector<void*> x3_parked;
     char err[512] = {0};
     std::vector<GraphEntry> graphs;      // least recently used first
     uint64_t call_seq = 0;               // top-level forward calls so far (GraphEntry::pin)
@@ -210,9 +218,26 @@ int32_t graph_cache_make_room(drnmf_handle_t h, hipStream_t stream, size_t max_e
 
 extern char g_create_err[512];
 
+// The matrix mode of the handle whose entry point this thread is inside (drnmf_set_matrix_mode): read by
+// gemm::launch / gemm_tn::launch, which see operands and a stream but no handle.
+extern thread_local int tl_matrix_mode;
+extern thread_local drnmf_handle_t tl_handle;
+struct MatrixModeScope {
+    int prev;
+    drnmf_handle_t prev_h;
+    explicit MatrixModeScope(drnmf_handle_t h) : prev(tl_matrix_mode), prev_h(tl_handle) {
+        if (h) { tl_matrix_mode = h->matrix_mode; tl_handle = h; }
+    }
+    ~MatrixModeScope() { tl_matrix_mode = prev; tl_handle = prev_h; }
+};
+// >= bytes of device scratch for split operands, private to (the current entry point's handle, stream);
+// NULL without a handle / device or when the allocation fails (the caller then takes the fp32 kernels)
+void* x3_scratch_get(hipStream_t stream, size_t bytes);
+
 #define DRNMF_LOCK(h)                                        \
     std::unique_lock<std::recursive_mutex> handle_lock_;     \
-    if (h) handle_lock_ = std::unique_lock<std::recursive_mutex>((h)->mu)
+    if (h) handle_lock_ = std::unique_lock<std::recursive_mutex>((h)->mu); \
+    MatrixModeScope matrix_mode_scope_(h)
 
 #define DRNMF_FAIL(h, code, ...)                                  \
     do {                                                          \

@@ -28,6 +28,9 @@ struct Operands {
     int64_t lda, ldb;
     int ktail = 0;    // extra contraction columns K .. K+ktail-1 (<= 2), see below
     int thin = 0;     // 1: output column N (row N of Bt) exists BEHIND the N tiled columns, see THIN below
+    // split-operand mode only (gemm_nt_x3.h; set by launch()): Bt already split into bf16 planes
+    const void* B3 = nullptr;
+    int kt3 = 0;
 };
 
 // VEC: lda, ldb, K multiples of 4, base pointers 16-byte aligned -> one branch-free float4 load
@@ -390,6 +393,10 @@ inline int64_t launch_tiles(const Operands& g) {
     return ((g.M + BM - 1) / BM) * ((n + BN - 1) / BN);
 }
 
+// gemm_nt_x3.h: the same product with split operands (matrix mode DRNMF_MATRIX_BF16X3)
+template <class Epi>
+inline hipError_t launch_x3(const Operands& g, bool thin, const Epi& epi, hipStream_t stream, bool* taken);
+
 template <class Epi>
 inline hipError_t launch(const Operands& g_in, const Epi& epi, hipStream_t stream) {
     Operands g = g_in;
@@ -399,6 +406,11 @@ inline hipError_t launch(const Operands& g_in, const Epi& epi, hipStream_t strea
     const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (tiles <= 0 || tiles > 0x7fffffff || g.M > 0x7fffff00 || g.ktail < 0 || g.ktail > 2)
         return hipErrorInvalidValue;
+    if (vec && tl_matrix_mode == DRNMF_MATRIX_BF16X3) {
+        bool taken = false;
+        const hipError_t e = launch_x3(g, thin, epi, stream, &taken);
+        if (taken || e != hipSuccess) return e;
+    }
     if (thin)
         hipLaunchKernelGGL((gemm_nt_kernel<Epi, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream,
                            g, epi);
@@ -412,3 +424,5 @@ inline hipError_t launch(const Operands& g_in, const Epi& epi, hipStream_t strea
 }
 
 }  // namespace gemm
+
+#include "gemm_nt_x3.h"

@@ -22,7 +22,7 @@ const char* const kTuneNames[] = {
     "DRNMF_ABLATE", "DRNMF_ABLATE_A", "DRNMF_ABLATE_B", "DRNMF_CP_FULL", "DRNMF_DENSE_NW", "DRNMF_FPG",
     "DRNMF_GRAM", "DRNMF_KS", "DRNMF_LATE", "DRNMF_NO_ALLB", "DRNMF_NO_GRAPH",
     "DRNMF_PERSIST", "DRNMF_PERSIST_FAULT", "DRNMF_RB", "DRNMF_RBA", "DRNMF_SPLIT",
-    "DRNMF_THIN", "DRNMF_PF", "DRNMF_PF_SLEEP"};
+    "DRNMF_THIN", "DRNMF_PF", "DRNMF_PF_SLEEP", "DRNMF_NT_XCD"};
 std::mutex g_tune_mu;
 // (values are never erased or overwritten in place: a pointer handed out stays valid for the
 // process lifetime; a reload appends a new generation)
@@ -50,6 +50,45 @@ extern "C" int32_t drnmf_reload_env(void) {
 }
 
 extern "C" int32_t drnmf_version(void) { return DRNMF_VERSION; }
+
+thread_local int tl_matrix_mode = DRNMF_MATRIX_F32;
+thread_local drnmf_handle_t tl_handle = nullptr;
+
+void* x3_scratch_get(hipStream_t stream, size_t bytes) {
+    drnmf_handle_t h = tl_handle;          // (the entry point that got us here holds h->mu)
+    if (!h || h->device < 0) return nullptr;
+    for (auto& s : h->x3_scratch) {
+        if (s.stream != stream) continue;
+        if (s.bytes >= bytes) return s.ptr;
+        void* p = nullptr;
+        const size_t want = bytes + bytes / 2;
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        h->x3_parked.push_back(s.ptr);
+        s.ptr = p;
+        s.bytes = want;
+        return p;
+    }
+    void* p = nullptr;
+    const size_t want = bytes < ((size_t)16 << 20) ? ((size_t)16 << 20) : bytes;
+    if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    h->x3_scratch.push_back({stream, p, want});
+    return p;
+}
+
+extern "C" int32_t drnmf_set_matrix_mode(drnmf_handle_t h, int32_t mode) {
+    DRNMF_LOCK(h);
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (mode != DRNMF_MATRIX_F32 && mode != DRNMF_MATRIX_BF16X3)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "set_matrix_mode: unknown mode %d", mode);
+    h->matrix_mode = mode;
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_get_matrix_mode(drnmf_handle_t h) {
+    DRNMF_LOCK(h);
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    return h->matrix_mode;
+}
 
 extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
     if (!out) return DRNMF_ERR_INVALID_ARG;
@@ -244,6 +283,11 @@ extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
     if (h->persist_done) (void)hipEventDestroy(h->persist_done);
     if (h->persist_flag) (void)hipHostFree(h->persist_flag);
     if (h->persist_lock_fd >= 0) close(h->persist_lock_fd);      // (releases the flock)
+    if (!h->x3_scratch.empty() || !h->x3_parked.empty()) {
+        (void)hipDeviceSynchronize();
+        for (auto& s : h->x3_scratch) (void)hipFree(s.ptr);
+        for (void* p : h->x3_parked) (void)hipFree(p);
+    }
     delete h;
     return DRNMF_OK;
 }

@@ -659,6 +659,28 @@ def reload_env():
     _capi.lib().drnmf_reload_env()
 
 
+MATRIX_MODES = {"f32": _capi.MATRIX_F32, "bf16x3": _capi.MATRIX_BF16X3}
+
+
+def set_matrix_mode(mode, device=None):
+    """How the frame-parallel matrix products of this process's handle on `device` contract
+    (include/drnmf.h, DRNMF_MATRIX_*): 'f32' (exact-fp32 MFMA, the default) or 'bf16x3' (three bf16 planes
+    per operand, six bf16 MFMAs per product, fp32 accumulate).  Returns the previous mode's name."""
+    if mode not in MATRIX_MODES:
+        raise ValueError("matrix mode must be one of %s" % sorted(MATRIX_MODES))
+    L = _capi.lib()
+    h = _capi.handle(torch.cuda.current_device() if device is None else _dev_of(device))
+    prev = L.drnmf_get_matrix_mode(h)
+    _capi.check(L.drnmf_set_matrix_mode(h, MATRIX_MODES[mode]), h, "drnmf_set_matrix_mode")
+    return {v: k for k, v in MATRIX_MODES.items()}[prev]
+
+
+def get_matrix_mode(device=None):
+    L = _capi.lib()
+    h = _capi.handle(torch.cuda.current_device() if device is None else _dev_of(device))
+    return {v: k for k, v in MATRIX_MODES.items()}[L.drnmf_get_matrix_mode(h)]
+
+
 def divide_a_by_aplusb(A, B):
     """exp(log(1e-7+A) - log(1e-7+A+B)) (custom_layers.py:41-45), elementwise."""
     L = _capi.lib()

@@ -50,6 +50,19 @@ enum {
 /* divergence selector for the frame-parallel ISTA / MU kernels */
 enum { DRNMF_DIV_ED = 0, DRNMF_DIV_KL = 1, DRNMF_DIV_BETA = 2 };
 
+/* How the frame-parallel (time-batched) matrix products contract -- drnmf_set_matrix_mode.
+ *   DRNMF_MATRIX_F32     exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain).  The default, and
+ *                        what every figure labelled "f32" is measured with: the reference computes in
+ *                        float32 (enhance.py:219-223).
+ *   DRNMF_MATRIX_BF16X3  every fp32 operand split into three bf16 planes (hi + mid + lo = the fp32 value
+ *                        exactly) on its way into LDS; six v_mfma_f32_32x32x16_bf16 per product (hi.hi,
+ *                        hi.mid, mid.hi, hi.lo, lo.hi, mid.mid), fp32 accumulate.  The dropped terms are
+ *                        below 2^-26 of |a||b| -- under the rounding of the fp32 accumulation itself -- at
+ *                        2.67x the matrix rate of the fp32 pipe.  Results differ from the f32 mode in the
+ *                        last bits (error table against the fp64 oracle: profiles/r06_x3_error_table.md);
+ *                        every tolerance of the test suite holds in both modes. */
+enum { DRNMF_MATRIX_F32 = 0, DRNMF_MATRIX_BF16X3 = 1 };
+
 typedef struct drnmf_handle_s* drnmf_handle_t;
 
 /* Problem descriptor of the recurrent cell (SimpleDeepRNN, custom_layers.py:104-412, as
@@ -103,9 +116,10 @@ int32_t drnmf_status_take_device(drnmf_handle_t h, float* dst_device, void* stre
  * the device; the first handle that takes an exclusive flock on /tmp/drnmf_persist_<pci bus id>.lock
  * (at drnmf_create, held until drnmf_destroy / process exit) is the one admitted. */
 int32_t drnmf_persist_admitted(drnmf_handle_t h);
-/* Why (not): a static-lifetime, human-readable sentence owned by the handle ("admitted", "lock file
- * ... is held by another process", "open(...) failed: Permission denied", ...).  Never NULL for a
- * valid handle. */
+/* Why (not): a human-readable sentence ("admitted", "lock file ... is held by another process",
+ * "open(...) failed: Permission denied", ...) written once by drnmf_create and never changed afterwards; it
+ * lives IN the handle and dies with it (copy it if it must outlive drnmf_destroy).  Never NULL for a valid
+ * handle. */
 const char* drnmf_persist_admit_reason(drnmf_handle_t h);
 /* A ring of `*slots` 4-float slots in host-mapped, coherent memory owned by the handle: a valid
  * DEVICE pointer for the `report4` argument of drnmf_adam_step_flat and readable by the host once an
@@ -115,6 +129,13 @@ int32_t drnmf_host_report_ring(drnmf_handle_t h, float** ring_host, int32_t* slo
 /* Tuning / measurement variables (DRNMF_*) are read from the environment once
  * per process; drnmf_reload_env retakes the snapshot (tests that flip a variable between calls). */
 int32_t drnmf_reload_env(void);
+
+/* Matrix mode of the handle (above): applies to every later call on it that runs frame-parallel products
+ * (ISTA / MU inference, dictionary training, the mask head, the time-batched weight gradients and hoisted
+ * products of the cell).  The recurrent chain kernels always contract in exact fp32 (or fp16 operands,
+ * drnmf_cell_desc_t.operand_f16).  No reference counterpart: Theano picks its own GEMM. */
+int32_t drnmf_set_matrix_mode(drnmf_handle_t h, int32_t mode);
+int32_t drnmf_get_matrix_mode(drnmf_handle_t h);
 
 /* ---- parameter maps: replaces build_alt's maps_from_alt lambdas (enhance.py:161-204) and their
  * evaluation in SimpleDeepRNN.build (custom_layers.py:234-287).
