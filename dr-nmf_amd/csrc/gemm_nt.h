@@ -31,6 +31,7 @@ struct Operands {
     // split-operand mode only (gemm_nt_x3.h; set by launch()): Bt already split into bf16 planes
     const void* B3 = nullptr;
     int kt3 = 0;
+    int per_xcd = 0;  // tiles per XCD of the XCD-aware workgroup -> tile map (0: identity)
 };
 
 // VEC: lda, ldb, K multiples of 4, base pointers 16-byte aligned -> one branch-free float4 load

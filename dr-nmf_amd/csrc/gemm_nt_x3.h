@@ -57,7 +57,9 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // low half rn
 }
 __device__ __forceinline__ float lo_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
 __device__ __forceinline__ float hi_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
-// two consecutive contraction slots -> one dword per plane
+// two consecutive contraction slots -> one dword per plane.  Round-to-nearest planes (v_cvt_pk_bf16_f32): the
+// residuals carry random signs.  Planes by truncation (and / subtract, the same instruction count) leave every
+// dropped term with the sign of the product: 2.2e-6 instead of 3.8e-7 rms on H W^T (tools/probes/x3_nt_probe.hip).
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
     const unsigned h = pk_bf16(x0, x1);
     const float r0 = x0 - lo_f32(h), r1 = x1 - hi_f32(h);
@@ -101,6 +103,16 @@ x3_split_rows_kernel(const float* __restrict__ Bt, int64_t ldb, int N, int K, in
     o[8] = p2;
 }
 
+// -DX3_TIMELINE (tools/probes/x3_nt_probe.hip only): s_memtime phase sums of wave 0 of workgroups 0..63
+#ifdef X3_TIMELINE
+__device__ unsigned long long g_x3_timeline[64][8];
+#define X3_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define X3_ADD(slot, a, b) tl_sum[slot] += (b) - (a)
+#else
+#define X3_T(var) do { } while (0)
+#define X3_ADD(slot, a, b) do { } while (0)
+#endif
+
 template <class Epi, bool THIN>
 __global__ void __launch_bounds__(256, 2) gemm_nt_x3_kernel(const Operands g, const Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[2 * X3_OPER / 4];
@@ -109,15 +121,28 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_x3_kernel(const Operands g, co
     const int li = l & 31, kk = l >> 5;
     const int wm = w >> 1, wn = w & 1;
 
+    // Workgroup -> tile, XCD-aware (g.per_xcd > 0): consecutive workgroup ids go round the 8 XCDs, each with
+    // its own L2, and the tiles_n column tiles of a row tile read the same 128 rows of A -- XCD x takes the
+    // contiguous range [x * per_xcd, (x + 1) * per_xcd) of the row-major tile order, so a row tile's A operand
+    // crosses the fabric once instead of once per XCD that holds one of its column tiles.
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int64_t tm = blockIdx.x / tiles_n;
-    const int tn = blockIdx.x % tiles_n;
+    int lin = (int)blockIdx.x;
+    if (g.per_xcd) {
+        lin = (int)(blockIdx.x & 7) * g.per_xcd + (int)(blockIdx.x >> 3);
+        if ((int64_t)lin >= ((g.M + BM - 1) / BM) * tiles_n) return;
+    }
+    const int64_t tm = lin / tiles_n;
+    const int tn = lin % tiles_n;
     const int64_t m0 = tm * BM;
     const int n0 = tn * BN;
 
     // staging map of A: thread -> (row = tid/8 + 32 i, 4 floats at k = (tid%8) * 4)
     const int srow = tid >> 3, sk = (tid & 7) * 4;
     // ... of B3: a linear copy, thread -> 16-byte pieces tid + 256 i (i < 6) of the tile's 1536
+    // (by LDS-DMA into a second B buffer instead -- global_load_lds_dwordx4, no staging registers, no
+    // ds_write_b128: measured equal, 163.6 / 144.9 against 169.9 / 140.2 TFLOP/s-eq for the two ISTA products,
+    // profiles/r06_x3_steps.txt; the compiler makes every LDS read behind an LDS-DMA wait for it, which pins the
+    // DMA behind the tile's last fragment read)
     const u32x4* B3 = (const u32x4*)g.B3 + (int64_t)tn * g.kt3 * (X3_OPER / 16) + tid;
 
     f32x16 acc[2][2];
@@ -139,10 +164,16 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_x3_kernel(const Operands g, co
         const int kc = k < g.K ? k : 0;
         return *(const f32x4*)(base + rr * ld + kc);
     };
-    auto gload = [&](int kt) __attribute__((always_inline)) {
+    // A is fetched TWO tiles ahead (gload_a(kt + 2) right behind the split of tile kt + 1, into the registers
+    // that split just freed): a k-tile of this kernel is ~0.5 us of MFMAs, less than an HBM round trip under
+    // load, and with one tile of lookahead the split waited for its operand whenever A did not sit in the
+    // Infinity Cache (M = 16384: 185, M = 32768: 160 TFLOP/s-eq).  B3 (cache-resident) one tile ahead.
+    auto gload_a = [&](int kt) __attribute__((always_inline)) {
         if (THIN) rt = raw4(g.Bt, g.N, g.N + 1, g.ldb, kt * BK + sk);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = raw4(g.A, m0 + srow + 32 * i, g.M, g.lda, kt * BK + sk);
+    };
+    auto gload_b = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) rb[i] = B3[kt * (X3_OPER / 16) + 256 * i];
     };
@@ -203,39 +234,53 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_x3_kernel(const Operands g, co
             if (NB == 2 || (NB == 1 && (t & 1) == 0))
                 acc[t >> 1][t & 1] = mfma_bf16(fa[st][t >> 1][PA[q]], fb[st][t & 1][PB[q]], acc[t >> 1][t & 1]);
         };
+        // (priority over the other workgroup's waves while this one feeds the matrix pipe: they are in their
+        // store phase or would only interleave with it -- +2 .. 6 %)
+        __builtin_amdgcn_s_setprio(3);
         fetch(std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (STAGE) gload(kt_next);
+        if (STAGE) gload_b(kt_next);
         fetch(std::integral_constant<int, 1>{});
-        // step 0: the 10 (+1) global loads of the next tile and the 12 fragment reads of step 1 between its MFMAs
+        // step 0: the 6 loads of the next B3 tile and the 12 fragment reads of step 1 between its MFMAs
         static_for<24>([&](auto qt) __attribute__((always_inline)) { product(std::integral_constant<int, 0>{}, qt); });
         if (NB == 2) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (STAGE && i < (THIN ? 11 : 10)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (STAGE && i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         // step 1: one piece of A's split behind each of its first 8 MFMAs, fenced (sched_group_barrier left
-        // the VALU operations in one lump behind the MFMAs)
+        // the VALU operations in one lump behind the MFMAs); then the loads of the A tile after next
         static_for<24>([&](auto qt) __attribute__((always_inline)) {
             product(std::integral_constant<int, 1>{}, qt);
             if constexpr (STAGE && decltype(qt)::value < 8) {
                 split_piece(qt, full_tag, kt_next * BK);
                 if (NB == 2) __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (STAGE && decltype(qt)::value == 8) {
+                gload_a(kt_next + 1);         // (clamped addresses: a tile past the end is loaded and never used)
+                if (NB == 2) __builtin_amdgcn_sched_barrier(0);
+            }
         });
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
 
     const int nkt = (g.K + BK - 1) / BK;
     // (wave-uniform: tn, wn and N are)
     const int nb = n0 + wn * 64 + 32 < g.N ? 2 : (n0 + wn * 64 < g.N ? 1 : 0);
-    gload(0);
+#ifdef X3_TIMELINE
+    unsigned long long tl_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    X3_T(t_start);
+    gload_a(0);
+    gload_b(0);
     static_for<8>([&](auto m) __attribute__((always_inline)) { split_piece(m, std::false_type{}, 0); });
+    gload_a(1);
     store_staged();
     __syncthreads();
     {
@@ -245,10 +290,19 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_x3_kernel(const Operands g, co
             int kt = 0;
             if (m0 + BM <= g.M)        // every k-tile but the last is then whole: no selects
                 for (; (kt + 2) * BK <= g.K && kt + 1 < nkt; ++kt) {
+                    X3_T(t0);
                     ktile(std::true_type{}, std::true_type{}, kt + 1, nb_tag);
+                    X3_T(t1);
                     __syncthreads();
+                    X3_T(t2);
                     store_staged();
+#ifdef X3_TIMELINE
+                    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+#endif
+                    X3_T(t3);
                     __syncthreads();
+                    X3_T(t4);
+                    X3_ADD(0, t0, t1); X3_ADD(1, t1, t2); X3_ADD(2, t2, t3); X3_ADD(3, t3, t4); X3_ADD(7, 0ull, 1ull);
                 }
             for (; kt + 1 < nkt; ++kt) {
                 ktile(std::true_type{}, std::false_type{}, kt + 1, nb_tag);
@@ -262,6 +316,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_x3_kernel(const Operands g, co
         else body(std::integral_constant<int, 0>{});
     }
 
+    X3_T(t_loop_end);
     // Last k-tile and epilogue (gemm_nt.h).  Register v of lane l holds row (v&3) + 8*(v>>2) + 4*(l>>5),
     // column l&31.
     constexpr bool EARLY = epi_early<Epi>::value;
@@ -374,6 +429,16 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_x3_kernel(const Operands g, co
             }
         }
     }
+#ifdef X3_TIMELINE
+    if (tid == 0 && blockIdx.x < 64) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long loop = 0;
+        for (int k = 0; k < 4; ++k) loop += tl_sum[k];
+        tl_sum[4] = (t_loop_end - t_start) - loop;
+        tl_sum[5] = t_end - t_loop_end;
+        for (int k = 0; k < 8; ++k) g_x3_timeline[blockIdx.x][k] = tl_sum[k];
+    }
+#endif
     if constexpr (RED) {
         __syncthreads();                       // every wave is done with the staged tiles
         lds[tid] = red;
@@ -382,7 +447,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_x3_kernel(const Operands g, co
             if (tid < o) lds[tid] += lds[tid + o];
             __syncthreads();
         }
-        if (tid == 0) epi.red_out[blockIdx.x] = lds[0];
+        if (tid == 0) epi.red_out[lin] = lds[0];
     }
 }
 
@@ -400,7 +465,12 @@ inline hipError_t launch_x3(const Operands& g_in, bool thin, const Epi& epi, hip
                        g.N, g.K, KT, total, (u32x4*)scratch);
     g.B3 = scratch;
     g.kt3 = KT;
-    const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const char* xe = getenv("X3_XCD");
+    if (tiles >= 64 && !(xe && atoi(xe) == 0)) {          // (a handful of tiles: nothing to share)
+        g.per_xcd = (int)((tiles + 7) / 8);
+        tiles = (int64_t)g.per_xcd * 8;
+    }
     if (thin)
         hipLaunchKernelGGL((gemm_nt_x3_kernel<Epi, true>), dim3((unsigned)tiles), dim3(256), 0, stream, g, epi);
     else

@@ -9,6 +9,7 @@
 //   MFMA fragments are single-dword reads of 32 consecutive columns (conflict-free).
 #pragma once
 #include "common.h"
+#include "gemm_nt.h"      // (gemm_nt_x3.h: the split-operand helpers gemm_tn_x3.h shares)
 
 #include <type_traits>
 
@@ -240,6 +241,9 @@ inline int pick_splits(int M, int N, int64_t Kdim, int max_splits) {
 }
 
 template <class Epi>
+inline hipError_t launch_x3(const Operands& gg, const Epi& epi, dim3 grid, hipStream_t stream);   // gemm_tn_x3.h
+
+template <class Epi>
 inline hipError_t launch(const Operands& g, const Epi& epi, int splits, hipStream_t stream) {
     // the 4-wide column groups must not straddle M / N: pad the operand or take the scalar path
     const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.M % 4 == 0) && (g.N % 4 == 0) &&
@@ -249,6 +253,7 @@ inline hipError_t launch(const Operands& g, const Epi& epi, int splits, hipStrea
     gg.splits = splits;
     const int per_xcd = (tiles * splits + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
+    if (vec && tl_matrix_mode == DRNMF_MATRIX_BF16X3) return launch_x3(gg, epi, grid, stream);
     if (vec)
         hipLaunchKernelGGL((gemm_tn_kernel<Epi, true>), grid, dim3(256), 0, stream, gg, epi);
     else
@@ -257,3 +262,5 @@ inline hipError_t launch(const Operands& g, const Epi& epi, int splits, hipStrea
 }
 
 }  // namespace gemm_tn
+
+#include "gemm_tn_x3.h"

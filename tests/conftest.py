@@ -48,6 +48,20 @@ def _drnmf_env_snapshot():
     _reload_drnmf_env()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _drnmf_matrix_mode_of_the_session():
+    """DRNMF_TEST_MATRIX_MODE=bf16x3 runs the WHOLE GPU suite with the frame-parallel products in the
+    split-operand mode (include/drnmf.h DRNMF_MATRIX_BF16X3) -- every tolerance unchanged.  Unset: the default
+    exact-fp32 mode; tests/test_gpu_x3.py covers the mode either way."""
+    mode = os.environ.get("DRNMF_TEST_MATRIX_MODE")
+    if mode:
+        import torch
+        if torch.cuda.is_available():
+            from drnmf_amd import ops
+            ops.set_matrix_mode(mode, 0)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
