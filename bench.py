@@ -682,7 +682,9 @@ def cpu_baseline(F, r, K, B, frames, tied):
     with _limit_threads(best_t):
         t_dense = run_dense(P)
         t_fact = run_fact(P)
-    fb = cpu_fwd_bwd(F, r, K, B, max(2, min(64, frames // 4)), tied, best_t)
+    cand_fb = [t for t in (8, 16, 32, 64) if t <= max_threads] or [max_threads]
+    fb = cpu_fwd_bwd(F, r, K, B, max(2, min(64, frames // 4)), tied, cand_fb)
+    host = host_description()
     fwd_sample = ("numpy fp32 restatement of the reference op graph (dense U, Gram S, per-step GEMMs), "
                   "FORWARD of the recurrent cell on %d utterances x %d frames of the same workload "
                   "(Gram/matrix build %.1f s excluded); BLAS threads swept, best of %s reported (host "
@@ -692,6 +694,10 @@ def cpu_baseline(F, r, K, B, frames, tied):
     # headline; the forward of the reference's dense op graph is kept next to it
     return {
         "value": fb["value"], "unit": "frames/s", "cores": fb["cores"], "kind": "port",
+        "threads": fb["cores"], "passes": fb["passes"], "min": fb["min"], "max": fb["max"], "spread": fb["spread"],
+        "thread_sweep_frames_per_s": fb.get("thread_sweep_frames_per_s"),
+        "cpu_model": host["cpu_model"], "physical_cores": host["physical_cores"],
+        "hardware_threads": host["hardware_threads"], "blas": host["blas"],
         "sample": "the metric's step on the host: " + fb["sample"] + "; the same model and batch shape "
                   "as the headline (forward alone, reference op graph: `forward_only`)",
         "forward_only": {"value": B * frames / t_dense, "unit": "frames/s", "cores": int(best_t),
@@ -700,11 +706,56 @@ def cpu_baseline(F, r, K, B, frames, tied):
     }
 
 
-def cpu_fwd_bwd(F, r, K, B, frames, tied, threads):
+def host_description():
+    """CPU model, physical cores, hardware threads and BLAS of this host (SURVEY.md 8d asks for them beside
+    the CPU baseline)."""
+    model, phys, logical = None, set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+        if pid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    blas = []
+    try:
+        from threadpoolctl import threadpool_info
+        blas = sorted(set("%s %s" % (p_.get("internal_api", "?"), p_.get("version", "")) for p_ in threadpool_info()))
+    except Exception:        # noqa: BLE001
+        pass
+    try:
+        import torch
+        cfg = torch.__config__.show()
+        tb = [n for n in ("MKL", "OpenBLAS", "BLIS", "Eigen") if ("USE_" + n.upper() + "=ON") in cfg or
+              ("BLAS_INFO=" + n.lower()) in cfg]
+        if tb:
+            blas.append("torch: " + "/".join(tb))
+    except Exception:        # noqa: BLE001
+        pass
+    return {"cpu_model": model, "physical_cores": len(phys) or None, "hardware_threads": logical or os.cpu_count(),
+            "blas": ", ".join(blas) or None}
+
+
+def cpu_fwd_bwd(F, r, K, B, frames, tied, threads, passes=5):
     """The metric's own step on the host: forward + loss + backward of the whole model by torch-CPU
     fp32 autograd of the oracle restatement (oracle/drnmf_torch_ref.py, factored form -- the
     reference gets its gradients from Theano autodiff of the same graph, enhance.py:1071-1073), on
-    a bounded sample, `threads` intra-op threads."""
+    a bounded sample.  A MEASUREMENT, not a sample of one: the intra-op thread count is
+    chosen by a sweep on an eighth of the sample, then one untimed pass and `passes` timed ones; the value is
+    the MEDIAN, the spread is reported with it."""
     import torch
     from oracle import drnmf_oracle as O
     from oracle import drnmf_torch_ref as TR
@@ -714,7 +765,6 @@ def cpu_fwd_bwd(F, r, K, B, frames, tied, threads):
                   alph=np.float32(400.0 if r >= 1000 else 50.0), lam1=np.float32(1.0))
     alt, labels = O.build_alt(N, K, params, () if tied else ("log_D", "log_alph"))
     old = torch.get_num_threads()
-    torch.set_num_threads(int(threads))
     try:
         f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
         a = {k: f32(v).requires_grad_(k.startswith("log_D") or k.startswith("log_alph"))
@@ -723,21 +773,40 @@ def cpu_fwd_bwd(F, r, K, B, frames, tied, threads):
         kc = f32(np.log(1e-7 + P["W"][:, :r]).T).requires_grad_(True)
         kn = f32(np.log(1e-7 + P["W"][:, r:]).T).requires_grad_(True)
         x, y = f32(P["X"]), f32(P["Y"])
-        w = torch.ones((B, frames), dtype=torch.float32)
-        best = None
-        for _ in range(2):                           # second pass: allocator and BLAS warmed up
+
+        def one_pass(nf):
+            w = torch.ones((B, nf), dtype=torch.float32)
             t0 = time.perf_counter()
-            loss, _, _ = TR.model_loss(x, y, w, a, labels, K, lh0, kc, kn)
+            loss, _, _ = TR.model_loss(x[:, :nf], y[:, :nf], w, a, labels, K, lh0, kc, kn)
             loss.backward()
             dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
             for t_ in list(a.values()) + [lh0, kc, kn]:
                 t_.grad = None
+            return dt
+        sweep = {}
+        if isinstance(threads, (list, tuple)):
+            nf = max(2, frames // 8)
+            for t in threads:
+                torch.set_num_threads(int(t))
+                one_pass(nf)
+                sweep[int(t)] = B * nf / min(one_pass(nf), one_pass(nf))
+            threads = max(sweep, key=sweep.get)
+        torch.set_num_threads(int(threads))
+        one_pass(frames)                              # allocator and BLAS warmed up
+        dts = sorted(one_pass(frames) for _ in range(passes))
     finally:
         torch.set_num_threads(old)
-    return {"value": B * frames / best, "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": "torch-CPU fp32 autograd of the factored restatement (forward + loss + backward, "
-                      "no optimiser step), %d utterances x %d frames, best of 2 passes" % (B, frames)}
+    med = dts[len(dts) // 2]
+    rates = [B * frames / d for d in dts]
+    out = {"value": B * frames / med, "unit": "frames/s", "cores": int(threads), "kind": "port",
+           "passes": passes, "min": min(rates), "max": max(rates),
+           "spread": (max(rates) - min(rates)) / (B * frames / med),
+           "sample": "torch-CPU fp32 autograd of the factored restatement (forward + loss + backward, "
+                     "no optimiser step), %d utterances x %d frames, median of %d passes behind one untimed "
+                     "pass, %d intra-op threads" % (B, frames, passes, int(threads))}
+    if sweep:
+        out["thread_sweep_frames_per_s"] = {str(k): v for k, v in sorted(sweep.items())}
+    return out
 
 
 def config1_bench(torch, dev):

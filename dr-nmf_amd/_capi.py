@@ -89,6 +89,9 @@ SIGNATURES = {
     "drnmf_sumsq": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "drnmf_adam_step_flat": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32,
                                     _f32, _i32, _f32, _vp, _vp]),
+    "drnmf_adam_step_flat_counted": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double,
+                                            C.c_double, C.c_double, _f32, _f32, _i32, _f32, _vp, _vp, _vp,
+                                            _vp]),
     "drnmf_check_status": (_i32, [_vp]),
     "drnmf_status_take_device": (_i32, [_vp, _vp, _vp]),
     "drnmf_reload_env": (_i32, []),

@@ -220,14 +220,33 @@ sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
 //   clip   : norm = sqrt(sum g^2) * scale > clipnorm  ->  scale *= clipnorm / norm
 // A non-zero fault word (a persistent chain of this step timed out on SOME rank: the word is part of
 // the all-reduced buffer) skips the update on every rank; report[1] tells the host.
+// COUNTED form (step_in != NULL; drnmf_adam_step_flat_counted): the number of steps APPLIED so far lives on the
+// device.  t = *step_in + 1, lr_t = lr / (1 + decay (t - 1)) * sqrt(1 - b2^t) / (1 - b1^t) is evaluated here in
+// double (Keras' Adam.get_updates), and workgroup 0 leaves *step_out = t -- or *step_in again when the fault
+// word skipped the update.  A skipped step is thereby not an iteration ON EVERY RANK AT THE SAME STEP (the
+// fault word is all-reduced), whatever the host threads of the ranks have read by then (a host-side
+// counter corrected when the fault report happens to be read let the replicas' bias corrections diverge).
 __global__ void __launch_bounds__(256)
 adam_flat_kernel(const drnmf_adam_block_t* __restrict__ blocks, const float* __restrict__ g,
                  float* __restrict__ m, float* __restrict__ v, const float* __restrict__ scalars,
                  const float* __restrict__ sumsq256, float lr_t, float b1, float b2, float eps,
-                 float clipnorm, int loss_norm, float reg_loss, float* __restrict__ report) {
+                 float clipnorm, int loss_norm, float reg_loss, float* __restrict__ report,
+                 const float* __restrict__ step_in, float* __restrict__ step_out, double lr_d, double decay_d,
+                 double b1_d, double b2_d) {
     __shared__ double red[256];
+    __shared__ float lr_sh;
     const float sse = scalars[0], cnt = fmaxf(scalars[1], 1.f), rows = scalars[2];
     const bool fault = scalars[3] != 0.f;
+    if (step_in) {                                     // (block-uniform)
+        if (threadIdx.x == 0) {
+            const double t0 = (double)*step_in, t = t0 + 1.0;
+            const double lr0 = decay_d > 0.0 ? lr_d * (1.0 / (1.0 + decay_d * t0)) : lr_d;
+            lr_sh = (float)(lr0 * sqrt(1.0 - pow(b2_d, t)) / (1.0 - pow(b1_d, t)));
+            if (blockIdx.x == 0) *step_out = fault ? (float)t0 : (float)t;
+        }
+        __syncthreads();
+        lr_t = lr_sh;
+    }
     float scale = 1.f / cnt;
     if (loss_norm == 1) scale *= rows / cnt;
     const float scale_loss = scale;
@@ -435,7 +454,33 @@ extern "C" int32_t drnmf_adam_step_flat(drnmf_handle_t h, int64_t n_blocks,
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat: loss_norm must be 0 (masked mean) or 1 (keras204)");
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream_,
                        blocks, flat_grad, flat_m, flat_v, scalars4, sumsq256, lr_t, beta1, beta2, eps,
-                       clipnorm, (int)loss_norm, reg_loss, report4);
+                       clipnorm, (int)loss_norm, reg_loss, report4, (const float*)nullptr, (float*)nullptr, 0.0,
+                       0.0, 0.0, 0.0);
+    DRNMF_HIP(h, hipGetLastError());
+    return DRNMF_OK;
+}
+
+extern "C" int32_t drnmf_adam_step_flat_counted(drnmf_handle_t h, int64_t n_blocks,
+                                                const drnmf_adam_block_t* blocks, const float* flat_grad,
+                                                float* flat_m, float* flat_v, const float* scalars4,
+                                                const float* sumsq256, double lr, double decay, double beta1,
+                                                double beta2, float eps, float clipnorm, int32_t loss_norm,
+                                                float reg_loss, const float* step_in, float* step_out,
+                                                float* report4, void* stream_) {
+    DRNMF_LOCK(h);
+    if (!h) return DRNMF_ERR_INVALID_ARG;
+    if (n_blocks <= 0 || n_blocks > 0x7fffffff || !blocks || !flat_grad || !flat_m || !flat_v || !scalars4 ||
+        !step_in || !step_out || step_in == step_out)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat_counted: bad argument");
+    if (!(lr > 0.0) || decay < 0.0 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat_counted: lr > 0, decay >= 0, 0 <= beta < 1 required");
+    if (clipnorm > 0.f && !sumsq256)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat_counted: clipnorm > 0 needs the drnmf_sumsq partials");
+    if (loss_norm != 0 && loss_norm != 1)
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat_counted: loss_norm must be 0 (masked mean) or 1 (keras204)");
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream_,
+                       blocks, flat_grad, flat_m, flat_v, scalars4, sumsq256, 0.f, (float)beta1, (float)beta2, eps,
+                       clipnorm, (int)loss_norm, reg_loss, report4, step_in, step_out, lr, decay, beta1, beta2);
     DRNMF_HIP(h, hipGetLastError());
     return DRNMF_OK;
 }

@@ -1052,17 +1052,54 @@ class UnfoldedSNMFModel(object):
                                 h_off=h.shape[-1] - self.cell.output_dim)
         return (mask, h) if want_hidden else mask
 
-    def predict_on_batch(self, x):
+    def predict_on_batch(self, x, lengths=None):
         # (one slab of `predict`: pinned staging both ways -- a pageable device-to-host copy runs at a sixth
         # of the link rate; a chain that timed out raises after the copy has synchronised)
-        return self.predict(x, batch_size=max(1, len(x)))
+        return self.predict(x, batch_size=max(1, len(x)), lengths=lengths)
 
-    def predict(self, x, batch_size=250, verbose=0):
+    @staticmethod
+    def valid_lengths(x, mask_value):
+        """1 + index of the last frame of every sequence that is NOT masked (Masking(mask_value), enhance.py:253:
+        a frame is masked when EVERY bin equals mask_value); 0 for a sequence without a valid frame.  x [n,T,F]
+        float32 numpy.  Exact, and cheap for the reference's layout (padding behind the valid prefix,
+        audio_dataset.py:144-161): the first bin decides almost every frame, whole rows are compared only over the
+        trailing run that bin leaves undecided."""
+        xs = torch.from_numpy(x)
+        n, T, _ = x.shape
+        mv = float(mask_value)
+        first_ok = (xs[:, :, 0] != mv)                                   # frames that are surely valid
+        pos = torch.arange(1, T + 1, dtype=torch.int64).unsqueeze(0)
+        lens = (first_ok * pos).amax(dim=1) if T else torch.zeros((n,), dtype=torch.int64)
+        for i in range(n):
+            lo = int(lens[i])
+            if lo < T:
+                tail_ok = (xs[i, lo:] != mv).any(dim=-1)                 # undecided frames: every bin
+                if bool(tail_ok.any()):
+                    lens[i] = lo + 1 + int(torch.nonzero(tail_ok)[-1])
+        return lens.numpy()
+
+    PREDICT_T_STEP = 32     # slab lengths are rounded up to a multiple of this many frames (graph reuse)
+
+    def predict(self, x, batch_size=250, verbose=0, lengths=None, length_aware=True):
         """keras Model.predict(x, batch_size): enhance.py's inference loop (1185-1193 validation, 1215-1223
         test: `predict_on_batch` over slabs of 250 utterances) as ONE call.  x [n,T,F] numpy -> masks
-        [n,T,F] numpy, equal bit for bit to that loop.  Slab s+1 goes up and slab s-1's masks come down
-        on two copy streams, through pinned staging buffers the model keeps, while slab s computes: the
-        PCIe time of a slab hides behind the chain of the next."""
+        [n,T,F] numpy.  Slab s+1 goes up and slab s-1's masks come down on two copy streams, through pinned
+        staging buffers the model keeps, while slab s computes: the PCIe time of a slab hides behind the chain
+        of the next.
+
+        Length-aware (default).  The reference pads every utterance to the longest of the data set and crops
+        the masks afterwards (enhance.py:1181, 1200-1203): a run at T_max for every row spends 1 - mean(len) /
+        T_max of its frames on padding.  Here the utterances are sorted by valid length, slabs are formed of
+        neighbours, and a slab runs (and is copied, both ways) at the longest valid length IN THE SLAB, rounded up
+        to PREDICT_T_STEP frames; results return to the caller's order.  Nothing the caller can see changes:
+        a frame computed is the same frame of the same sequence (rows never interact, custom_layers.py:337-338,
+        and a sequence's frames depend on its earlier frames only), and a masked frame repeats the output of
+        the frame before it (K.rnn), so the frames behind a slab's length are filled with the slab's last
+        computed frame -- the full [n,T,F] array equals the one-length run (bit for bit wherever the head takes
+        the same kernel for both row counts, i.e. from 2048 frames per slab on; tests/test_gpu_parity.py).
+        `lengths` [n] (optional): 1 + the index of each sequence's last valid frame, as the caller's data set
+        knows it (audio_dataset.py:159-161) -- frames at or behind it are TAKEN to be padding; without it the
+        lengths are read off x (valid_lengths).  length_aware=False: every slab at T, input order."""
         x = np.asarray(x, dtype=np.float32)
         if x.ndim != 3:
             raise ValueError('predict: x must be (n, T, F), got shape %s' % (x.shape,))
@@ -1073,58 +1110,99 @@ class UnfoldedSNMFModel(object):
         dev = self.cell.device
         Fo = int(self.clean.kernel.shape[1])
         out = np.empty((n, T, Fo), dtype=np.float32)
-        if n == 0:
+        if n == 0 or T == 0:
             return out
         bs = min(bs, n)
-        nbuf = 1 if n <= bs else 2
+        stateful = bool(getattr(self.cell, 'stateful', False))
+        if length_aware and not stateful:
+            if lengths is None:
+                lens = self.valid_lengths(x, self.mask_value)
+            else:
+                lens = np.asarray(lengths, dtype=np.int64).reshape(-1)
+                if lens.shape[0] != n or (lens < 0).any() or (lens > T).any():
+                    raise ValueError('predict: lengths must be %d values in [0, %d]' % (n, T))
+            order = np.argsort(-lens, kind='stable')          # longest first: the largest buffers come first
+            step = self.PREDICT_T_STEP
+            slabs = []
+            for lo in range(0, n, bs):
+                idx = order[lo:lo + bs]
+                Ts = int(min(T, max(1, -(-int(lens[idx].max()) // step) * step)))
+                slabs.append((idx, Ts))
+        else:
+            # (a stateful layer carries row i's state to row i of the next batch: order and length stay)
+            slabs = [(np.arange(lo, min(lo + bs, n)), T) for lo in range(0, n, bs)]
+        nbuf = 1 if len(slabs) == 1 else 2
+        cap_T = max(Ts for _, Ts in slabs)
         pipe = getattr(self, '_predict_pipe', None)
-        if pipe is None or pipe['shape'][:4] != (bs, T, F, Fo) or pipe['shape'][4] < nbuf:
-            pin = lambda w: [torch.empty((bs, T, w), dtype=torch.float32, pin_memory=True) for _ in range(nbuf)]
+        # (keyed on CAPACITY: the reference's loop -- 250, ..., the remainder, every epoch -- and the slabs of
+        # different lengths above reuse one set of pinned buffers; they are re-made only to grow)
+        if (pipe is None or pipe['F'] != (F, Fo) or pipe['cap_in'] < bs * cap_T * F or
+                pipe['cap_out'] < bs * cap_T * Fo or pipe['nbuf'] < nbuf or pipe['dev'] != dev):
             self._predict_pipe = None                # (the old buffers go before the new ones come)
-            pipe = dict(shape=(bs, T, F, Fo, nbuf), stage=pin(F), back=pin(Fo),
-                        xd=[torch.empty((bs, T, F), dtype=torch.float32, device=dev) for _ in range(nbuf)],
+            cin, cout = bs * cap_T * F, bs * cap_T * Fo
+            pin = lambda c: [torch.empty((c,), dtype=torch.float32, pin_memory=True) for _ in range(nbuf)]
+            pipe = dict(F=(F, Fo), cap_in=cin, cap_out=cout, nbuf=nbuf, dev=dev, stage=pin(cin), back=pin(cout),
+                        xd=[torch.empty((cin,), dtype=torch.float32, device=dev) for _ in range(nbuf)],
                         up=torch.cuda.Stream(dev), down=torch.cuda.Stream(dev))
             self._predict_pipe = pipe
         main = torch.cuda.current_stream(dev)
         ev = lambda: [torch.cuda.Event(), torch.cuda.Event()]
         ev_up, ev_comp, ev_down = ev(), ev(), ev()
         xs, res = torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(out)
-        slabs = [(lo, min(lo + bs, n)) for lo in range(0, n, bs)]
+        view = lambda buf, b, Ts, w: buf[:b * Ts * w].view(b, Ts, w)
 
         def collect(s):                              # slab s: pinned staging -> the caller's array
-            lo, hi = slabs[s]
+            idx, Ts = slabs[s]
             ev_down[s & 1].synchronize()
-            res[lo:hi].copy_(pipe['back'][s & 1][:hi - lo])
+            back = view(pipe['back'][s & 1], len(idx), Ts, Fo)
+            if Ts == T and idx[-1] - idx[0] == len(idx) - 1 and (np.diff(idx) == 1).all():
+                res[int(idx[0]):int(idx[-1]) + 1].copy_(back)
+                return
+            for k, i in enumerate(idx):
+                res[int(i), :Ts].copy_(back[k])
+                if Ts < T:                           # masked frames repeat the last output (K.rnn)
+                    res[int(i), Ts:] = back[k, Ts - 1]
 
         def send(s):                                 # slab s: the caller's array -> pinned staging -> device
-            lo, hi = slabs[s]
-            j, b = s & 1, hi - lo
+            idx, Ts = slabs[s]
+            j, b = s & 1, len(idx)
             if s >= 2:
                 ev_up[j].synchronize()               # slab s-2 has left this staging buffer
-            pipe['stage'][j][:b].copy_(xs[lo:hi])
+            stage = view(pipe['stage'][j], b, Ts, F)
+            if Ts == T and (np.diff(idx) == 1).all():
+                stage.copy_(xs[int(idx[0]):int(idx[-1]) + 1])
+            else:
+                for k, i in enumerate(idx):
+                    stage[k].copy_(xs[int(i), :Ts])
             with torch.cuda.stream(pipe['up']):
                 if s >= 2:
                     pipe['up'].wait_event(ev_comp[j])    # ... and its chain has read xd[j]
-                pipe['xd'][j][:b].copy_(pipe['stage'][j][:b], non_blocking=True)
+                view(pipe['xd'][j], b, Ts, F).copy_(stage, non_blocking=True)
                 ev_up[j].record(pipe['up'])
-        send(0)
-        for s, (lo, hi) in enumerate(slabs):
-            j, b = s & 1, hi - lo
-            if s + 1 < len(slabs):
-                send(s + 1)      # one slab ahead: enqueueing a slab's launches keeps this thread busy for
+        try:
+            send(0)
+            for s, (idx, Ts) in enumerate(slabs):
+                j, b = s & 1, len(idx)
+                if s + 1 < len(slabs):
+                    send(s + 1)  # one slab ahead: enqueueing a slab's launches keeps this thread busy for
                                  # about as long as the device needs to run them
-            main.wait_event(ev_up[j])
-            mask = self.forward(pipe['xd'][j][:b])
-            ev_comp[j].record(main)
-            with torch.cuda.stream(pipe['down']):
-                pipe['down'].wait_event(ev_comp[j])
-                pipe['back'][j][:b].copy_(mask, non_blocking=True)
-                ev_down[j].record(pipe['down'])
-            mask.record_stream(pipe['down'])
-            if s >= 1:
-                collect(s - 1)
-        collect(len(slabs) - 1)
-        main.synchronize()
+                main.wait_event(ev_up[j])
+                mask = self.forward(view(pipe['xd'][j], b, Ts, F))
+                ev_comp[j].record(main)
+                with torch.cuda.stream(pipe['down']):
+                    pipe['down'].wait_event(ev_comp[j])
+                    view(pipe['back'][j], b, Ts, Fo).copy_(mask, non_blocking=True)
+                    ev_down[j].record(pipe['down'])
+                mask.record_stream(pipe['down'])
+                if s >= 1:
+                    collect(s - 1)
+            collect(len(slabs) - 1)
+        finally:
+            # (an exception inside the loop -- out of memory, a raise from forward -- must not leave copies
+            # in flight on the side streams into buffers the next call reuses)
+            pipe['up'].synchronize()
+            pipe['down'].synchronize()
+            main.synchronize()
         ops.check_status(dev)
         return out
 
@@ -1213,6 +1291,9 @@ class UnfoldedSNMFModel(object):
         self._sumsq = torch.zeros(256, dtype=torch.float32, device=cell.device)
         self._pending = []               # DeviceLoss of recent steps, oldest first
         self._step_no = 0
+        # applied optimiser steps, ON THE DEVICE (ping-pong pair: launch n reads [n & 1], writes [(n + 1) & 1];
+        # drnmf_adam_step_flat_counted): a step the fault word skipped is not counted, identically on every rank
+        self._step_dev = torch.zeros((2,), dtype=torch.float32, device=cell.device)
         self.sync_replicas()
         return self
 
@@ -1398,29 +1479,28 @@ class UnfoldedSNMFModel(object):
             reg_loss = self._add_regularizers(scale)     # (before the clip: Keras clips the total gradient)
         if o['clipnorm'] > 0:                           # global-norm clip [K2.0.4-memory]
             ops.sumsq_partials(flat[:-ns], out=self._sumsq)
-        lr = o['lr']
-        if o['decay'] > 0:
-            lr *= 1.0 / (1.0 + o['decay'] * o['iterations'])
-        t = o['iterations'] + 1
-        lr_t = lr * np.sqrt(1.0 - o['b2'] ** t) / (1.0 - o['b1'] ** t)
         table, nb = self._adam_blocks()
         ring, base = ops.host_report_ring(self.cell.device)
         slot, register = _claim_report_slot(ops._dev_of(self.cell.device), ring.shape[0])
+        j = self._step_no & 1
         self._step_no += 1
-        ops.adam_step_flat(table, nb, flat, self._mflat, self._vflat, flat[-ns:], lr_t, o['b1'], o['b2'],
-                           o['eps'], clipnorm=o['clipnorm'], keras204=keras204, reg_loss=reg_loss,
-                           sumsq256=self._sumsq if o['clipnorm'] > 0 else None,
-                           report=base + 16 * slot)
+        # (lr_t -- decay and bias correction -- is evaluated by the launch from the device's own count of applied
+        # steps: a host-side count, corrected whenever a fault report happened to be read, made the ranks of a
+        # data-parallel group pass different lr_t for a few steps after a skipped one)
+        ops.adam_step_flat_counted(table, nb, flat, self._mflat, self._vflat, flat[-ns:], o['lr'], o['decay'],
+                                   self._step_dev[j:j + 1], self._step_dev[1 - j:2 - j], beta1=o['b1'],
+                                   beta2=o['b2'], eps=o['eps'], clipnorm=o['clipnorm'], keras204=keras204,
+                                   reg_loss=reg_loss, sumsq256=self._sumsq if o['clipnorm'] > 0 else None,
+                                   report=base + 16 * slot)
         ev = torch.cuda.Event()
         ev.record()
-        # (a step the device skipped -- fault word set -- is not an iteration: the count is taken back when
-        # its report is read, at most PENDING_STEPS steps later; the steps enqueued in between ran with a
-        # bias correction one step ahead, the count is right again from then on)
+        # opt['iterations'] is the host's MIRROR of that count (get_config, logging): steps enqueued minus the
+        # skipped ones it has been told about so far; nothing on the device depends on it
         def uncount(o=o):
             o['iterations'] = max(0, o['iterations'] - 1)
         loss = DeviceLoss(ev, ring[slot], self.cell.device, on_fault=uncount)
         register(loss)
-        o['iterations'] = t
+        o['iterations'] += 1
         # the prepared parameter block is stale; the (u0_diag, u0_off, uk_off) scalars are derived
         # from log_U1 / log_Uk, which compile() refuses to train: re-deriving them here would cost
         # two N x N device-to-host copies and a host pass per step

@@ -607,6 +607,22 @@ def adam_step_flat(table, n_blocks, flat_grad, flat_m, flat_v, scalars4, lr_t, b
     _capi.check(rc, h, "drnmf_adam_step_flat")
 
 
+def adam_step_flat_counted(table, n_blocks, flat_grad, flat_m, flat_v, scalars4, lr, decay, step_in, step_out,
+                           beta1=0.9, beta2=0.999, eps=1e-8, clipnorm=0.0, keras204=False, reg_loss=0.0,
+                           sumsq256=None, report=None):
+    """adam_step_flat with the step count on the device: `step_in` / `step_out` are two DIFFERENT one-element
+    float32 device tensors (applied steps before / after this launch); lr_t is evaluated by the launch."""
+    L = _capi.lib()
+    h = _capi.handle(_dev_index(flat_grad))
+    rc = L.drnmf_adam_step_flat_counted(h, int(n_blocks), _capi.ptr(table), _capi.ptr(flat_grad),
+                                        _capi.ptr(flat_m), _capi.ptr(flat_v), _capi.ptr(scalars4),
+                                        _capi.ptr(sumsq256), float(lr), float(decay), float(beta1), float(beta2),
+                                        float(eps), float(clipnorm), 1 if keras204 else 0, float(reg_loss),
+                                        _capi.ptr(step_in), _capi.ptr(step_out),
+                                        report if isinstance(report, int) else _capi.ptr(report), _stream())
+    _capi.check(rc, h, "drnmf_adam_step_flat_counted")
+
+
 _report_rings = {}
 
 

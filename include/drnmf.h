@@ -450,6 +450,21 @@ int32_t drnmf_adam_step_flat(drnmf_handle_t h, int64_t n_blocks, const drnmf_ada
                              const float* scalars4, const float* sumsq256, float lr_t, float beta1,
                              float beta2, float eps, float clipnorm, int32_t loss_norm,
                              float reg_loss, float* report4, void* stream);
+/* The same launch with the STEP COUNT on the device (what the product's train_on_batch uses).  Keras keeps
+ * `iterations` as a backend variable updated inside the training function (Adam.get_updates); here
+ *   step_in   device: number of steps applied so far, as a float (exact to 2^24)
+ *   step_out  device, != step_in (ping-pong: a launch's workgroups read step_in while workgroup 0 writes):
+ *             step_in + 1, or step_in unchanged when the fault word skipped the update
+ *   lr, decay, beta1, beta2  the optimiser's constants; the launch evaluates, in double,
+ *             lr_t = lr / (1 + decay * step_in) * sqrt(1 - beta2^t) / (1 - beta1^t),  t = step_in + 1.
+ * A skipped step is therefore not an iteration, on every rank of a data-parallel group at the same step and
+ * without any host involvement (the fault word is part of the all-reduced buffer). */
+int32_t drnmf_adam_step_flat_counted(drnmf_handle_t h, int64_t n_blocks, const drnmf_adam_block_t* blocks,
+                                     const float* flat_grad, float* flat_m, float* flat_v,
+                                     const float* scalars4, const float* sumsq256, double lr, double decay,
+                                     double beta1, double beta2, float eps, float clipnorm,
+                                     int32_t loss_norm, float reg_loss, const float* step_in, float* step_out,
+                                     float* report4, void* stream);
 
 /* ---- data-parallel training: ONE all-reduce(sum) per optimiser step over the flat fp32 buffer
  * [gradients..., sum w*mse, count, rows] and one broadcast that makes the replicas' weights

@@ -16,7 +16,8 @@ fn_t drnmf_all_exports[] = {
     REF(drnmf_head_forward), REF(drnmf_loss_head_workspace_bytes), REF(drnmf_loss_head_backward),
     REF(drnmf_snmf_cost_head_backward), REF(drnmf_cell_backward_workspace_bytes),
     REF(drnmf_cell_backward), REF(drnmf_cell_backward_stateful), REF(drnmf_cell_backward_ista), REF(drnmf_cell_backward_ista_stateful), REF(drnmf_adam_step), REF(drnmf_sumsq),
-    REF(drnmf_adam_step_flat), REF(drnmf_check_status), REF(drnmf_status_take_device),
+    REF(drnmf_adam_step_flat), REF(drnmf_adam_step_flat_counted), REF(drnmf_set_matrix_mode), REF(drnmf_get_matrix_mode),
+    REF(drnmf_check_status), REF(drnmf_status_take_device),
     REF(drnmf_host_report_ring), REF(drnmf_reload_env), REF(drnmf_create_unbound), REF(drnmf_persist_admitted), REF(drnmf_persist_admit_reason),
     REF(drnmf_ista_workspace_bytes), REF(drnmf_ista_forward), REF(drnmf_mu_workspace_bytes),
     REF(drnmf_mu_forward), REF(drnmf_snmf_train_workspace_bytes), REF(drnmf_snmf_train_init),

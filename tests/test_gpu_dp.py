@@ -60,6 +60,25 @@ def test_rccl_communicator_through_the_c_abi(dev):
     assert L.drnmf_comm_init(h, C.create_string_buffer(128), 0, 1) == -1   # already owns one
     dp.comm_destroy(dev)
     assert L.drnmf_comm_info(h, C.byref(r), C.byref(w)) == 0 and w.value == 1
+    # the handle can own a communicator AGAIN (a second fit() / a re-formed group), and the collective takes
+    # the headline's gradient buffer: 107 MB (configs[1] untied, K = 25: DESIGN.md section 5)
+    assert dp.comm_init(dev, rank_=0, world_=1) == (0, 1)
+    huge = torch.rand(26_750_000, device=dev)
+    want = huge.clone()
+    dp.allreduce_sum_(huge, force=True)
+    dp.broadcast_(huge, 0, force=True)
+    torch.cuda.synchronize()
+    assert torch.equal(huge, want)
+    dp.comm_destroy(dev)
+    assert L.drnmf_comm_info(h, C.byref(r), C.byref(w)) == 0 and w.value == 1
+
+
+def _session_matrix_mode():
+    """Spawned workers do not run conftest's session fixture: take DRNMF_TEST_MATRIX_MODE themselves."""
+    mode = os.environ.get("DRNMF_TEST_MATRIX_MODE")
+    if mode:
+        from drnmf_amd import ops
+        ops.set_matrix_mode(mode, 0)
 
 
 def _free_port():
@@ -96,6 +115,7 @@ def _dp_worker(rank, world, port, out_dir):
     os.environ["DRNMF_DP_BACKEND"] = "torch"       # two ranks on one GPU: no RCCL
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    _session_matrix_mode()
     from drnmf_amd import callbacks, dp
     P, w = _problem()
     model = _model(seed=100 + rank)
@@ -108,6 +128,61 @@ def _dp_worker(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, "w%d.npz" % rank), *model.get_weights(),
              loss=np.array(hist["loss"]), val=np.array(hist["val_loss"]))
     torch.distributed.destroy_process_group()
+
+
+def _skipped_step_worker(rank, world, port, out_dir):
+    """Twelve data-parallel steps with decay (lr_t depends on the step count); step 3 carries a fault word on
+    rank 0 only (what drnmf_status_take_device leaves when a persistent chain of that rank timed out).  Rank 0
+    reads that step's loss AT ONCE, rank 1 reads no loss at all -- it is told by a later train_on_batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DRNMF_DP_BACKEND"] = "torch"
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    _session_matrix_mode()
+    from drnmf_amd import _capi, dp
+    P, w = _problem()
+    model = _model(seed=100 + rank)
+    model.compile(lr=1e-2, decay=0.05)
+    lo, hi = dp.shard(B_ALL)
+    inner = model.loss_and_grads
+    state = {"step": 0}
+
+    def faulty(*a, **k):
+        flat = inner(*a, **k)
+        if state["step"] == 3 and rank == 0:
+            flat[-1] += 1.0
+        return flat
+    model.loss_and_grads = faulty
+    told = 0
+    for step in range(12):
+        state["step"] = step
+        try:
+            loss = model.train_on_batch(P["X"][lo:hi], P["Y"][lo:hi], w[lo:hi])
+            if rank == 0 and step == 3:
+                float(loss)
+        except _capi.DrnmfError:
+            told += 1
+    torch.cuda.synchronize()
+    assert told == 1, told                                  # every rank hears of the skipped step exactly once
+    applied = float(model._step_dev[model._step_no & 1])
+    np.savez(os.path.join(out_dir, "skip%d.npz" % rank), *model.get_weights(), applied=np.array([applied]),
+             mirror=np.array([model.opt["iterations"]]))
+    torch.distributed.destroy_process_group()
+
+
+def test_skipped_step_keeps_the_replicas_identical_whoever_reads_the_loss(dev, tmp_path):
+    """the bias correction / decay of Adam hang on the number of APPLIED steps.  That count
+    lives on the device (drnmf_adam_step_flat_counted) and is not advanced by a step the all-reduced fault word
+    skipped -- so the ranks of a data-parallel group keep passing the same lr_t whenever their host threads get
+    round to reading the fault report (before: a host-side count, taken back when the report was read)."""
+    port = _free_port()
+    mp.spawn(_skipped_step_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z0, z1 = np.load(tmp_path / "skip0.npz"), np.load(tmp_path / "skip1.npz")
+    for k in [k for k in z0.files if k.startswith("arr_")]:
+        np.testing.assert_array_equal(z0[k], z1[k])
+    assert z0["applied"][0] == 11.0 and z1["applied"][0] == 11.0     # twelve enqueued, one skipped
+    assert z0["mirror"][0] == 11 and z1["mirror"][0] == 11
 
 
 def test_two_rank_product_training_equals_single_process(dev, tmp_path):
@@ -432,6 +507,7 @@ def _tenant_worker(rank, world, out_dir):
     import test_gpu_parity as TP
     from drnmf_amd import ops
     torch.cuda.set_device(0)
+    _session_matrix_mode()
     os.environ["DRNMF_GRAM"] = "1"
     os.environ["DRNMF_PERSIST"] = "1"
     ops.reload_env()
@@ -514,6 +590,7 @@ def test_timed_out_training_step_is_skipped_and_reported(dev, monkeypatch):
         assert np.array_equal(a, b)                          # the update was skipped
     assert torch.equal(m_before, model._mflat)
     assert model.opt["iterations"] == it_before              # (a skipped step is not an iteration: ADVICE r4)
+    assert float(model._step_dev[model._step_no & 1]) == it_before      # ... on the device, where lr_t is made
     ops.check_status(dev)                                    # the fault word was consumed by the step
     l2 = float(model.train_on_batch(P["X"], P["Y"], w))
     assert np.isfinite(l2) and any(not np.array_equal(a, b) for a, b in zip(before, model.get_weights()))
