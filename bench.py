@@ -114,6 +114,77 @@ def ista_bench(torch, dev, F, N, K, W, n=32768):
             "gemm_launch_us": sec / (2 * K) * 1e6}
 
 
+def both_modes(fn, pick, *args, **kw):
+    """fn(*args) with the frame-parallel products in the exact-fp32 mode (the figures at the top level, as in
+    earlier rounds) and again in the split-operand mode (DRNMF_MATRIX_BF16X3, include/drnmf.h) under "bf16x3";
+    `pick(result)` -> the time-like figure whose ratio is reported as speedup_bf16x3."""
+    from drnmf_amd import ops
+    prev = ops.set_matrix_mode("f32")
+    try:
+        res = fn(*args, **kw)
+        ops.set_matrix_mode("bf16x3")
+        alt = fn(*args, **kw)
+    finally:
+        ops.set_matrix_mode(prev)
+    res["matrix_mode"] = "f32 (v_mfma_f32_32x32x2_f32, exact)"
+    alt["matrix_mode"] = "f32 via bf16x3 operands, f32 accumulate (6 x v_mfma_f32_32x32x16_bf16 per product)"
+    res["bf16x3"] = alt
+    try:
+        res["speedup_bf16x3"] = pick(res) / pick(alt)
+    except Exception:        # noqa: BLE001
+        pass
+    return res
+
+
+def ragged_inference_bench(torch, dev, F=257, r=1000, K=5, T=2000, n=500, slab=250):
+    """The reference's inference over a RAGGED data set (enhance.py:1181-1203: every utterance padded to the
+    longest, masks cropped afterwards): `predict` as the reference runs it -- every slab at T_max, input order
+    -- against the length-aware `predict` (utterances sorted by valid length, each slab at its own length,
+    dr-nmf_amd/layers.py).  Lengths as SURVEY.md 8(d) draws them for the training configs: uniform in
+    [0.4 T, T].  The figure is VALID frames per second, host arrays in and out (PCIe-inclusive: never `value`),
+    the shipped r = 1000, K = 5 model at the reference's frame cap (util.py:319)."""
+    import time
+    from drnmf_amd import layers
+    N = 2 * r
+    W, log_h0, X = synth_on_device(torch, dev, slab, T, F, r, seed=123)
+    rng = np.random.Generator(np.random.PCG64(7654))
+    lens = rng.integers(int(0.4 * T), T + 1, size=n)
+    xh = np.concatenate([X.cpu().numpy()] * ((n + slab - 1) // slab))[:n].copy()
+    for i, L in enumerate(lens):
+        xh[i, L:] = -1.0
+    del X
+    p = dict(input_dim=F, hidden_dim=N, output_dim=F, mask_value=-1., maxseq=T, K_layers=K, W=W,
+             alph=400.0 if r >= 1000 else 50.0, lam1=1.0, params_trainable=["log_D", "log_alph"],
+             params_untied=["log_D", "log_alph"])
+    model = layers.build_unfolded_snmf(p, device=dev)
+    model.cell.log_h0.copy_(torch.from_numpy(log_h0))
+    valid = int(lens.sum())
+    res = {}
+    ref = None
+    for name, kw in (("padded_to_T_max", dict(length_aware=False)), ("length_aware", dict()),
+                     ("length_aware_lengths_given", dict(lengths=lens))):
+        model.predict(xh, batch_size=slab, **kw)           # staging buffers, graphs
+        t0 = time.perf_counter()
+        m = model.predict(xh, batch_size=slab, **kw)
+        sec = time.perf_counter() - t0
+        res[name] = {"valid_frames_per_s": valid / sec, "s": sec}
+        if ref is None:
+            ref = m
+        else:
+            res[name]["bit_equal_to_padded_run_on_valid_frames"] = bool(
+                all(np.array_equal(m[i, :L], ref[i, :L]) for i, L in enumerate(lens)))
+            res[name]["bit_equal_on_all_frames"] = bool(np.array_equal(m, ref))
+        del m
+    res.update({"utterances": n, "T_max": T, "F": F, "N": N, "K": K, "slab": slab, "valid_frames": valid,
+                "mean_length_over_T_max": float(lens.mean() / T),
+                "speedup_valid_frames": res["length_aware"]["valid_frames_per_s"] /
+                res["padded_to_T_max"]["valid_frames_per_s"]})
+    model.free_predict_buffers()
+    del model, xh, ref
+    torch.cuda.empty_cache()
+    return res
+
+
 def mu_bench(torch, dev, F, N, W, n=32768, iters=20):
     """SNMF inference by multiplicative updates with W fixed -- the classical baseline branch of
     enhance.py:838-852 that replaces the Matlab process (200 iterations there) -- on n frames,
@@ -286,6 +357,25 @@ def slab_bench(torch, dev, F, r, K, T, slab=250, host_slabs=0):
     return out
 
 
+def c5_pmc_traffic():
+    """L2-side bytes per launch of the config-5 fp16 chain kernels from the newest committed PMC summary
+    (profiles/r*_pmc_c5_pf1_summary.json; FETCH_SIZE x 2 + WRITE_SIZE as in pmc_traffic), per kernel."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_c5_pf1_summary.json")))
+    if not files:
+        return None
+    try:
+        js = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None
+    per = {k: v.get("hbm_side_read_bytes_per_launch", 0.0) + v.get("hbm_side_write_bytes_per_launch", 0.0)
+           for k, v in js.items() if isinstance(v, dict) and k.startswith("cell_") and
+           "hbm_side_read_bytes_per_launch" in v}
+    return {"file": "profiles/" + os.path.basename(files[-1]), "bytes_per_launch_by_kernel": per,
+            "lib_src_sha16_of_profile": js.get("_lib_src_sha16")}
+
+
 def config5_bench(torch, dev, frames=64, B=64):
     """BASELINE configs[4] shape on ONE GPU (the config itself is an 8-GPU stress line): W 1025 x
     8000, K=50 untied, forward (cell + head) with fp32 and with fp16 MFMA operands (fp32
@@ -333,11 +423,18 @@ def config5_bench(torch, dev, frames=64, B=64):
         step_us = sec / (frames * K) * 1e6
         bytes_step = float(F) * N * esz + 2.0 * B * (N + F) * esz
         gbs_step = bytes_step / (step_us * 1e-6) / 1e9
+        # the same launch under the kernel trace (committed: tools/profile_shape.py 64 16 1025 4000 50 f16)
+        prof = rocprof_launch_us("r*_c5_f16_kernel_stats.csv") if name == "f16" else None
         out[name] = {"frames_per_s": B * frames / sec, "tflops": tf, "frac_of_mfma_peak": tf / peak,
                      "launch_us": launch_us, "layer_step_us": step_us,
                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                   "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                  "bytes_per_launch": bytes_launch},
+                                  "bytes_per_launch": bytes_launch,
+                                  "algorithmic_bytes_per_launch": bytes_launch,
+                                  "launch_us_rocprof": prof,
+                                  "frac_rocprof": (bytes_launch / (prof["mean_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS)
+                                  if prof else None,
+                                  "traffic": c5_pmc_traffic() if name == "f16" else None},
                      "roofline_per_layer_step": {"bound": "hbm", "achieved": gbs_step, "peak": PEAK_HBM_GBS,
                                                  "unit": "GB/s", "frac": gbs_step / PEAK_HBM_GBS,
                                                  "bytes_per_layer_step": bytes_step}}
@@ -587,7 +684,7 @@ def pmc_traffic():
     return None, None
 
 
-def rocprof_launch_us():
+def rocprof_launch_us(pattern="r*_bench_kernel_stats.csv"):
     """Average launch duration of the chain kernels in the newest committed rocprofv3
     --kernel-trace --stats summary of this command (profiles/*_kernel_stats.csv): the PROFILED
     figure, reported next to the unprofiled HIP-event one (the kernel-trace instrumentation adds
@@ -596,7 +693,7 @@ def rocprof_launch_us():
     import csv
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_bench_kernel_stats.csv")))
+    files = sorted(glob.glob(os.path.join(here, "profiles", pattern)))
     if not files:
         return None
     tot, calls, per = 0.0, 0, {}
@@ -1055,7 +1152,24 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 ar = {"bytes": int(flat.numel()) * 4, "ms": e0.elapsed_time(e1) / 5.0}
-            return dict(wall=wall, ev_ms=ev_ms, phases=phases, bp=bp, losses=losses, allreduce=ar)
+            x3 = None
+            if world == 1 and not a.no_extras:
+                # the SAME step with the time-batched products (weight gradients, mask head and its backward) in
+                # the split-operand mode: a second, separately labelled figure -- never `value`
+                prev = ops.set_matrix_mode("bf16x3")
+                try:
+                    model.phase_events = {}
+                    xl = []
+                    xwall, xev = timed(lambda: xl.append(model.train_on_batch(X, Y, wts)), max(2, min(a.steps, 5)), 1)
+                    model.phase_events = None
+                    model.backward_profile = {}
+                    model.train_on_batch(X, Y, wts)
+                    xbp = dict(model.backward_profile)
+                    model.backward_profile = None
+                    x3 = dict(wall=xwall, steps=max(2, min(a.steps, 5)), bp=xbp, loss_last=float(xl[-1]))
+                finally:
+                    ops.set_matrix_mode(prev)
+            return dict(wall=wall, ev_ms=ev_ms, phases=phases, bp=bp, losses=losses, allreduce=ar, x3=x3)
         train = run_guarded(headline, 900.0, on_timeout)
     if train is not None and "error" not in train:
         wall, ev_ms = train["wall"], train["ev_ms"]
@@ -1093,6 +1207,14 @@ def main():
                                    "by drnmf_cell_backward_profile) / launches; includes the "
                                    "~1.5 us launch boundary, as a zero-gap kernel trace does",
                 "launch_us_rocprof": prof,
+                "frac_rocprof": (flops_per_launch / (prof["mean_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS)
+                if prof else None,
+                "frac_rocprof_source": (prof or {}).get("file"),
+                "algorithmic_bytes_per_launch": 4.0 * (F * N + B * (N + F)),
+                "algorithmic_bytes_note": "one layer's dictionary (one packing, F x N fp32) + the activations a "
+                                          "launch exchanges (h in, residual out or the reverse: B (N + F) fp32); "
+                                          "`traffic` is the PMC figure of the same launch (L2-side, every XCD's "
+                                          "fetch of a shared operand counted)",
             },
             "step_breakdown_ms": {
                 "cell_forward_chain": fwd_ms, "head_and_loss": train["phases"]["head_and_loss"],
@@ -1105,6 +1227,18 @@ def main():
                 flops_step / (ev_ms / a.steps * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "loss_first": float(train["losses"][0]), "loss_last": float(train["losses"][-1]),
         }
+        if train.get("x3"):
+            x3 = train["x3"]
+            out["headline_bf16x3"] = {
+                "value": world * B * T * x3["steps"] / x3["wall"], "unit": "frames/s",
+                "ms_per_step": x3["wall"] * 1e3 / x3["steps"],
+                "dtype": "f32 via bf16x3 operands, f32 accumulate (the time-batched products: weight gradients, "
+                         "mask head and its backward; the recurrent chain kernels contract in exact f32 in both)",
+                "bptt_time_batched_weight_gradients_ms": x3["bp"]["batched_ms"],
+                "bptt_sequential_pass_ms": x3["bp"]["chain_ms"],
+                "loss_last": x3["loss_last"],
+                "note": "a second, separately labelled line (VERDICT r5 item 1): `value` above is the native-f32 "
+                        "figure; same model, batch and step"}
     elif train is not None:
         out = {"metric": "STFT frames/sec (fwd+bwd), %d-bin x %d-frame, K=%d unrolls" % (F, T, K),
                "value": None, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
@@ -1162,6 +1296,7 @@ def main():
                      "duration_source": "HIP events around the cell's graph replays, unprofiled "
                                         "run, / T(2K-1) launches",
                      "launch_us_rocprof": prof,
+                     "algorithmic_bytes_per_launch": 4.0 * (F * N + B * (N + F)),
                      "per_kernel_us_plain_launches_with_events": per_kernel},
         "whole_forward_tflops": whole,
         "whole_forward_frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
@@ -1191,10 +1326,15 @@ def main():
         del h_buf, m_buf
         torch.cuda.empty_cache()
         if not a.no_ista:
-            extra["ista_frame_parallel"] = safe(ista_bench, torch, dev, F, N, K, W)
-            extra["mu_inference"] = safe(mu_bench, torch, dev, F, N, W)
+            extra["ista_frame_parallel"] = safe(both_modes, ista_bench, lambda d: d["gemm_launch_us"],
+                                                torch, dev, F, N, K, W)
+            extra["mu_inference"] = safe(both_modes, mu_bench, lambda d: d["ms_per_iteration"], torch, dev, F, N, W)
             extra["stft_front_end"] = safe(stft_bench, torch, dev)
-            extra["dictionary_training"] = safe(snmf_train_bench, torch, dev, F, r)
+            extra["dictionary_training"] = safe(both_modes, snmf_train_bench,
+                                                lambda d: d["ed"]["ms_per_iteration"], torch, dev, F, r)
+            dt = extra["dictionary_training"]
+            if "bf16x3" in dt and "kl" in dt and "kl" in dt["bf16x3"]:
+                dt["speedup_bf16x3_kl"] = dt["kl"]["ms_per_iteration"] / dt["bf16x3"]["kl"]["ms_per_iteration"]
         extra["config1_single_utterance"] = safe(config1_bench, torch, dev)
         if not a.no_slab:
             extra["inference_slab_250"] = safe(slab_bench, torch, dev, F, r, K, T, host_slabs=3)
@@ -1211,6 +1351,7 @@ def main():
             # the same slab for the shipped small model (params_unfolded_snmf_*.yaml: N_fft = 512, r = 100,
             # K = 5): 16 persistent row-tile chains, two per XCD (csrc/cell_gram_persist.h)
             extra["inference_slab_250_shipped_r100"] = safe(slab_bench, torch, dev, 257, 100, 5, 500)
+            extra["inference_ragged_dataset"] = safe(ragged_inference_bench, torch, dev)
             extra["reference_op_graph_dense_kernel"] = safe(dense_graph_bench, torch, dev, F, r, K, B)
         if not a.no_config5:
             extra["config5_shape"] = safe(config5_bench, torch, dev)

@@ -22,7 +22,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # set DRNMF_OFFLOAD_ARCH=gfx950 and rebuild.
 ARCH = ["--offload-arch=" + os.environ.get("DRNMF_OFFLOAD_ARCH", "gfx950:xnack-")]
 # DRNMF_TIMELINE=1: measurement build with s_memtime stamps in the cell kernels (tools/timeline.py)
-FLAGS = ARCH + (["-DDRNMF_TIMELINE"] if os.environ.get("DRNMF_TIMELINE") else []) + os.environ.get("DRNMF_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# DRNMF_MEASURE=1: measurement build -- the ablation arguments / environment aids of DESIGN.md section 8 compiled in
+FLAGS = ARCH + (["-DDRNMF_TIMELINE"] if os.environ.get("DRNMF_TIMELINE") else []) + \
+    (["-DDRNMF_MEASURE"] if os.environ.get("DRNMF_MEASURE") else []) + os.environ.get("DRNMF_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          # scalar kernel arguments arrive preloaded in SGPRs (no kernarg load on the critical path)
          "-mllvm", "-amdgpu-kernarg-preload-count=16",
          # `#pragma unroll` means it: with the default threshold the optimiser refused to unroll the output-tile

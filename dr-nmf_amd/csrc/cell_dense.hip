@@ -486,7 +486,7 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
     // layer-step with 4 / 8 / 16 waves: F=513 N=2000 B=64: 17.6 / 17.2 / 19.3; F=257 N=2000 B=32:
     // 14.9 / 13.8 / 16.8; F=257 N=200 B=32: 4.8 / 5.2 / 6.0
     int nw = (D.Np / 16) * 2 + (d->connect_input ? D.Fp / 16 : 0) >= 128 ? 8 : 4;
-    if (const char* e = tune_env("DRNMF_DENSE_NW")) {   // tuning aid
+    if (const char* e = measure_env("DRNMF_DENSE_NW")) {   // tuning aid
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16) nw = v;
     }

@@ -71,8 +71,10 @@ struct CellAArgs {
     float* xcur;             // [Bp][Fp] packed x_t, republished by the first layer for cell_b
     int B, T, N, Bp, Fp, Np, numA, nchunks, KS, ntail;
     int tail_tile;           // 16-bin tile index of the odd bins (= MFMA tiles of 16 bins)
+#ifdef DRNMF_MEASURE
     int ablate;              // measurement aid (DRNMF_ABLATE_A): bit 0 = dictionary loads read chunk 0,
                              // bit 1 = residual loads read chunk 0 (fp16 mode; results are garbage)
+#endif
     float* Rsave;            // training (all-hidden, fp32, k >= 1): this layer's residual r_k of every
                              // frame, row-major [B*T][Fp] with the columns of every MFMA bin tile in
                              // the saved order (common.h tile_unpermute), for the weight gradients of
@@ -260,9 +262,9 @@ cell_a_kernel(const float* rsrc_, const void* Dn_, const int* t_rd_, int Bp_, in
     auto load_chunk = [&](int i, int g) {      // chunk i of this wave -> slot g
         int c = w + NW_A * i;
         c = c > clast ? clast : c;
-        const int cb = (HALF && (a.ablate & 1)) ? 0 : c;
+        const int cb = HALF ? DRNMF_ABLATED(a.ablate, 1, c) : c;
         if (A16) {
-            const int ca = (a.ablate & 2) ? 0 : c;
+            const int ca = DRNMF_ABLATED(a.ablate, 2, c);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
         } else {
@@ -821,7 +823,7 @@ void* a_func_g(int per_wave, bool first, bool last, bool qred = false) {
     // (8 operand slots measured no better at F=1025, N=8000: 26.9 vs 26.0 us per launch; not instantiated)
     // two groups per wave (F = 513), one row block, fp32: epilogue operand loads behind the first chunk
     bool late = RB == 1 && !HALF && per_wave > 4 && per_wave <= 8;
-    if (const char* e = tune_env("DRNMF_LATE"))   // tuning aid: 0 = never, 2 = whenever instantiated
+    if (const char* e = measure_env("DRNMF_LATE"))   // tuning aid: 0 = never, 2 = whenever instantiated
         late = atoi(e) == 2 ? (RB == 1 && !HALF && per_wave > 2) : (late && atoi(e) != 0);
     if (late && !qred) return a_func<4, KS, RB, AH, HALF, (RB == 1 && !HALF)>(first, last);
     return a_func<4, KS, RB, AH, HALF>(first, last, qred);
@@ -1297,7 +1299,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
     // ---- one frame = 2K-1 launches, as a cached hipGraph -------------------------------------
     // measurement aid: DRNMF_ABLATE=1 launches the same grids but every workgroup exits at once
     // (launch/boundary floor of the frame graph; results are garbage)
-    const bool ablate = tune_env("DRNMF_ABLATE") != nullptr;
+    const bool ablate = measure_env("DRNMF_ABLATE") != nullptr;
     std::vector<uint64_t> key = {
         (uint64_t)d->B, (uint64_t)d->T, (uint64_t)d->F, (uint64_t)d->N, (uint64_t)d->K,
         (uint64_t)d->n_D, (uint64_t)d->return_all_hidden + 2 * (uint64_t)(d->operand_f16 != 0),
@@ -1343,7 +1345,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
 
     // fp16 mode, untied layers: the cell_a launch ahead of a cell_b prefetches that cell_b's dictionary
     // (cell_a_kernel's fifth wave; DRNMF_PF=0 switches it off: measurement aid)
-    const bool pf_on = half && d->n_D == K && K > 1 && !(tune_env("DRNMF_PF") && atoi(tune_env("DRNMF_PF")) == 0);
+    const bool pf_on = half && d->n_D == K && K > 1 && !(measure_env("DRNMF_PF") && atoi(measure_env("DRNMF_PF")) == 0);
     auto make_a = [&](int k) {
         CellAArgs a;
         a.Dn = DnA_of(k);
@@ -1382,7 +1384,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         a.out_width = d->return_all_hidden ? d->N * K : d->N;
         a.out_off = d->return_all_hidden ? k * d->N : 0;
         a.write_out = (d->return_all_hidden || k == K - 1) ? 1 : 0;
+#ifdef DRNMF_MEASURE
         a.ablate = tune_env("DRNMF_ABLATE_A") ? atoi(tune_env("DRNMF_ABLATE_A")) : 0;
+#endif
         a.Rsave = (W.off_rsave != 0 && k >= 1)
                       ? (float*)(ws + W.off_rsave) + (size_t)(k - 1) * d->B * d->T * W.Fp : nullptr;
         // fp16 mode, a cell_b launch behind this one: its dictionary goes into the L2s meanwhile
@@ -1391,7 +1395,7 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         // (the prefetching wave starts ~2 us into the launch: the working waves' first fetches are the
         // latency-critical part.  Delay in units of 512 cycles, us per launch at the config-5 shape:
         // 0 8.58-8.62, 2 8.58, 4 8.55, 8 8.47, 12 8.42, 16 8.54, 24 9.28, 32 10.2; no prefetch 8.82)
-        a.pf_sleep = tune_env("DRNMF_PF_SLEEP") ? atoi(tune_env("DRNMF_PF_SLEEP")) : 10;
+        a.pf_sleep = measure_env("DRNMF_PF_SLEEP") ? atoi(measure_env("DRNMF_PF_SLEEP")) : 10;
         a.x16 = half ? (const f16*)(ws + W.off_xp16) : nullptr;
         if (pf_on && k + 1 < K) a.Dn_pf = DnB_of(k + 1);
         return a;
@@ -1407,7 +1411,9 @@ static int32_t cell_forward_impl(drnmf_handle_t h, const drnmf_cell_desc_t* d, c
         b.logKS = 0;
         while ((1 << b.logKS) < W.KS) ++b.logKS;
         b.nch_ks = W.nch_ks;
+#ifdef DRNMF_MEASURE
         b.ablate = tune_env("DRNMF_ABLATE_B") ? atoi(tune_env("DRNMF_ABLATE_B")) : 0;
+#endif
         b.q_in = (const float*)(ws + W.off_qpart) + (size_t)(k & 1) * W.numA * MAX_TAIL * W.Bp;
         b.qsum = (float*)(ws + W.off_qsum);
         b.numA = W.numA; b.ntail = W.ntail;

@@ -36,7 +36,9 @@ struct CellBArgs {
     float* rpart;            // [KS][Bp][Fp]
     const int* t_rd;
     int Bp, Fp, Np, nft, KS, logKS, nch_ks;   // nch_ks = 16-atom chunks per atom range
+#ifdef DRNMF_MEASURE
     int ablate = 0;          // measurement aid (DRNMF_ABLATE_B), see cell_b_kernel
+#endif
     // odd bins: the per-atom-block partial dot products the producing cell_a / bwd_a launch left
     // ([MAX_TAIL][Bp][numA]) are summed HERE, by the first workgroup of every row tile group, into
     // qsum [MAX_TAIL][Bp]: the consuming launch then loads one value per row instead of numA (at
@@ -66,12 +68,17 @@ struct CellBArgs {
 template <int GB, int RB = 1, int NW = 8, bool HALF = false, bool QRED = false>
 __global__ void __launch_bounds__(64 * NW)
 cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rpart, int Fp_,
-              int Np_, int nft_, int KS_, int nch_ks_, int Bp_, int ablate_,   // 15 dwords: preloaded
+              int Np_, int nft_, int KS_, int nch_ks_, int Bp_, DRNMF_ABLATE_PARAM   // <= 15 dwords: preloaded
               const float* q_in, float* qsum, int numA, int ntail) {
-    // (ablate_: measurement aid DRNMF_ABLATE_B, bit 0 = every dictionary load reads chunk 0, bit 1 =
-    // every activation load reads chunk 0 -- the stream in question then costs nothing; results are garbage)
+    // (-DDRNMF_MEASURE builds only -- ablate_, DRNMF_ABLATE_B: bit 0 = every dictionary load reads chunk 0,
+    // bit 1 = every activation load reads chunk 0; the stream in question then costs nothing, results are garbage)
+#ifdef DRNMF_MEASURE
     const CellBArgs a{Dn_next, h_in, xp, rpart, nullptr, Bp_, Fp_, Np_, nft_, KS_,
                       __builtin_ctz((unsigned)KS_), nch_ks_, ablate_, q_in, qsum, numA, ntail};
+#else
+    const CellBArgs a{Dn_next, h_in, xp, rpart, nullptr, Bp_, Fp_, Np_, nft_, KS_,
+                      __builtin_ctz((unsigned)KS_), nch_ks_, q_in, qsum, numA, ntail};
+#endif
     __shared__ float qred[MAX_TAIL][NW];
     __shared__ __attribute__((aligned(16))) float red[NW * RB * 16 * 17];   // row stride 17: the
     // epilogue threads read (row, bin 4s+q) with row fastest -- stride 16 would be an 8-way bank conflict
@@ -122,7 +129,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
         int c = w + NW * (base + g);
         c = c > clast ? clast : c;
         if (HALF) {
-            const int ca = (ablate_ & 2) ? 0 : c, cb = (ablate_ & 1) ? 0 : c;
+            const int ca = DRNMF_ABLATED(ablate_, 2, c), cb = DRNMF_ABLATED(ablate_, 1, c);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
             bh[g] = *(const f16x8*)(brow16 + 512 * cb);
@@ -200,14 +207,14 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
         for (int g = AW - 1; g < GB; ++g) {
             int c = w + NW * g;
             c = c > clast ? clast : c;
-            bh[g] = *(const f16x8*)(brow16 + 512 * ((ablate_ & 1) ? 0 : c));
+            bh[g] = *(const f16x8*)(brow16 + 512 * DRNMF_ABLATED(ablate_, 1, c));
         }
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
             {
                 int c = w + NW * (i + AW - 1);
                 c = c > clast ? clast : c;
-                const int ca = (ablate_ & 2) ? 0 : c;
+                const int ca = DRNMF_ABLATED(ablate_, 2, c);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
                     ah[(i + AW - 1) % AW][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
@@ -231,7 +238,7 @@ cell_b_kernel(const void* Dn_next, const float* h_in, const float* xp, float* rp
         auto load_slot = [&](int i, int g) {
             int c = w + NW * i;
             c = c > clast ? clast : c;
-            const int ca = (ablate_ & 2) ? 0 : c, cb = (ablate_ & 1) ? 0 : c;
+            const int ca = DRNMF_ABLATED(ablate_, 2, c), cb = DRNMF_ABLATED(ablate_, 1, c);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) ah[g][rb] = *(const f16x8*)(arow16 + rb * astep16 + 512 * ca);
             bh[g] = *(const f16x8*)(brow16 + 512 * cb);
@@ -314,7 +321,10 @@ struct CellBParams {
     void* p[15];
     explicit CellBParams(CellBArgs& b)
         : p{&b.Dn_next, &b.h, &b.xp, &b.rpart, &b.Fp, &b.Np, &b.nft, &b.KS, &b.nch_ks, &b.Bp,
-            &b.ablate, &b.q_in, &b.qsum, &b.numA, &b.ntail} {}
+#ifdef DRNMF_MEASURE
+            &b.ablate,
+#endif
+            &b.q_in, &b.qsum, &b.numA, &b.ntail} {}
 };
 
 __global__ void advance_frame_kernel(int* tptr) { *tptr += 1; }
@@ -574,7 +584,7 @@ void* pick_b_func_rb(int nch_ks) {
         // cell_b launch against 10.4 with 8 and 9.8 with the dictionary operands up front; 16 waves
         // with every operand of every chunk requested up front: 19 us -- the per-CU miss path
         // degrades when it is flooded)
-        if (per_wave > 8 && per_wave <= 32 && !tune_env("DRNMF_NO_ALLB"))
+        if (per_wave > 8 && per_wave <= 32 && !measure_env("DRNMF_NO_ALLB"))
             return (void*)&cell_b_kernel<32, 1, 8, true, QRED>;     // all dictionary operands up front
     }
     return (void*)&cell_b_kernel<8, RB, 8, HALF, QRED>;

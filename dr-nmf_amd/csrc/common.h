@@ -203,6 +203,20 @@ struct drnmf_handle_s {
 // query and the call it sizes therefore see the same values even if the environment changes in
 // between.  Returns NULL when the variable was not set.
 const char* tune_env(const char* name);
+// MEASUREMENT aids exist only in a -DDRNMF_MEASURE build (build.py: DRNMF_MEASURE=1), as
+// the s_memtime stamps exist only in a -DDRNMF_TIMELINE one: the operand-redirecting `ablate` arguments of the
+// chain kernels, empty-kernel graphs, the fifth wave's start delay, per-kernel variant overrides.  The product
+// library carries none of them -- not in a kernel signature, not in an address computation, not as an
+// environment read (profiles/r06_ab_no_aids.txt: the same numbers with and without).
+#ifdef DRNMF_MEASURE
+static inline const char* measure_env(const char* name) { return tune_env(name); }
+#define DRNMF_ABLATE_PARAM int ablate_,
+#define DRNMF_ABLATED(word, bit, c) (((word) & (bit)) ? 0 : (c))
+#else
+static inline const char* measure_env(const char*) { return nullptr; }
+#define DRNMF_ABLATE_PARAM
+#define DRNMF_ABLATED(word, bit, c) (c)
+#endif
 
 // cell_gram_persist.h support (params.hip)
 int32_t persist_check_flag(drnmf_handle_t h);             // DRNMF_ERR_TIMEOUT once after a chain gave up

@@ -385,7 +385,7 @@ inline bool vec_ok(const Operands& g) {
 }
 // N = 128 j + 1: the odd column rides on the full tiles' staging (THIN above)
 inline bool thin_applies(const Operands& g) {
-    const char* te = tune_env("DRNMF_THIN");                  // measurement aid: 0 = a tile column of its own
+    const char* te = measure_env("DRNMF_THIN");                  // measurement aid: 0 = a tile column of its own
     return vec_ok(g) && g.ktail == 0 && g.N > BN && g.N % BN == 1 && !(te && atoi(te) == 0);
 }
 // workgroups of launch(g, ...) = partials a REDUCE epilogue leaves at red_out[0 .. launch_tiles)

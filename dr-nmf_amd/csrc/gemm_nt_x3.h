@@ -466,7 +466,7 @@ inline hipError_t launch_x3(const Operands& g_in, bool thin, const Epi& epi, hip
     g.B3 = scratch;
     g.kt3 = KT;
     int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    const char* xe = getenv("X3_XCD");
+    const char* xe = measure_env("DRNMF_NT_XCD");     // (0: identity order)
     if (tiles >= 64 && !(xe && atoi(xe) == 0)) {          // (a handful of tiles: nothing to share)
         g.per_xcd = (int)((tiles + 7) / 8);
         tiles = (int64_t)g.per_xcd * 8;

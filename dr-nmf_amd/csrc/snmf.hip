@@ -385,7 +385,7 @@ extern "C" int32_t drnmf_ista_forward(drnmf_handle_t h, int64_t n, int32_t F, in
     const int Fm = F - nt;
     // ... riding on the X^ product's full tiles (gemm_nt.h THIN) when there is one of them behind whole
     // 128-column tiles and the operands allow 16-byte loads, else by ista_tail_kernel
-    const char* te = tune_env("DRNMF_THIN");
+    const char* te = measure_env("DRNMF_THIN");
     const bool thin = nt == 1 && Fm % gemm::BN == 0 && N % 4 == 0 && (((uintptr_t)H | (uintptr_t)W) & 15) == 0 &&
                       !(te && atoi(te) == 0);
     gemm::Operands g1{H, W, n, thin ? F : Fm, N, N, N};          // X^ = H . W^T  (contract atoms)
@@ -475,7 +475,7 @@ extern "C" int32_t drnmf_mu_forward(drnmf_handle_t h, int64_t n, int32_t F, int3
     const int Fm = F - nt;
     // (the odd bin's lambda: rides on the product's full tiles when the shape allows, as in
     // drnmf_ista_forward, else mu_tail_kernel)
-    const char* te = tune_env("DRNMF_THIN");
+    const char* te = measure_env("DRNMF_THIN");
     const bool thin = nt == 1 && Fm % gemm::BN == 0 && N % 4 == 0 && (((uintptr_t)H | (uintptr_t)Wn) & 15) == 0 &&
                       !(te && atoi(te) == 0);
     gemm::Operands gl{H, Wn, n, thin ? F : Fm, N, N, N};           // W H  (row layout: H . Wn^T)

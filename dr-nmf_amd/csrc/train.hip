@@ -472,8 +472,8 @@ extern "C" int32_t drnmf_adam_step_flat_counted(drnmf_handle_t h, int64_t n_bloc
     if (n_blocks <= 0 || n_blocks > 0x7fffffff || !blocks || !flat_grad || !flat_m || !flat_v || !scalars4 ||
         !step_in || !step_out || step_in == step_out)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat_counted: bad argument");
-    if (!(lr > 0.0) || decay < 0.0 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
-        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat_counted: lr > 0, decay >= 0, 0 <= beta < 1 required");
+    if (!(lr >= 0.0) || !(decay >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
+        DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat_counted: lr >= 0, decay >= 0, 0 <= beta < 1 required");
     if (clipnorm > 0.f && !sumsq256)
         DRNMF_FAIL(h, DRNMF_ERR_INVALID_ARG, "adam_step_flat_counted: clipnorm > 0 needs the drnmf_sumsq partials");
     if (loss_norm != 0 && loss_norm != 1)
