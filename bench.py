@@ -136,13 +136,16 @@ def both_modes(fn, pick, *args, **kw):
     return res
 
 
-def ragged_inference_bench(torch, dev, F=257, r=1000, K=5, T=2000, n=500, slab=250):
+def ragged_inference_bench(torch, dev, F=257, r=1000, K=5, T=2000, n=2000, slab=250):
     """The reference's inference over a RAGGED data set (enhance.py:1181-1203: every utterance padded to the
     longest, masks cropped afterwards): `predict` as the reference runs it -- every slab at T_max, input order
     -- against the length-aware `predict` (utterances sorted by valid length, each slab at its own length,
     dr-nmf_amd/layers.py).  Lengths as SURVEY.md 8(d) draws them for the training configs: uniform in
-    [0.4 T, T].  The figure is VALID frames per second, host arrays in and out (PCIe-inclusive: never `value`),
-    the shipped r = 1000, K = 5 model at the reference's frame cap (util.py:319)."""
+    [0.4 T, T]; 2000 utterances (CHiME2's test / validation lists hold 1980 / 2460) = eight slabs of 250.  The
+    figure is VALID frames per second, host arrays in and out (PCIe-inclusive: never `value`), the shipped
+    r = 1000, K = 5 model at the reference's frame cap (util.py:319).  The two runs group different utterances into
+    a slab, and a 250-row slab runs as sub-batches with their own kernel variants: equal to fp32 rounding, not bit
+    for bit (bit-equality at one kernel variant: tests/test_gpu_parity.py)."""
     import time
     from drnmf_amd import layers
     N = 2 * r
@@ -171,9 +174,8 @@ def ragged_inference_bench(torch, dev, F=257, r=1000, K=5, T=2000, n=500, slab=2
         if ref is None:
             ref = m
         else:
-            res[name]["bit_equal_to_padded_run_on_valid_frames"] = bool(
-                all(np.array_equal(m[i, :L], ref[i, :L]) for i, L in enumerate(lens)))
-            res[name]["bit_equal_on_all_frames"] = bool(np.array_equal(m, ref))
+            res[name]["max_abs_diff_to_padded_run_on_valid_frames"] = float(
+                max(np.abs(m[i, :L] - ref[i, :L]).max() for i, L in enumerate(lens) if L))
         del m
     res.update({"utterances": n, "T_max": T, "F": F, "N": N, "K": K, "slab": slab, "valid_frames": valid,
                 "mean_length_over_T_max": float(lens.mean() / T),
@@ -1352,6 +1354,10 @@ def main():
             # K = 5): 16 persistent row-tile chains, two per XCD (csrc/cell_gram_persist.h)
             extra["inference_slab_250_shipped_r100"] = safe(slab_bench, torch, dev, 257, 100, 5, 500)
             extra["inference_ragged_dataset"] = safe(ragged_inference_bench, torch, dev)
+            # ... and with the headline's dictionary (F = 513, N = 2000, K = 25): there the GPU, not the host's
+            # staging copies, bounds `predict`
+            extra["inference_ragged_dataset_configs1_model"] = safe(ragged_inference_bench, torch, dev, F=F, r=r, K=K,
+                                                                    T=T, n=1000, slab=250)
             extra["reference_op_graph_dense_kernel"] = safe(dense_graph_bench, torch, dev, F, r, K, B)
         if not a.no_config5:
             extra["config5_shape"] = safe(config5_bench, torch, dev)

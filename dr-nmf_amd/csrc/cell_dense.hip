@@ -520,9 +520,21 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
                 (uint64_t)d->K, (uint64_t)d->connect_input, (uint64_t)d->activation,
                 (uint64_t)d->return_all_hidden + 2 * (uint64_t)(d->operand_f16 != 0), (uint64_t)(uintptr_t)params,
                 (uint64_t)(uintptr_t)h_out, (uint64_t)(uintptr_t)workspace, (uint64_t)frames, (uint64_t)nw};
-            for (auto& g : h->graphs)
-                if (g.key == key) { g.last_stream = stream; *out = g.exec; return DRNMF_OK; }
-            {   // bounded cache: the oldest entry is retired without synchronising (common.h)
+            // (as the fused path, cell_forward.hip: a hit moves to the back -- eviction is least-recently-used --
+            // and is pinned by THIS call, whose sequence number dense_forward_impl advanced)
+            for (size_t gi = 0; gi < h->graphs.size(); ++gi)
+                if (h->graphs[gi].key == key) {
+                    if (gi + 1 != h->graphs.size()) {
+                        GraphEntry hit = h->graphs[gi];
+                        h->graphs.erase(h->graphs.begin() + (ptrdiff_t)gi);
+                        h->graphs.push_back(hit);
+                    }
+                    h->graphs.back().last_stream = stream;
+                    h->graphs.back().pin = h->call_seq;
+                    *out = h->graphs.back().exec;
+                    return DRNMF_OK;
+                }
+            {   // bounded cache: the least recently used entry is retired without synchronising (common.h)
                 const int32_t erc = graph_cache_make_room(h, stream, 24);
                 if (erc) return erc;
             }
@@ -557,10 +569,12 @@ static int32_t dense_forward_impl(drnmf_handle_t h, const drnmf_dense_desc_t* d,
             }
             DRNMF_HIP(h, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
             ge.last_stream = stream;
+            ge.pin = h->call_seq;
             h->graphs.push_back(ge);
             *out = ge.exec;
             return DRNMF_OK;
         };
+        ++h->call_seq;       // (a top-level call: entries pinned by an EARLIER call become evictable again)
         hipGraphExec_t ex = nullptr;
         rc = get_graph(fpg, &ex);
         if (rc) return rc;

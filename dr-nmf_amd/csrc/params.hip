@@ -139,10 +139,18 @@ extern "C" int32_t drnmf_create(drnmf_handle_t* out, int32_t device) {
         for (char* c = bus; *c; ++c)
             if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
         snprintf(path, sizeof(path), "/tmp/drnmf_persist_%s.lock", bus);
-        const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        // (a predictable name in a shared directory: never follow a link another user planted there, and widen
+        // the mode only of a regular, singly linked file this user owns -- ADVICE r5)
+        int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+        struct stat st;
+        if (fd >= 0 && (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_nlink != 1)) {
+            close(fd);
+            fd = -1;
+            errno = ELOOP;
+        }
         if (fd >= 0) {
             // (world-writable whatever the creator's umask: the next user of the box must be able to open it)
-            (void)fchmod(fd, 0666);
+            if (st.st_uid == geteuid()) (void)fchmod(fd, 0666);
             if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
                 h->persist_lock_fd = fd;
                 snprintf(h->persist_reason, sizeof(h->persist_reason), "admitted (holds %s)", path);

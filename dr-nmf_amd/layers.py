@@ -1064,21 +1064,31 @@ class UnfoldedSNMFModel(object):
         float32 numpy.  Exact, and cheap for the reference's layout (padding behind the valid prefix,
         audio_dataset.py:144-161): the first bin decides almost every frame, whole rows are compared only over the
         trailing run that bin leaves undecided."""
-        xs = torch.from_numpy(x)
         n, T, _ = x.shape
-        mv = float(mask_value)
-        first_ok = (xs[:, :, 0] != mv)                                   # frames that are surely valid
-        pos = torch.arange(1, T + 1, dtype=torch.int64).unsqueeze(0)
-        lens = (first_ok * pos).amax(dim=1) if T else torch.zeros((n,), dtype=torch.int64)
+        mv = np.float32(mask_value)
+        first_ok = x[:, :, 0] != mv                                      # frames that are surely valid
+        lens = (first_ok * np.arange(1, T + 1, dtype=np.int64)).max(axis=1) if T else np.zeros((n,), np.int64)
         for i in range(n):
             lo = int(lens[i])
             if lo < T:
-                tail_ok = (xs[i, lo:] != mv).any(dim=-1)                 # undecided frames: every bin
-                if bool(tail_ok.any()):
-                    lens[i] = lo + 1 + int(torch.nonzero(tail_ok)[-1])
-        return lens.numpy()
+                tail = x[i, lo:]
+                # (plain numpy: single-threaded, no thread-pool hand-off per utterance -- 0.7 ms each through
+                # torch on a 256-thread host)
+                if tail.min() != mv or tail.max() != mv:                 # undecided frames: every bin
+                    ok = (tail != mv).any(axis=-1)
+                    lens[i] = lo + 1 + int(np.nonzero(ok)[0][-1])
+        return lens
 
     PREDICT_T_STEP = 32     # slab lengths are rounded up to a multiple of this many frames (graph reuse)
+    HOST_COPY_THREADS = 8   # worker threads of predict's host-side staging copies
+
+    def _host_pool(self):
+        pool = getattr(self, '_host_pool_obj', None)
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self._host_pool_obj = ThreadPoolExecutor(max_workers=self.HOST_COPY_THREADS,
+                                                            thread_name_prefix='drnmf-stage')
+        return pool
 
     def predict(self, x, batch_size=250, verbose=0, lengths=None, length_aware=True):
         """keras Model.predict(x, batch_size): enhance.py's inference loop (1185-1193 validation, 1215-1223
@@ -1151,17 +1161,31 @@ class UnfoldedSNMFModel(object):
         xs, res = torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(out)
         view = lambda buf, b, Ts, w: buf[:b * Ts * w].view(b, Ts, w)
 
+        # Host side of a slab: rows gathered into / scattered out of the pinned staging buffers by a few worker
+        # threads (numpy releases the GIL around its copy loops).  One torch op per row costs ~0.5 ms of thread-pool
+        # hand-off on a 256-thread host, one strided gather per slab runs at a third of memcpy speed -- either way the
+        # host, not the GPU, then bounds the shipped r = 1000 model (tools/ragged_probe.py).
+        x_np, out_np = xs.numpy(), out
+        pool = self._host_pool()
+
+        def rows(fn, b):
+            nw = max(1, min(self.HOST_COPY_THREADS, b))
+            futs = [pool.submit(fn, range(t, b, nw)) for t in range(nw)]
+            for f in futs:
+                f.result()
+
         def collect(s):                              # slab s: pinned staging -> the caller's array
             idx, Ts = slabs[s]
             ev_down[s & 1].synchronize()
-            back = view(pipe['back'][s & 1], len(idx), Ts, Fo)
-            if Ts == T and idx[-1] - idx[0] == len(idx) - 1 and (np.diff(idx) == 1).all():
-                res[int(idx[0]):int(idx[-1]) + 1].copy_(back)
-                return
-            for k, i in enumerate(idx):
-                res[int(i), :Ts].copy_(back[k])
-                if Ts < T:                           # masked frames repeat the last output (K.rnn)
-                    res[int(i), Ts:] = back[k, Ts - 1]
+            back = view(pipe['back'][s & 1], len(idx), Ts, Fo).numpy()
+
+            def put(ks):
+                for k in ks:
+                    i = int(idx[k])
+                    out_np[i, :Ts] = back[k]
+                    if Ts < T:                       # masked frames repeat the last output (K.rnn)
+                        out_np[i, Ts:] = back[k, Ts - 1]
+            rows(put, len(idx))
 
         def send(s):                                 # slab s: the caller's array -> pinned staging -> device
             idx, Ts = slabs[s]
@@ -1169,11 +1193,12 @@ class UnfoldedSNMFModel(object):
             if s >= 2:
                 ev_up[j].synchronize()               # slab s-2 has left this staging buffer
             stage = view(pipe['stage'][j], b, Ts, F)
-            if Ts == T and (np.diff(idx) == 1).all():
-                stage.copy_(xs[int(idx[0]):int(idx[-1]) + 1])
-            else:
-                for k, i in enumerate(idx):
-                    stage[k].copy_(xs[int(i), :Ts])
+            stage_np = stage.numpy()
+
+            def get(ks):
+                for k in ks:
+                    stage_np[k] = x_np[int(idx[k]), :Ts]
+            rows(get, b)
             with torch.cuda.stream(pipe['up']):
                 if s >= 2:
                     pipe['up'].wait_event(ev_comp[j])    # ... and its chain has read xd[j]
@@ -1210,6 +1235,10 @@ class UnfoldedSNMFModel(object):
         """Drop the pinned staging buffers, device slabs and copy streams `predict` / `predict_on_batch` keep
         between calls (they are re-made on the next call)."""
         self._predict_pipe = None
+        pool = getattr(self, '_host_pool_obj', None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+            self._host_pool_obj = None
 
     __call__ = forward
 
@@ -1691,16 +1720,38 @@ class UnfoldedSNMFModel(object):
             torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         xv, yv = validation_data[0], validation_data[1]
         wv = validation_data[2] if len(validation_data) > 2 else None
-        nv = xv.shape[0]
+        nv, Tv = xv.shape[0], xv.shape[1]
         s4 = torch.zeros(4, dtype=torch.float32, device=dev)
         self._drop_stale_fault()
+        # Length-aware, as predict(): a frame behind a sequence's last non-zero weight adds nothing to either
+        # sum (the reference's sample weights are the data mask, enhance.py:1148-1152) and nothing to the
+        # frames before it, so the sequences are taken in order of that length and every mini-batch runs at the
+        # longest one IN IT (rounded up to PREDICT_T_STEP frames).  The same terms are summed; only their
+        # grouping into mini-batches -- fp32 partial sums -- differs from the input-order pass.
+        order, lens = np.arange(nv), None
+        if wv is not None and not bool(getattr(self.cell, 'stateful', False)) and Tv > self.PREDICT_T_STEP:
+            key = (id(wv), tuple(wv.shape))
+            cached = getattr(self, '_val_lens', None)
+            if cached is None or cached[0] != key:
+                wt = wv if isinstance(wv, torch.Tensor) else torch.from_numpy(np.asarray(wv))
+                pos = torch.arange(1, Tv + 1, device=wt.device).unsqueeze(0)
+                cached = (key, ((wt != 0) * pos).amax(dim=1).cpu().numpy())
+                self._val_lens = cached
+            lens = cached[1]
+            order = np.argsort(-lens, kind='stable')
         for lo in range(0, nv, int(batch_size)):
-            b = np.arange(lo, min(nv, lo + int(batch_size)))
-            xb, yb = tt(take(xv, b)), tt(take(yv, b))
-            wb = tt(take(wv, b)) if wv is not None else \
+            b = order[lo:min(nv, lo + int(batch_size))]
+            Tb = Tv
+            if lens is not None:
+                step = self.PREDICT_T_STEP
+                Tb = int(min(Tv, max(1, -(-int(lens[b].max()) // step) * step)))
+            cut = (lambda a: a) if Tb == Tv else (lambda a: a[:, :Tb].contiguous() if isinstance(a, torch.Tensor)
+                                                  else np.ascontiguousarray(a[:, :Tb]))
+            xb, yb = tt(cut(take(xv, b))), tt(cut(take(yv, b)))
+            wb = tt(cut(take(wv, b))) if wv is not None else \
                 torch.ones(xb.shape[:2], dtype=torch.float32, device=dev)
             s4[:2].add_(self._validation_sums(xb, yb, wb))
-            s4[2] += float(xb.shape[0] * xb.shape[1])
+            s4[2] += float(len(b) * Tv)          # (frames of the PADDED batch: loss_norm='keras204' divides by them)
         ops.status_take(s4[3:])
         dp.allreduce_sum_(s4)
         sse, cnt, rows, fault = s4.tolist()

@@ -324,10 +324,14 @@ def main(out_path=None):
         out['wav_%s_read' % tag] = ut['wavread'](path)
     shutil.rmtree(tmpd)
 
+    # what produced the bits: exp / fft results may differ in the last place between builds of numpy / scipy
+    import scipy
+    out['meta_versions'] = np.array(['python %d.%d' % sys.version_info[:2], 'numpy ' + np.__version__,
+                                     'scipy ' + scipy.__version__])
     out_path = out_path or os.path.join(HERE, 'reference_numpy_golden.npz')
     np.savez_compressed(out_path, **out)
     print('wrote', out_path, len(out), 'arrays')
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

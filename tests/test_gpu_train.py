@@ -580,6 +580,23 @@ def test_fused_adam_launch_matches_numpy_adam(dev, opts):
     np.testing.assert_allclose(model._vflat.cpu().numpy(), v, rtol=4e-4, atol=1e-12)
 
 
+def test_fit_validation_pass_is_length_aware(dev):
+    """fit()'s validation pass takes the sequences in order of their last non-zero weight and runs every
+    mini-batch at the longest one in it (layers._validate, as predict does): the same terms, another grouping
+    -- the value equals test_on_batch over the padded set to fp32 summation order."""
+    B, T = 9, 80
+    model, P, wmask = _setup(B, T, 21, 6, 2, ("log_D", "log_alph"))
+    rng = np.random.default_rng(8)
+    X, Y, w = P["X"].copy(), P["Y"].copy(), np.ones((B, T), np.float32)
+    for i, L in enumerate(rng.integers(16, T + 1, size=B)):
+        X[i, L:], Y[i, L:], w[i, L:] = -1.0, -1.0, 0.0
+    for loss_norm in ("masked_mean", "keras204"):
+        model.compile(lr=0.0, loss_norm=loss_norm)
+        hist = model.fit(X, Y, sample_weight=w, batch_size=4, epochs=1, shuffle=False, validation_data=(X, Y, w))
+        whole = model.test_on_batch(X, Y, w)
+        assert abs(hist["val_loss"][0] - whole) <= 2e-6 * abs(whole), (loss_norm, hist["val_loss"][0], whole)
+
+
 def test_fit_validates_in_mini_batches(dev):
     """fit() evaluates validation_data in mini-batches of batch_size (Keras' test loop; enhance.py:1152-1157)
     with the sums accumulated on the device: the value equals test_on_batch over the whole set."""

@@ -9,23 +9,40 @@ from oracle import drnmf_oracle as O
 
 
 # ------------------------------------------------------------------ golden vectors (reference)
-@pytest.mark.filterwarnings("ignore::DeprecationWarning", "ignore::SyntaxWarning")   # (the reference's py2 string escapes)
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference lives in the build container only")
 def test_golden_file_is_what_the_reference_produces_today(golden, tmp_path):
-    """Where the reference is present: run the committed generator again and compare every array with the
-    committed fixture, bit for bit (the fixture is data produced by the reference's own code, nothing else)."""
-    import importlib.util
+    """Where the reference is present: run the committed generator again -- in a process of its own, it exec()s
+    function bodies taken from the reference tree -- and compare every array with the committed fixture (the
+    fixture is data produced by the reference's own code, nothing else).  Bit for bit under the toolchain that
+    wrote the fixture; a different numpy / scipy build may differ in the last place of exp / fft results, and a
+    Python without lib2to3 (3.13+) cannot convert the reference at all: those are reasons to SKIP, not failures
+    of the library."""
+    import subprocess
+    import sys
+    import scipy
+    if subprocess.run([sys.executable, "-c", "import lib2to3"], capture_output=True).returncode != 0:
+        pytest.skip("no lib2to3 in this Python: the reference's Python-2 sources cannot be converted")
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")
-    spec = importlib.util.spec_from_file_location("make_golden", here)
-    mg = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mg)
     out = str(tmp_path / "again.npz")
-    mg.main(out)
+    run = subprocess.run([sys.executable, here, out], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr[-2000:]
     again = np.load(out)
     assert sorted(again.files) == sorted(golden.files)
+    same_tools = list(again["meta_versions"]) == list(golden["meta_versions"])
     for k in golden.files:
-        assert again[k].dtype == golden[k].dtype and np.array_equal(again[k], golden[k]), k
-
+        if k == "meta_versions":
+            continue
+        assert again[k].dtype == golden[k].dtype and again[k].shape == golden[k].shape, k
+        if np.array_equal(again[k], golden[k]):
+            continue
+        if same_tools or not np.issubdtype(golden[k].dtype, np.floating):
+            raise AssertionError("%s differs from the committed fixture" % k)
+        # another numpy / scipy build: a few units in the last place, nothing more
+        np.testing.assert_allclose(again[k], golden[k], rtol=8 * np.finfo(golden[k].dtype).eps,
+                                   atol=8 * np.finfo(golden[k].dtype).tiny, err_msg=k)
+    if not same_tools:
+        pytest.skip("fixture written by %s, this is %s: compared to 8 ulp instead of bit for bit"
+                    % (list(golden["meta_versions"]), list(again["meta_versions"])))
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
