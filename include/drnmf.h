@@ -10,7 +10,9 @@
  * Conventions
  *  - every pointer is a DEVICE pointer unless its name ends in _host; the caller owns all memory;
  *    the library allocates nothing persistent except the opaque handle (error string, cached
- *    hipGraph executables);
+ *    hipGraph executables) and -- only after drnmf_set_matrix_mode(h, DRNMF_MATRIX_BF16X3) -- one device
+ *    scratch buffer per stream for the split Bt operand of the frame-parallel products (16 MB, grown to the
+ *    largest such operand seen; freed by drnmf_destroy);
  *  - every call enqueues on the caller's `stream` (a hipStream_t passed as void*), never
  *    synchronises the device (exceptions, named where they are declared: drnmf_cell_profile, and
  *    drnmf_comm_init, which is a rendezvous), and returns a status (0 = OK, <0 = error; text via
