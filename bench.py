@@ -1364,9 +1364,9 @@ def main():
         if not a.no_train:
             del X
             torch.cuda.empty_cache()
-            extra["train_step_configs2"] = safe(train_bench, torch, dev)
+            extra["train_step_configs2"] = safe(both_modes, train_bench, lambda d: d["ms_per_step"], torch, dev)
             # the other shipped dictionary size (params_unfolded_snmf_ea1e7d48: r = 100, K = 5)
-            extra["train_step_configs2_r100"] = safe(train_bench, torch, dev,
+            extra["train_step_configs2_r100"] = safe(both_modes, train_bench, lambda d: d["ms_per_step"], torch, dev,
                                                      shape=(32, 500, 257, 100, 5))
     if world > 1 and not a.no_extras:
         # ---- the 8-GPU configurations of BASELINE.json (configs[3], configs[4]): every rank takes part ----

@@ -292,9 +292,14 @@ extern "C" int32_t drnmf_destroy(drnmf_handle_t h) {
     if (h->persist_flag) (void)hipHostFree(h->persist_flag);
     if (h->persist_lock_fd >= 0) close(h->persist_lock_fd);      // (releases the flock)
     if (!h->x3_scratch.empty() || !h->x3_parked.empty()) {
+        // (work that reads the scratch may still be in flight on THIS handle's device, which need not be current)
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (h->device >= 0 && cur != h->device) (void)hipSetDevice(h->device);
         (void)hipDeviceSynchronize();
         for (auto& s : h->x3_scratch) (void)hipFree(s.ptr);
         for (void* p : h->x3_parked) (void)hipFree(p);
+        if (cur >= 0 && cur != h->device) (void)hipSetDevice(cur);
     }
     delete h;
     return DRNMF_OK;

@@ -31,6 +31,17 @@ stats fwd "$B" --forward-only --steps 1 --warmup 1 --no-cpu-baseline --no-extras
 stats ista "$ROOT/tools/ista_profile.py" 32768 513 2000 25
 stats c5 "$ROOT/tools/c5_profile.py" 16
 stats train_c3 "$ROOT/tools/train_profile.py" 32 500 257 1000 5 3
+# round 6: the same two workloads with the frame-parallel products in the split-operand mode (DRNMF_MATRIX_BF16X3)
+stats ista_x3 "$ROOT/tools/ista_profile.py" 32768 513 2000 25 bf16x3
+stats snmf_train_x3 "$ROOT/tools/snmf_profile.py" 32768 513 1000 20 both bf16x3
+# ... the config-5 shape with fp16 operands ALONE (bench.py's config5_shape.f16.roofline.frac_rocprof reads this file)
+stats c5_f16 "$ROOT/tools/profile_shape.py" 64 16 1025 4000 50 f16
+# ... error of the mode against fp64 beside the exact-fp32 mode's, and the speed check
+python3 "$ROOT/tools/x3_error_table.py" > "$OUT/x3_error_table.md" 2> "$OUT/x3_error_table.err"
+python3 "$ROOT/tools/x3_check.py" > "$OUT/x3_check.txt" 2>&1
+# ... SQ counters of the ISTA products in both modes (clock, matrix-pipe busy, LDS conflicts)
+( cd "$ROOT" && bash tools/x3_pmc.sh "$TAG/x3pmc" "f32 bf16x3" > "$OUT/x3_pmc.txt" 2>&1 )
+rm -rf "$OUT/x3pmc"
 # dictionary training (sparse_nmf_gpu.m:210-298), 20 iterations each of KL and ED on 32768 x 513 x 1000
 stats snmf_train "$ROOT/tools/snmf_profile.py" 32768 513 1000 20
 python3 "$ROOT/tools/snmf_profile.py" 32768 513 1000 20 > "$OUT/snmf_train_unprofiled.txt" 2>&1
@@ -84,15 +95,13 @@ python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_b250_summary.json" "$OUT/pmc
 # 5c. config 5 (F=1025, N=8000, K=50 untied, B=64, fp16 operands), 8 frames: L2-side traffic of the two cell kernels with
 #     and without cell_a's prefetching wave (FETCH_SIZE counts Infinity-Cache hits too: it shows how often a layer's
 #     dictionary CROSSES the fabric, not where from)
-for pf in 1 0; do
-  export DRNMF_PF=$pf
+for pf in 1; do      # (DRNMF_PF=0 is a -DDRNMF_MEASURE aid since round 6: the shipped configuration only)
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_c5_fetch_pf$pf" -o p -- python3 "$ROOT/tools/profile_shape.py" 64 8 1025 4000 50 f16 \
       > /dev/null 2> "$OUT/pmc_c5_fetch_pf$pf.err"
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d "$OUT/pmc_c5_write_pf$pf" -o p -- python3 "$ROOT/tools/profile_shape.py" 64 8 1025 4000 50 f16 \
       > /dev/null 2> "$OUT/pmc_c5_write_pf$pf.err"
   python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/pmc_c5_pf${pf}_summary.json" "$OUT/pmc_c5_fetch_pf$pf" "$OUT/pmc_c5_write_pf$pf"
 done
-unset DRNMF_PF
 # 6. the persistent chains of the shipped r = 100 training step: wave-cycle split and matrix-pipe time
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_r100" -o p -- python3 "$ROOT/tools/train_profile.py" 32 500 257 100 5 3 \

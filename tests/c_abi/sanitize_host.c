@@ -168,6 +168,18 @@ static void refused_calls(drnmf_handle_t h) {
     REFUSED(h, drnmf_adam_step_flat(h, 1, NULL, &f, &f, &f, &f, NULL, 1e-3f, .9f, .999f, 1e-8f, 0.f, 0, 0.f, NULL, NULL));
     REFUSED(h, drnmf_adam_step_flat(h, 1, &blk, &f, &f, &f, &f, NULL, 1e-3f, .9f, .999f, 1e-8f, 1.f, 0, 0.f, NULL, NULL));
     REFUSED(h, drnmf_adam_step_flat(h, 1, &blk, &f, &f, &f, &f, NULL, 1e-3f, .9f, .999f, 1e-8f, 0.f, 5, 0.f, NULL, NULL));
+    /* the counted form: step_in / step_out must be two different device words; the optimiser constants are checked */
+    REFUSED(h, drnmf_adam_step_flat_counted(h, 1, &blk, &f, &f, &f, &f, NULL, 1e-3, 0., .9, .999, 1e-8f, 0.f, 0, 0.f, &f, &f, NULL, NULL));
+    REFUSED(h, drnmf_adam_step_flat_counted(h, 1, &blk, &f, &f, &f, &f, NULL, 1e-3, 0., .9, .999, 1e-8f, 0.f, 0, 0.f, NULL, &f, NULL, NULL));
+    { float f2 = 0.f;
+      REFUSED(h, drnmf_adam_step_flat_counted(h, 1, &blk, &f, &f, &f, &f, NULL, -1., 0., .9, .999, 1e-8f, 0.f, 0, 0.f, &f, &f2, NULL, NULL));
+      REFUSED(h, drnmf_adam_step_flat_counted(h, 1, &blk, &f, &f, &f, &f, NULL, 1e-3, 0., 1.5, .999, 1e-8f, 0.f, 0, 0.f, &f, &f2, NULL, NULL));
+      REFUSED(h, drnmf_adam_step_flat_counted(h, 1, &blk, &f, &f, &f, &f, NULL, 1e-3, 0., .9, .999, 1e-8f, 1.f, 0, 0.f, &f, &f2, NULL, NULL)); }
+    /* matrix mode of the handle */
+    CHECK(drnmf_get_matrix_mode(h) == DRNMF_MATRIX_F32 && drnmf_get_matrix_mode(NULL) < 0);
+    REFUSED(h, drnmf_set_matrix_mode(h, 7));
+    CHECK(drnmf_set_matrix_mode(h, DRNMF_MATRIX_BF16X3) == DRNMF_OK && drnmf_get_matrix_mode(h) == DRNMF_MATRIX_BF16X3);
+    CHECK(drnmf_set_matrix_mode(h, DRNMF_MATRIX_F32) == DRNMF_OK && drnmf_set_matrix_mode(NULL, 0) < 0);
     REFUSED(h, drnmf_ista_forward(h, 10, 65, 32, 3, 0, 2.f, 1.f, 8.f, nf, nf, nf, NULL, 0, NULL));
     REFUSED(h, drnmf_ista_forward(h, 10, 65, 32, 3, 7, 2.f, 1.f, 8.f, &f, &f, &f, aligned, 1 << 20, NULL));
     REFUSED(h, drnmf_mu_forward(h, 10, 65, 32, 5, 2.f, .1f, nf, nf, nf, nf, nf, NULL, 0, NULL));

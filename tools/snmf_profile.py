@@ -1,5 +1,5 @@
 """Dictionary training (sparse_nmf_gpu.m:210-298) at an arbitrary shape, for rocprofv3 --kernel-trace --stats:
-    python tools/snmf_profile.py n F r iters [kl|ed|both]
+    python tools/snmf_profile.py n F r iters [kl|ed|both] [f32|bf16x3]
 One warm-up pair of iterations, then `iters` timed multiplicative-update iterations (W and H) per divergence."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +8,7 @@ import __graft_entry__ as G; G.build()
 from drnmf_amd import ops
 n, F, r, iters = [int(v) for v in sys.argv[1:5]]
 which = sys.argv[5] if len(sys.argv) > 5 else 'both'
+ops.set_matrix_mode(sys.argv[6] if len(sys.argv) > 6 else 'f32')
 dev = torch.device('cuda:0')
 g = torch.Generator(device=dev); g.manual_seed(6)
 V = torch.rand((n, F), generator=g, device=dev) ** 2 + 1e-3
