@@ -98,6 +98,45 @@ int main(int argc, char** argv) {
         if (fabs((double)expect[i]) > maxref) maxref = fabs((double)expect[i]);
     }
     printf("version %d  max_abs_err %.6e  max_ref %.6e\n", (int)drnmf_version(), maxerr, maxref);
+
+    /* The matrix mode of the handle (round 6): frame-parallel ISTA (enhance.py:402-418) on the same frames with
+     * the dictionary of layer 0, in the exact-fp32 mode and with split bf16 operands -- the two agree to fp32
+     * rounding, and the mode is a property of the handle that a plain-C host can switch. */
+    {
+        const int64_t n = (int64_t)B * T;
+        float* Wh = (float*)malloc(sizeof(float) * F * N);
+        float* Xh = (float*)malloc(sizeof(float) * n * F);
+        for (size_t i = 0; i < (size_t)F * N; ++i) Wh[i] = expf(log_D[i]);
+        for (size_t i = 0; i < (size_t)n * F; ++i) Xh[i] = x[i] < 0.f ? 0.f : x[i];    /* (padding frames: zeros) */
+        float* dW = (float*)to_device(Wh, sizeof(float) * F * N);
+        float* dX = (float*)to_device(Xh, sizeof(float) * n * F);
+        const size_t ib = drnmf_ista_workspace_bytes(n, F, N);
+        void* iws = to_device(NULL, ib);
+        float* res[2];
+        for (int mode = 0; mode < 2; ++mode) {
+            float* H0 = (float*)malloc(sizeof(float) * n * N);
+            for (size_t i = 0; i < (size_t)n * N; ++i) H0[i] = 0.1f + 0.001f * (float)(i % 97);
+            float* dH = (float*)to_device(H0, sizeof(float) * n * N);
+            if (drnmf_set_matrix_mode(h, mode ? DRNMF_MATRIX_BF16X3 : DRNMF_MATRIX_F32) != DRNMF_OK ||
+                drnmf_get_matrix_mode(h) != (mode ? DRNMF_MATRIX_BF16X3 : DRNMF_MATRIX_F32) ||
+                drnmf_ista_forward(h, n, F, N, 3, DRNMF_DIV_ED, 2.f, 0.3f, (float)N / 4.f, dX, dW, dH, iws, ib,
+                                   stream) != DRNMF_OK) {
+                fprintf(stderr, "matrix mode %d: %s\n", mode, drnmf_last_error(h));
+                return 2;
+            }
+            CHECK_HIP(hipStreamSynchronize(stream));
+            CHECK_HIP(hipMemcpy(H0, dH, sizeof(float) * n * N, hipMemcpyDeviceToHost));
+            res[mode] = H0;
+        }
+        double md = 0.0, mr = 0.0;
+        for (size_t i = 0; i < (size_t)n * N; ++i) {
+            const double e = fabs((double)res[0][i] - (double)res[1][i]);
+            if (e > md) md = e;
+            if (fabs((double)res[0][i]) > mr) mr = fabs((double)res[0][i]);
+        }
+        printf("matrix_mode f32_vs_bf16x3 max_rel_diff %.6e\n", mr > 0 ? md / mr : 0.0);
+        if (drnmf_set_matrix_mode(h, DRNMF_MATRIX_F32) != DRNMF_OK) return 2;
+    }
     drnmf_destroy(h);
     return 0;
 }

@@ -1015,6 +1015,10 @@ def test_plain_c_host_program_over_the_c_abi(dev, tmp_path):
     assert out.returncode == 0, out.stderr
     err, mx = (float(out.stdout.split(k)[1].split()[0]) for k in ("max_abs_err", "max_ref"))
     assert mx > 0 and err <= H_TOL * mx, out.stdout
+    # ... and the same host switches the handle's matrix mode (drnmf_set_matrix_mode): frame-parallel ISTA in the
+    # exact-fp32 and the split-operand mode agree to fp32 rounding
+    diff = float(out.stdout.split("max_rel_diff")[1].split()[0])
+    assert diff <= 2e-5, out.stdout
 
 
 def test_graph_cache_key_carries_the_layout_choices(dev, monkeypatch):
