@@ -23,11 +23,12 @@
 //      32 rows x one piece) and both kinds of staging writes conflict-free.  48 KB per k-tile, ONE buffer,
 //      two workgroups per CU: one's store phase between its two barriers runs under the other's MFMAs.
 //
-// History of the numbers (frame-parallel ISTA, 32768 x 513 x 2000, TFLOP/s fp32-equivalent; fp32 pipe 117):
+// History of the numbers (frame-parallel ISTA, 32768 x 513 x 2000, TFLOP/s fp32-equivalent; fp32 pipe 117-120):
 // both operands split in the kernel behind the MFMAs 147, the same split interleaved with the MFMAs 149 (PMC:
 // matrix pipes 55 % busy at 1.73 GHz -- the chip clocks down under the VALU + MFMA load -- and a third of
-// the LDS cycles bank conflicts of the padded 208-byte rows), XCD-aware tile order +-0
-// (profiles/r06_x3_steps.txt).
+// the LDS cycles bank conflicts of the padded 208-byte rows), XCD-aware tile order +-0, Bt pre-split + swizzled
+// unpadded rows 180, priority in the MFMA phase 186 (pipes 64 % busy at 1.76 GHz): profiles/r06_x3_steps.txt,
+// profiles/r06_x3_pmc.txt.
 #pragma once
 
 #include <utility>

@@ -1158,7 +1158,7 @@ class UnfoldedSNMFModel(object):
         main = torch.cuda.current_stream(dev)
         ev = lambda: [torch.cuda.Event(), torch.cuda.Event()]
         ev_up, ev_comp, ev_down = ev(), ev(), ev()
-        xs, res = torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(out)
+        xs = torch.from_numpy(np.ascontiguousarray(x))
         view = lambda buf, b, Ts, w: buf[:b * Ts * w].view(b, Ts, w)
 
         # Host side of a slab: rows gathered into / scattered out of the pinned staging buffers by a few worker

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the frame-parallel ISTA: matrix modes x XCD-aware tile map (unprofiled, then kernel-trace stats)
+# A/B of the frame-parallel ISTA: matrix modes x XCD-aware tile map (unprofiled, then kernel-trace stats).
+# DRNMF_NT_XCD is a measurement aid: build with DRNMF_MEASURE=1 for the identity-order arm to take effect.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${1:-x3ab}
