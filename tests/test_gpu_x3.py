@@ -157,3 +157,56 @@ def test_gradients_match_autograd_in_x3_mode(dev, x3, cfg):
 def test_model_predict_in_x3_mode(dev, x3):
     import test_gpu_parity as P
     P.test_model_predict_on_batch_matches_oracle(dev, False)
+
+
+def test_fuzz_frame_parallel_products_in_both_modes(dev):
+    """Seeded random shapes on both sides of every tile boundary of gemm_nt_x3.h / gemm_tn_x3.h (128-row / 128-column
+    tiles, 32-slot k-tiles, the 2^k + 1 rider column, 1-2 odd contraction columns, operands that are not 16-byte
+    aligned and fall back to the fp32 kernels): frame-parallel ISTA (two NT products per iteration) and dictionary
+    training (NT + TN products, grid-wide objective sums) in the split-operand mode against the exact-fp32 mode."""
+    from drnmf_amd import ops
+    rng = np.random.default_rng(606)
+    g = torch.Generator(device=dev)
+    prev = ops.get_matrix_mode(dev)
+    try:
+        for it in range(40):
+            n = int(rng.choice([1, 5, 127, 128, 129, 255, 300, 517, 1000]))
+            F = int(rng.choice([4, 17, 31, 32, 33, 64, 65, 127, 129, 130, 256, 257, 260]))
+            N = int(rng.choice([4, 12, 31, 36, 64, 100, 128, 129, 200, 260, 516]))
+            K = int(rng.integers(1, 4))
+            div = ["ed", "kl", "beta"][int(rng.integers(0, 3))]
+            g.manual_seed(1000 + it)
+            W = torch.rand((F, N), generator=g, device=dev) ** 2 + 1e-3
+            W = W / (W * W).sum(0, keepdim=True).sqrt()
+            X = (torch.rand((n, N), generator=g, device=dev) < 0.3) * torch.rand((n, N), generator=g, device=dev) @ W.t() + 0.05
+            H0 = torch.rand((n, N), generator=g, device=dev) * 0.2 + 0.05
+            out = {}
+            for mode in ("f32", "bf16x3"):
+                ops.set_matrix_mode(mode, dev)
+                out[mode] = ops.ista_forward(X, W, H0.clone(), 0.1, 4.0 * N, K, divergence=div, beta=1.5)
+            torch.cuda.synchronize()
+            d = (out["f32"] - out["bf16x3"]).abs().max().item() / max(out["f32"].abs().max().item(), 1e-30)
+            assert torch.isfinite(out["bf16x3"]).all() and d <= 2e-5, (dict(n=n, F=F, N=N, K=K, div=div, it=it), d)
+        for it in range(12):
+            n = int(rng.choice([64, 129, 500, 1030]))
+            F = int(rng.choice([33, 64, 65, 129, 257]))
+            r = int(rng.choice([4, 20, 36, 100, 130]))
+            beta = float(rng.choice([1.0, 2.0]))
+            g.manual_seed(2000 + it)
+            V = torch.rand((n, F), generator=g, device=dev) ** 2 + 1e-3
+            W0 = torch.rand((F, r), generator=g, device=dev)
+            H0 = torch.rand((n, r), generator=g, device=dev)
+            res = {}
+            for mode in ("f32", "bf16x3"):
+                ops.set_matrix_mode(mode, dev)
+                tr = ops.SnmfTrainer(V, W0.clone(), H0.clone(), beta=beta)
+                log = torch.zeros((3, 2), dtype=torch.float32, device=dev)
+                for i in range(3):
+                    tr.step(0.5, None, True, obj=log[i])
+                torch.cuda.synchronize()
+                res[mode] = (tr.W.clone(), tr.H.clone(), log.clone())
+            for a, b, tol in zip(res["f32"], res["bf16x3"], (5e-5, 5e-5, 5e-5)):
+                d = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30)
+                assert d <= tol, (dict(n=n, F=F, r=r, beta=beta, it=it), d)
+    finally:
+        ops.set_matrix_mode(prev, dev)
