@@ -72,9 +72,10 @@ def test_error_against_fp64_is_the_fp32_pipes(dev, n, F, N, K, alph, h0):
     """Frame-parallel ISTA (enhance.py:402-418) in both modes against fp64 on the same inputs: max and rms error
     within 2x the fp32 pipe's own (on most inputs the mode is the MORE accurate one: six roundings per 16
     contraction steps instead of sixteen).  One documented exception: an operand whose entries are all the SAME
-    value that is not a bf16 number (H0 = 0.1 everywhere) -- every element then has the same split, the
-    accumulate roundings of the bf16 MFMA (biased low, tools/x3_bias.py) add up coherently instead of averaging
-    out, and the residual X - H W^T amplifies it: rms 3.5x the fp32 pipe's after ONE iteration (6.8e-7 against
+    value that is not a bf16 number (H0 = 0.1 everywhere) -- every element then has the same split with the same
+    NEGATIVE mid plane, the alignment of those one-signed correction products into the large accumulator adds up
+    coherently instead of averaging out (with bf16-exact operands the mode is unbiased: profiles/r06_x3_steps.txt),
+    and the residual X - H W^T amplifies it: rms 3.5x the fp32 pipe's after ONE iteration (6.8e-7 against
     1.9e-7 of max |H|; the maximum stays within 1.5x, and the iteration contracts it: equal from K = 10 on)."""
     from drnmf_amd import ops
     X, W = _ista_problem(n, F, N, 5, dev)

@@ -44,6 +44,8 @@ struct EpiUpd {    // the shape of EpiIstaUpdate: read-modify-write of the outpu
 int main(int argc, char** argv) {
     const int64_t M = argc > 1 ? atoll(argv[1]) : 32768;
     const bool const_a = argc > 2;        // every A value 0.1f: the worst case for correlated rounding
+    const bool bf16_exact = argc > 3;     // ... A = 13/128 and B rounded to bf16: only the (hi, hi) product is non-zero,
+                                          //     what remains against fp64 is the bf16 MFMA's own accumulation
     const int reps = 10;
     struct Shape { int N, K, ktail; bool upd; const char* name; };
     const Shape shapes[] = {{513, 2000, 0, false, "X^ = H W^T (N = 513 thin, K = 2000)"},
@@ -56,8 +58,11 @@ int main(int argc, char** argv) {
     for (const Shape& s : shapes) {
         const int lda = (s.K + s.ktail + 3) / 4 * 4, ldb = lda, ldc = (s.N + 3) / 4 * 4;
         std::vector<float> hA((size_t)M * lda), hB((size_t)(s.N + 1) * ldb);
-        for (auto& v : hA) { const float u = U(rng); v = const_a ? 0.1f : (u < 0.3f ? 0.f : u * u * 3.f); }
-        for (auto& v : hB) { const float u = U(rng); v = u * u * u * u; }
+        for (auto& v : hA) { const float u = U(rng); v = bf16_exact ? 0.1015625f : const_a ? 0.1f : (u < 0.3f ? 0.f : u * u * 3.f); }
+        for (auto& v : hB) {
+            const float u = U(rng); v = u * u * u * u;
+            if (bf16_exact) { unsigned b; memcpy(&b, &v, 4); b = (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u; memcpy(&v, &b, 4); }
+        }
         float *A, *B, *C0, *C1;
         CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&B, hB.size() * 4));
         CK(hipMalloc(&C0, (size_t)M * ldc * 4)); CK(hipMalloc(&C1, (size_t)M * ldc * 4));

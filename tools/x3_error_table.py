@@ -87,8 +87,9 @@ for name, r in rows:
     print('| %s | %.2e | %.2e | %.2e | %.2e | %.2f | %.2f |' % (name, a[0], a[1], b[0], b[1], b[0] / a[0], b[1] / a[1]))
 print('''
 The one row above 2x: an operand whose entries are all the SAME non-bf16 value (H0 = 0.1 everywhere) after ONE iteration --
-every element then has the same three-plane split, the accumulate roundings of v_mfma_f32_32x32x16_bf16 (biased low:
-tools/x3_bias.py, mean error / rms error = -0.9) add up coherently instead of averaging out, and the residual X - H W^T
-amplifies them.  The maximum error stays within 1.5x, the iteration contracts it (equal from K = 10 on), and with any
+every element then has the same three-plane split with the same negative mid plane, the alignment of those one-signed
+correction products into the large accumulator adds up coherently instead of averaging out (tools/x3_bias.py: mean / rms
+error = 1.0; with bf16-exact operands the mode is unbiased, profiles/r06_x3_steps.txt), and the residual X - H W^T
+amplifies it.  The maximum error stays within 1.5x, the iteration contracts it (equal from K = 10 on), and with any
 spread in the operand the mode is the MORE accurate of the two (six roundings per 16 contraction steps instead of sixteen).
 Planes by truncation instead of round-to-nearest were measured and are worse (profiles/r06_x3_steps.txt).''')
